@@ -1,0 +1,74 @@
+/*
+ * oracle.h -- C interface of the CPU oracles (TEST INFRASTRUCTURE ONLY, see rm2_oracle.c / itemsim_oracle.c).
+ * Loaded with ctypes by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg; never by the product path.
+ */
+#ifndef FILMYOU_ORACLE_H
+#define FILMYOU_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* keys mirror the Hadoop Configuration keys of M/rmrecommender/RMRecommenderDriver.java:49-120 */
+typedef struct {
+    double lambda;                      /* "lambda" */
+    int32_t number_of_items;            /* "numberOfItems" (global, used only in pvpi -- quirk Q6) */
+    int32_t number_of_recommendations;  /* "numberOfRecommendations" */
+    int32_t filter_users;               /* "filterUsers": users with id < this get no list */
+    int32_t number_of_clusters;         /* "numberOfClusters" */
+    int32_t n_threads;                  /* OpenMP threads over the target users of a cluster (1 = serial reducer) */
+} rm2o_params;
+
+typedef struct rm2o_result rm2o_result;
+
+/* COO ratings (raw ids), clustering pairs (may be empty: every user -> cluster 0), optional clusteringCount[K]. */
+int rm2o_run(const rm2o_params* P, int64_t nnz, const int32_t* user, const int32_t* item, const float* score,
+             int64_t n_map, const int32_t* map_user, const int32_t* map_cluster, const int32_t* cluster_count,
+             rm2o_result** out);
+const char* rm2o_last_error(void);
+void rm2o_free(rm2o_result*);
+/* recommendations: grouped by cluster asc, user id asc, then best first (ties: ascending item id) */
+int64_t rm2o_n_recs(const rm2o_result*);
+const int32_t* rm2o_rec_user(const rm2o_result*);
+const int32_t* rm2o_rec_item(const rm2o_result*);
+const int32_t* rm2o_rec_cluster(const rm2o_result*);
+const float* rm2o_rec_score(const rm2o_result*);
+/* rm2/userSum and rm2/itemColl equivalents, ascending raw id */
+int64_t rm2o_n_users(const rm2o_result*);
+const int32_t* rm2o_user_id(const rm2o_result*);
+const double* rm2o_user_sum(const rm2o_result*);
+int64_t rm2o_n_items(const rm2o_result*);
+const int32_t* rm2o_item_id(const rm2o_result*);
+const double* rm2o_item_coll(const rm2o_result*);
+const double* rm2o_item_sum(const rm2o_result*);
+double rm2o_total_sum(const rm2o_result*);
+int64_t rm2o_log_terms(const rm2o_result*);
+int64_t rm2o_fma_terms(const rm2o_result*);
+double rm2o_seconds_scoring(const rm2o_result*);
+
+/* ---- item-item similarity (Mahout 0.8 RowSimilarityJob as called at M/baselinerecommender/BaselineRecommenderJob.java:241-253) ---- */
+enum { ISIM_COSINE = 0, ISIM_COOCCURRENCE = 1 };
+typedef struct {
+    int32_t similarity;                 /* --similarityClassname: SIMILARITY_COSINE | SIMILARITY_COOCCURRENCE */
+    int32_t max_similarities_per_item;  /* --maxSimilaritiesPerRow (default 100, BaselineRecommenderJob.java:67) */
+    int32_t exclude_self;               /* --excludeSelfSimilarity (the call site passes true) */
+    int32_t has_threshold;              /* 0 = RowSimilarityJob.NO_THRESHOLD */
+    double threshold;                   /* --threshold */
+    int32_t n_threads;
+} isimo_params;
+typedef struct isimo_result isimo_result;
+int isimo_run(const isimo_params* P, int64_t nnz, const int32_t* user, const int32_t* item, const float* score,
+              isimo_result** out);
+void isimo_free(isimo_result*);
+/* rows grouped by item id asc, best first (ties: ascending other-item id) */
+int64_t isimo_n(const isimo_result*);
+const int32_t* isimo_item(const isimo_result*);
+const int32_t* isimo_other(const isimo_result*);
+const double* isimo_sim(const isimo_result*);
+int64_t isimo_pairs(const isimo_result*);   /* sum_u n_u (n_u - 1) / 2 */
+double isimo_seconds(const isimo_result*);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
