@@ -1,0 +1,123 @@
+"""ctypes declarations of include/filmyou.h and the in-tree build of libfilmyou_hip.so.
+
+There is no CPU fallback: if the shared library is missing or does not load, importing callers get a loud
+ImportError/OSError; if no gfx950 device is present, fy_context_create returns FY_ERR_NO_DEVICE.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_DIR = os.path.join(_HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libfilmyou_hip.so")
+INCLUDE = os.path.join(os.path.dirname(_HERE), "include", "filmyou.h")
+SOURCES = ["fy_api.hip", "fy_prep.hip", "fy_rm2.hip", "fy_itemsim.hip"]
+HEADERS = ["fy_common.hpp", "fy_prep.hpp", "fy_cooc.hpp", "fy_rm2.hpp"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics", "-Wall",
+               "-Wno-unused-result"]
+
+# every symbol include/filmyou.h declares (tests check the library exports exactly these)
+SYMBOLS = [
+    "fy_abi_version", "fy_last_error", "fy_context_create", "fy_context_destroy", "fy_context_synchronize",
+    "fy_context_stream", "fy_ratings_create", "fy_ratings_destroy", "fy_ratings_nnz", "fy_rm2_prepare",
+    "fy_rm2_partial_stats", "fy_rm2_set_global_stats", "fy_rm2_score", "fy_rm2_job_destroy", "fy_rm2_run",
+    "fy_itemsim_build", "fy_itemsim_run", "fy_result_size", "fy_result_key0", "fy_result_key1", "fy_result_value",
+    "fy_result_aux", "fy_result_n_users", "fy_result_user_id", "fy_result_user_sum", "fy_result_n_items",
+    "fy_result_item_id", "fy_result_item_coll", "fy_result_total_sum", "fy_result_free", "fy_result_stats",
+]
+
+
+def _stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [INCLUDE]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    """hipcc cross-compiles for gfx950 without a GPU (about half a minute).  Returns the .so path."""
+    if not force and not _stale():
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        hipcc = "hipcc"
+    cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+class RM2Params(C.Structure):
+    _fields_ = [("lambda_", C.c_double), ("number_of_items", C.c_int32), ("number_of_recommendations", C.c_int32),
+                ("filter_users", C.c_int32), ("number_of_clusters", C.c_int32), ("rank", C.c_int32),
+                ("world", C.c_int32), ("flags", C.c_uint32), ("workspace_bytes", C.c_int64)]
+
+
+class ItemSimParams(C.Structure):
+    _fields_ = [("similarity", C.c_int32), ("max_similarities_per_item", C.c_int32), ("exclude_self", C.c_int32),
+                ("has_threshold", C.c_int32), ("threshold", C.c_double), ("rank", C.c_int32), ("world", C.c_int32),
+                ("flags", C.c_uint32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("nnz", C.c_int64), ("n_users", C.c_int64), ("n_items", C.c_int64),
+                ("n_clusters_nonempty", C.c_int64), ("users_scored", C.c_int64), ("recs", C.c_int64),
+                ("log_terms", C.c_int64), ("pair_contribs", C.c_int64), ("unordered_pairs", C.c_int64),
+                ("ms_prepare", C.c_double), ("ms_cooc", C.c_double), ("ms_score", C.c_double),
+                ("ms_topn", C.c_double), ("ms_total", C.c_double), ("score_launches", C.c_int64),
+                ("cooc_launches", C.c_int64)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+_lib = None
+
+
+def load():
+    """dlopen the in-tree library and declare argument types.  Raises OSError when it is missing (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OSError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                      "(the HIP extension is required; there is no CPU fallback)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i64, i32, pvp = C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_void_p)
+    L.fy_abi_version.restype = C.c_int
+    L.fy_last_error.restype = C.c_char_p
+    L.fy_context_create.argtypes = [C.c_int, pvp]
+    L.fy_context_destroy.argtypes = [vp]
+    L.fy_context_destroy.restype = None
+    L.fy_context_synchronize.argtypes = [vp]
+    L.fy_context_stream.argtypes = [vp]
+    L.fy_context_stream.restype = vp
+    L.fy_ratings_create.argtypes = [vp, i64, vp, vp, vp, C.c_int, pvp]
+    L.fy_ratings_destroy.argtypes = [vp]
+    L.fy_ratings_destroy.restype = None
+    L.fy_ratings_nnz.argtypes = [vp]
+    L.fy_ratings_nnz.restype = i64
+    L.fy_rm2_prepare.argtypes = [vp, C.POINTER(RM2Params), vp, i64, vp, vp, vp, pvp]
+    L.fy_rm2_partial_stats.argtypes = [vp, pvp, C.POINTER(i64)]
+    L.fy_rm2_set_global_stats.argtypes = [vp, vp, i32]
+    L.fy_rm2_score.argtypes = [vp, pvp]
+    L.fy_rm2_job_destroy.argtypes = [vp]
+    L.fy_rm2_job_destroy.restype = None
+    L.fy_rm2_run.argtypes = [C.POINTER(RM2Params), i64, vp, vp, vp, i64, vp, vp, vp, pvp]
+    L.fy_itemsim_build.argtypes = [vp, C.POINTER(ItemSimParams), vp, pvp]
+    L.fy_itemsim_run.argtypes = [C.POINTER(ItemSimParams), i64, vp, vp, vp, pvp]
+    for name, rt in (("size", i64), ("key0", vp), ("key1", vp), ("value", vp), ("aux", vp), ("n_users", i64),
+                     ("user_id", vp), ("user_sum", vp), ("n_items", i64), ("item_id", vp), ("item_coll", vp),
+                     ("total_sum", C.c_double)):
+        f = getattr(L, "fy_result_" + name)
+        f.argtypes = [vp]
+        f.restype = rt
+    L.fy_result_free.argtypes = [vp]
+    L.fy_result_free.restype = None
+    L.fy_result_stats.argtypes = [vp, C.POINTER(Stats)]
+    _lib = L
+    return L

@@ -1,0 +1,272 @@
+// fy_api.hip -- the extern "C" surface declared in include/filmyou.h: context, ratings, results, error plumbing.
+#include <memory>
+#include <new>
+
+#include "fy_rm2.hpp"
+
+namespace fy {
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+const char* last_error() { return g_err; }
+}  // namespace fy
+
+using namespace fy;
+
+// every entry point: no exception may cross the ABI
+#define FY_TRY try {
+#define FY_CATCH                                                           \
+    }                                                                      \
+    catch (const fy::Failure& f) { return f.code; }                        \
+    catch (const std::bad_alloc&) {                                        \
+        fy::set_error("host allocation failed");                           \
+        return FY_ERR_OUT_OF_MEMORY;                                       \
+    }                                                                      \
+    catch (const std::exception& e) {                                      \
+        fy::set_error("unexpected: %s", e.what());                         \
+        return FY_ERR_HIP;                                                 \
+    }                                                                      \
+    return FY_OK;
+
+extern "C" {
+
+int fy_abi_version(void) { return FY_ABI_VERSION; }
+const char* fy_last_error(void) { return fy::last_error(); }
+
+int fy_context_create(int device_ordinal, fy_context** out) {
+    if (!out) { set_error("out is NULL"); return FY_ERR_INVALID_ARGUMENT; }
+    *out = nullptr;
+    FY_TRY
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        FY_FAIL(FY_ERR_NO_DEVICE, "no HIP device is visible (%s); this library has no CPU fallback",
+                e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    }
+    if (device_ordinal < 0 || device_ordinal >= n) FY_FAIL(FY_ERR_INVALID_ARGUMENT, "device %d of %d", device_ordinal, n);
+    FY_HIP(hipSetDevice(device_ordinal));
+    hipDeviceProp_t prop;
+    FY_HIP(hipGetDeviceProperties(&prop, device_ordinal));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        FY_FAIL(FY_ERR_NO_DEVICE, "device %d is %s; the kernels are built for gfx950 (MI355X) only", device_ordinal, prop.gcnArchName);
+    std::unique_ptr<fy_context> c(new fy_context);
+    c->c.device = device_ordinal;
+    c->c.num_cus = prop.multiProcessorCount;
+    c->c.total_mem = prop.totalGlobalMem;
+    FY_HIP(hipStreamCreateWithFlags(&c->c.stream, hipStreamNonBlocking));
+    FY_HIP(hipDeviceGetDefaultMemPool(&c->c.pool, device_ordinal));
+    uint64_t keep = ~0ull;   // keep freed blocks in the pool: repeated jobs do not pay hipMalloc again
+    FY_HIP(hipMemPoolSetAttribute(c->c.pool, hipMemPoolAttrReleaseThreshold, &keep));
+    *out = c.release();
+    FY_CATCH
+}
+
+void fy_context_destroy(fy_context* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->c.device);
+    if (c->c.stream) {
+        (void)hipStreamSynchronize(c->c.stream);
+        (void)hipStreamDestroy(c->c.stream);
+    }
+    delete c;
+}
+
+int fy_context_synchronize(fy_context* c) {
+    if (!c) { set_error("context is NULL"); return FY_ERR_INVALID_ARGUMENT; }
+    FY_TRY
+    FY_HIP(hipStreamSynchronize(c->c.stream));
+    FY_CATCH
+}
+
+void* fy_context_stream(fy_context* c) { return c ? (void*)c->c.stream : nullptr; }
+
+int fy_ratings_create(fy_context* c, int64_t nnz, const int32_t* user, const int32_t* item, const float* score, int location,
+                      fy_ratings** out) {
+    if (!out) { set_error("out is NULL"); return FY_ERR_INVALID_ARGUMENT; }
+    *out = nullptr;
+    if (!c) { set_error("context is NULL"); return FY_ERR_INVALID_ARGUMENT; }
+    if (nnz < 0 || (nnz > 0 && (!user || !item || !score))) { set_error("ratings arrays are NULL or nnz < 0"); return FY_ERR_INVALID_ARGUMENT; }
+    if (location != FY_HOST && location != FY_DEVICE) { set_error("location must be FY_HOST or FY_DEVICE"); return FY_ERR_INVALID_ARGUMENT; }
+    FY_TRY
+    FY_HIP(hipSetDevice(c->c.device));
+    std::unique_ptr<fy_ratings> r(new fy_ratings);
+    r->ctx = &c->c;
+    r->nnz = nnz;
+    r->user.alloc(&c->c, (size_t)nnz);
+    r->item.alloc(&c->c, (size_t)nnz);
+    r->score.alloc(&c->c, (size_t)nnz);
+    if (nnz) {
+        const hipMemcpyKind k = location == FY_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+        FY_HIP(hipMemcpyAsync(r->user.get(), user, (size_t)nnz * 4, k, c->c.stream));
+        FY_HIP(hipMemcpyAsync(r->item.get(), item, (size_t)nnz * 4, k, c->c.stream));
+        FY_HIP(hipMemcpyAsync(r->score.get(), score, (size_t)nnz * 4, k, c->c.stream));
+        FY_HIP(hipStreamSynchronize(c->c.stream));   // the caller may free its arrays when this returns
+    }
+    *out = r.release();
+    FY_CATCH
+}
+
+void fy_ratings_destroy(fy_ratings* r) {
+    if (!r) return;
+    fy::Context* ctx = r->ctx;
+    delete r;
+    if (ctx) (void)hipStreamSynchronize(ctx->stream);
+}
+int64_t fy_ratings_nnz(const fy_ratings* r) { return r ? r->nnz : 0; }
+
+// ---------------------------------------------------------------- RM2
+int fy_rm2_prepare(fy_context* c, const fy_rm2_params* p, const fy_ratings* r, int64_t n_map, const int32_t* map_user,
+                   const int32_t* map_cluster, const int32_t* cluster_count, fy_rm2_job** out) {
+    if (!out) { set_error("out is NULL"); return FY_ERR_INVALID_ARGUMENT; }
+    *out = nullptr;
+    if (!c || !r) { set_error("context or ratings is NULL"); return FY_ERR_INVALID_ARGUMENT; }
+    if (r->ctx != &c->c) { set_error("ratings belong to another context"); return FY_ERR_INVALID_ARGUMENT; }
+    FY_TRY
+    FY_HIP(hipSetDevice(c->c.device));
+    *out = fy::rm2_prepare(&c->c, p, r, n_map, map_user, map_cluster, cluster_count);
+    FY_CATCH
+}
+
+int fy_rm2_partial_stats(fy_rm2_job* j, double** device_buf, int64_t* len) {
+    if (!j || !device_buf || !len) { set_error("NULL argument"); return FY_ERR_INVALID_ARGUMENT; }
+    FY_TRY
+    fy::rm2_partial_stats(j, device_buf, len);
+    FY_CATCH
+}
+
+int fy_rm2_set_global_stats(fy_rm2_job* j, const double* gathered_device, int32_t world) {
+    if (!j || !gathered_device) { set_error("NULL argument"); return FY_ERR_INVALID_ARGUMENT; }
+    FY_TRY
+    fy::rm2_set_global_stats(j, gathered_device, world);
+    FY_CATCH
+}
+
+int fy_rm2_score(fy_rm2_job* j, fy_result** out) {
+    if (!out) { set_error("out is NULL"); return FY_ERR_INVALID_ARGUMENT; }
+    *out = nullptr;
+    if (!j) { set_error("job is NULL"); return FY_ERR_INVALID_ARGUMENT; }
+    FY_TRY
+    *out = fy::rm2_score(j);
+    FY_CATCH
+}
+
+void fy_rm2_job_destroy(fy_rm2_job* j) { fy::rm2_job_destroy(j); }
+
+int fy_rm2_run(const fy_rm2_params* p, int64_t nnz, const int32_t* user, const int32_t* item, const float* score, int64_t n_map,
+               const int32_t* map_user, const int32_t* map_cluster, const int32_t* cluster_count, fy_result** out) {
+    if (!out) { set_error("out is NULL"); return FY_ERR_INVALID_ARGUMENT; }
+    *out = nullptr;
+    fy_context* c = nullptr;
+    fy_ratings* r = nullptr;
+    fy_rm2_job* j = nullptr;
+    int rc = fy_context_create(0, &c);
+    if (rc == FY_OK) rc = fy_ratings_create(c, nnz, user, item, score, FY_HOST, &r);
+    if (rc == FY_OK) rc = fy_rm2_prepare(c, p, r, n_map, map_user, map_cluster, cluster_count, &j);
+    if (rc == FY_OK) rc = fy_rm2_score(j, out);
+    if (rc == FY_OK) {
+        // the result outlives the context: bring everything to the host now
+        (void)fy_result_key0(*out);
+        (void)fy_result_user_sum(*out);
+        (*out)->d_key0.release(); (*out)->d_key1.release(); (*out)->d_aux.release(); (*out)->d_value.release();
+        (*out)->d_user_id.release(); (*out)->d_item_id.release(); (*out)->d_user_sum.release(); (*out)->d_icoll.release();
+        (*out)->ctx = nullptr;
+    }
+    fy_rm2_job_destroy(j);
+    fy_ratings_destroy(r);
+    fy_context_destroy(c);
+    return rc;
+}
+
+// ---------------------------------------------------------------- item-item similarity
+int fy_itemsim_build(fy_context* c, const fy_itemsim_params* p, const fy_ratings* r, fy_result** out) {
+    if (!out) { set_error("out is NULL"); return FY_ERR_INVALID_ARGUMENT; }
+    *out = nullptr;
+    if (!c || !r || !p) { set_error("NULL argument"); return FY_ERR_INVALID_ARGUMENT; }
+    if (r->ctx != &c->c) { set_error("ratings belong to another context"); return FY_ERR_INVALID_ARGUMENT; }
+    FY_TRY
+    FY_HIP(hipSetDevice(c->c.device));
+    *out = fy::itemsim_build(&c->c, p, r);
+    FY_CATCH
+}
+
+int fy_itemsim_run(const fy_itemsim_params* p, int64_t nnz, const int32_t* user, const int32_t* item, const float* score,
+                   fy_result** out) {
+    if (!out) { set_error("out is NULL"); return FY_ERR_INVALID_ARGUMENT; }
+    *out = nullptr;
+    fy_context* c = nullptr;
+    fy_ratings* r = nullptr;
+    int rc = fy_context_create(0, &c);
+    if (rc == FY_OK) rc = fy_ratings_create(c, nnz, user, item, score, FY_HOST, &r);
+    if (rc == FY_OK) rc = fy_itemsim_build(c, p, r, out);
+    if (rc == FY_OK) {
+        (void)fy_result_key0(*out);
+        (*out)->d_key0.release(); (*out)->d_key1.release(); (*out)->d_aux.release(); (*out)->d_value.release();
+        (*out)->ctx = nullptr;
+    }
+    fy_ratings_destroy(r);
+    fy_context_destroy(c);
+    return rc;
+}
+
+// ---------------------------------------------------------------- results
+static void rows_to_host(fy_result* r) {
+    if (r->rows_on_host) return;
+    r->rows_on_host = true;
+    const size_t n = (size_t)r->n;
+    r->h_key0.resize(n); r->h_key1.resize(n); r->h_aux.resize(n); r->h_value.resize(n);
+    if (n == 0 || !r->ctx) return;
+    try {
+        fy::d2h(r->ctx, r->h_key0.data(), r->d_key0.get(), n);
+        fy::d2h(r->ctx, r->h_key1.data(), r->d_key1.get(), n);
+        fy::d2h(r->ctx, r->h_aux.data(), r->d_aux.get(), n);
+        fy::d2h(r->ctx, r->h_value.data(), r->d_value.get(), n);
+        fy::sync(r->ctx);
+    } catch (const fy::Failure&) {
+    }
+}
+static void sums_to_host(fy_result* r) {
+    if (r->sums_on_host) return;
+    r->sums_on_host = true;
+    const size_t nu = r->d_user_id.size(), ni = r->d_item_id.size();
+    r->h_user_id.resize(nu); r->h_user_sum.resize(nu); r->h_item_id.resize(ni); r->h_icoll.resize(ni);
+    if (!r->ctx) return;
+    try {
+        fy::d2h(r->ctx, r->h_user_id.data(), r->d_user_id.get(), nu);
+        fy::d2h(r->ctx, r->h_user_sum.data(), r->d_user_sum.get(), nu);
+        fy::d2h(r->ctx, r->h_item_id.data(), r->d_item_id.get(), ni);
+        if (r->d_icoll.size() == ni) fy::d2h(r->ctx, r->h_icoll.data(), r->d_icoll.get(), ni);
+        fy::sync(r->ctx);
+    } catch (const fy::Failure&) {
+    }
+}
+
+int64_t fy_result_size(fy_result* r) { return r ? r->n : 0; }
+const int32_t* fy_result_key0(fy_result* r) { if (!r) return nullptr; rows_to_host(r); return r->h_key0.data(); }
+const int32_t* fy_result_key1(fy_result* r) { if (!r) return nullptr; rows_to_host(r); return r->h_key1.data(); }
+const float* fy_result_value(fy_result* r) { if (!r) return nullptr; rows_to_host(r); return r->h_value.data(); }
+const int32_t* fy_result_aux(fy_result* r) { if (!r) return nullptr; rows_to_host(r); return r->h_aux.data(); }
+int64_t fy_result_n_users(fy_result* r) { if (!r) return 0; sums_to_host(r); return (int64_t)r->h_user_id.size(); }
+const int32_t* fy_result_user_id(fy_result* r) { if (!r) return nullptr; sums_to_host(r); return r->h_user_id.data(); }
+const double* fy_result_user_sum(fy_result* r) { if (!r) return nullptr; sums_to_host(r); return r->h_user_sum.data(); }
+int64_t fy_result_n_items(fy_result* r) { if (!r) return 0; sums_to_host(r); return (int64_t)r->h_item_id.size(); }
+const int32_t* fy_result_item_id(fy_result* r) { if (!r) return nullptr; sums_to_host(r); return r->h_item_id.data(); }
+const double* fy_result_item_coll(fy_result* r) { if (!r) return nullptr; sums_to_host(r); return r->h_icoll.data(); }
+double fy_result_total_sum(fy_result* r) { return r ? r->total_sum : 0.0; }
+int fy_result_stats(fy_result* r, fy_stats* out) {
+    if (!r || !out) { set_error("NULL argument"); return FY_ERR_INVALID_ARGUMENT; }
+    *out = r->st;
+    return FY_OK;
+}
+void fy_result_free(fy_result* r) {
+    if (!r) return;
+    fy::Context* ctx = r->ctx;
+    delete r;
+    if (ctx) (void)hipStreamSynchronize(ctx->stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,163 @@
+// fy_common.hpp -- context, stream-ordered HBM buffers, error plumbing shared by the HIP translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/filmyou.h"
+
+namespace fy {
+
+// ---------------------------------------------------------------- errors
+void set_error(const char* fmt, ...);
+const char* last_error();
+
+struct Failure {
+    int code;
+};
+
+#define FY_HIP(expr)                                                                               \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) {                                                                    \
+            fy::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            throw fy::Failure{_e == hipErrorOutOfMemory ? FY_ERR_OUT_OF_MEMORY : FY_ERR_HIP};      \
+        }                                                                                          \
+    } while (0)
+
+#define FY_FAIL(code, ...)            \
+    do {                              \
+        fy::set_error(__VA_ARGS__);   \
+        throw fy::Failure{code};      \
+    } while (0)
+
+#define FY_KERNEL_CHECK() FY_HIP(hipGetLastError())
+
+// ---------------------------------------------------------------- context
+struct Context {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipMemPool_t pool = nullptr;
+    int num_cus = 256;
+    size_t lds_per_block = 160 * 1024;
+    size_t total_mem = 0;
+};
+
+// ---------------------------------------------------------------- HBM buffer (stream-ordered alloc / free)
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    Context* ctx = nullptr;
+    DevBuf() = default;
+    DevBuf(Context* c, size_t count) { alloc(c, count); }
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept { *this = std::move(o); }
+    DevBuf& operator=(DevBuf&& o) noexcept {
+        if (this != &o) {
+            release();
+            p = o.p; n = o.n; ctx = o.ctx;
+            o.p = nullptr; o.n = 0;
+        }
+        return *this;
+    }
+    ~DevBuf() { release(); }
+    void alloc(Context* c, size_t count) {
+        release();
+        ctx = c;
+        n = count;
+        size_t bytes = (count ? count : 1) * sizeof(T);
+        void* q = nullptr;
+        hipError_t e = hipMallocAsync(&q, bytes, c->stream);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("HBM allocation of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+            throw Failure{FY_ERR_OUT_OF_MEMORY};
+        }
+        p = static_cast<T*>(q);
+    }
+    void zero() { FY_HIP(hipMemsetAsync(p, 0, (n ? n : 1) * sizeof(T), ctx->stream)); }
+    void release() {
+        if (p) (void)hipFreeAsync(p, ctx->stream);
+        p = nullptr;
+        n = 0;
+    }
+    T* get() const { return p; }
+    size_t size() const { return n; }
+    size_t bytes() const { return n * sizeof(T); }
+};
+
+template <class T>
+inline void d2h(Context* c, T* dst, const T* src, size_t count) {
+    if (count) FY_HIP(hipMemcpyAsync(dst, src, count * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+}
+template <class T>
+inline void h2d(Context* c, T* dst, const T* src, size_t count) {
+    if (count) FY_HIP(hipMemcpyAsync(dst, src, count * sizeof(T), hipMemcpyHostToDevice, c->stream));
+}
+template <class T>
+inline void d2d(Context* c, T* dst, const T* src, size_t count) {
+    if (count) FY_HIP(hipMemcpyAsync(dst, src, count * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+}
+inline void sync(Context* c) { FY_HIP(hipStreamSynchronize(c->stream)); }
+
+template <class T>
+inline T fetch(Context* c, const T* src) {
+    T v;
+    d2h(c, &v, src, 1);
+    sync(c);
+    return v;
+}
+
+// ---------------------------------------------------------------- HIP-event phase timers on the context's stream
+struct EventTimer {
+    Context* ctx;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> spans;
+    explicit EventTimer(Context* c) : ctx(c) {}
+    ~EventTimer() {
+        for (auto& s : spans) { (void)hipEventDestroy(s.first); (void)hipEventDestroy(s.second); }
+    }
+    size_t begin() {
+        hipEvent_t a, b;
+        FY_HIP(hipEventCreate(&a));
+        FY_HIP(hipEventCreate(&b));
+        FY_HIP(hipEventRecord(a, ctx->stream));
+        spans.emplace_back(a, b);
+        return spans.size() - 1;
+    }
+    void end(size_t i) { FY_HIP(hipEventRecord(spans[i].second, ctx->stream)); }
+    // total milliseconds over all spans; the stream must have been synchronised
+    double total_ms() {
+        double t = 0;
+        for (auto& s : spans) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, s.first, s.second) == hipSuccess) t += ms;
+        }
+        return t;
+    }
+    size_t count() const { return spans.size(); }
+};
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+inline int64_t round_up(int64_t a, int64_t b) { return ceil_div(a, b) * b; }
+
+}  // namespace fy
+
+// ---------------------------------------------------------------- opaque ABI objects
+struct fy_context {
+    fy::Context c;
+};
+
+struct fy_ratings {
+    fy::Context* ctx = nullptr;
+    int64_t nnz = 0;
+    fy::DevBuf<int32_t> user, item;
+    fy::DevBuf<float> score;
+};

@@ -1,0 +1,492 @@
+// fy_prep.hip -- COO ratings -> cluster-major CSR + CSC in HBM (the reference's map / shuffle / group phases).
+//
+// What each step replaces in the reference (M/ = src/main/java/es/udc/fi/dc/irlab/):
+//   score > 0 filter          M/rm/SimpleScoreByUserHDFSMapper.java:37-40, ScoreByClusterHDFSMapper.java:40-41
+//   user -> cluster routing   M/common/AbstractByClusterMapper.java:46-79 (missing user -> 0)
+//   cluster sizes             M/nmf/clustering/CountClustersJob (the clusteringCount side file), validated here
+//   group ratings by cluster  the RM2-3 shuffle + secondary sort (M/rm/RM2Job.java:225-258)
+//   per-cluster item set      M/rm/AbstractRM2Reducer.java:238-272 (createUserAndItemMappings)
+// Sorting and scanning are plumbing and use rocPRIM; every other step is a hand-written kernel.
+#include <cstring>
+#include <cstdlib>
+
+#include <rocprim/rocprim.hpp>
+
+#include <algorithm>
+#include <numeric>
+
+#include "fy_prep.hpp"
+
+namespace fy {
+
+// ---------------------------------------------------------------- rocPRIM wrappers
+template <class K, class V>
+static void sort_pairs_impl(Context* c, K* kin, K* kout, V* vin, V* vout, size_t n, int end_bit) {
+    if (n == 0) return;
+    size_t tmp = 0;
+    FY_HIP(rocprim::radix_sort_pairs(nullptr, tmp, kin, kout, vin, vout, n, 0, end_bit, c->stream));
+    DevBuf<char> t(c, tmp);
+    FY_HIP(rocprim::radix_sort_pairs(t.get(), tmp, kin, kout, vin, vout, n, 0, end_bit, c->stream));
+}
+void sort_pairs_u64_u32(Context* c, uint64_t* kin, uint64_t* kout, uint32_t* vin, uint32_t* vout, size_t n, int end_bit) {
+    sort_pairs_impl(c, kin, kout, vin, vout, n, end_bit);
+}
+void sort_pairs_u64_f32(Context* c, uint64_t* kin, uint64_t* kout, float* vin, float* vout, size_t n, int end_bit) {
+    sort_pairs_impl(c, kin, kout, vin, vout, n, end_bit);
+}
+void inclusive_scan_u32(Context* c, const uint32_t* in, uint32_t* out, size_t n) {
+    if (n == 0) return;
+    size_t tmp = 0;
+    FY_HIP(rocprim::inclusive_scan(nullptr, tmp, in, out, n, rocprim::plus<uint32_t>(), c->stream));
+    DevBuf<char> t(c, tmp);
+    FY_HIP(rocprim::inclusive_scan(t.get(), tmp, in, out, n, rocprim::plus<uint32_t>(), c->stream));
+}
+void exclusive_scan_i32(Context* c, const int32_t* in, int32_t* out, size_t n) {
+    if (n == 0) return;
+    size_t tmp = 0;
+    FY_HIP(rocprim::exclusive_scan(nullptr, tmp, in, out, int32_t(0), n, rocprim::plus<int32_t>(), c->stream));
+    DevBuf<char> t(c, tmp);
+    FY_HIP(rocprim::exclusive_scan(t.get(), tmp, in, out, int32_t(0), n, rocprim::plus<int32_t>(), c->stream));
+}
+void inclusive_scan_i64(Context* c, const int64_t* in, int64_t* out, size_t n) {
+    if (n == 0) return;
+    size_t tmp = 0;
+    FY_HIP(rocprim::inclusive_scan(nullptr, tmp, in, out, n, rocprim::plus<int64_t>(), c->stream));
+    DevBuf<char> t(c, tmp);
+    FY_HIP(rocprim::inclusive_scan(t.get(), tmp, in, out, n, rocprim::plus<int64_t>(), c->stream));
+}
+
+// ---------------------------------------------------------------- kernels
+enum { ERR_NEG_ID = 1, ERR_DUP = 2, ERR_CLUSTER_RANGE = 4 };
+
+static inline int grid_for(int64_t n, int block = 256, int cap = 256 * 16) {
+    int64_t g = ceil_div(n, block);
+    return (int)std::max<int64_t>(1, std::min<int64_t>(g, cap));
+}
+
+// key = user:item for kept ratings, all-ones for dropped ones (they sort to the end)
+__global__ void k_user_item_keys(int64_t n, const int32_t* __restrict__ user, const int32_t* __restrict__ item,
+                                 const float* __restrict__ score, int keep_nonpositive, uint64_t* __restrict__ keys,
+                                 unsigned long long* __restrict__ kept, int* __restrict__ err) {
+    unsigned long long local = 0;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        const float s = score[t];
+        const bool keep = keep_nonpositive ? (s == s) : (s > 0.0f);   // NaN never passes "score > 0"
+        uint64_t k = ~0ull;
+        if (keep) {
+            const int32_t u = user[t], i = item[t];
+            if (u < 0 || i < 0) atomicOr(err, ERR_NEG_ID);
+            k = ((uint64_t)(uint32_t)u << 32) | (uint32_t)i;
+            local++;
+        }
+        keys[t] = k;
+    }
+    // wave reduce then one atomic per wave
+    for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o, 64);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(kept, local);
+}
+
+__global__ void k_heads_hi32(int64_t n, const uint64_t* __restrict__ keys, uint32_t* __restrict__ head, int check_dup,
+                             int* __restrict__ err) {
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t h = 1;
+        if (t > 0) {
+            const uint64_t a = keys[t - 1], b = keys[t];
+            h = (a >> 32) != (b >> 32);
+            if (check_dup && a == b) atomicOr(err, ERR_DUP);
+        }
+        head[t] = h;
+    }
+}
+
+__global__ void k_heads_full(int64_t n, const uint64_t* __restrict__ keys, uint32_t* __restrict__ head) {
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x)
+        head[t] = (t == 0) || (keys[t] != keys[t - 1]);
+}
+
+// at every user head: uid[du] = raw id, ustart[du] = t
+__global__ void k_scatter_users(int64_t n, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ head,
+                                const uint32_t* __restrict__ du1, int32_t* __restrict__ uid, int32_t* __restrict__ ustart) {
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x)
+        if (head[t]) {
+            const uint32_t d = du1[t] - 1;
+            uid[d] = (int32_t)(keys[t] >> 32);
+            ustart[d] = (int32_t)t;
+        }
+}
+
+// one wave per user: s_u = sum of (double) score in a fixed order (DoubleSumAndCountReducer.java:35-38), degree
+__global__ void k_user_sums(int32_t nU, const int32_t* __restrict__ ustart, const float* __restrict__ score,
+                            double* __restrict__ usum, int32_t* __restrict__ udeg) {
+    const int lane = threadIdx.x & 63;
+    const int wpb = blockDim.x >> 6;
+    for (int32_t u = blockIdx.x * wpb + (threadIdx.x >> 6); u < nU; u += gridDim.x * wpb) {
+        const int32_t a = ustart[u], b = ustart[u + 1];
+        double s = 0.0;
+        for (int32_t t = a + lane; t < b; t += 64) s += (double)score[t];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+        if (lane == 0) { usum[u] = s; udeg[u] = b - a; }
+    }
+}
+
+// cluster of a user: last entry of the (stably sorted) clustering map with that user id, 0 when absent (Q2)
+__global__ void k_lookup_cluster(int32_t nU, const int32_t* __restrict__ uid, int64_t n_map,
+                                 const uint64_t* __restrict__ map_sorted /* user:cluster */, int32_t K,
+                                 int32_t* __restrict__ ucluster, int* __restrict__ err) {
+    for (int32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < nU; u += gridDim.x * blockDim.x) {
+        const uint32_t id = (uint32_t)uid[u];
+        int64_t lo = 0, hi = n_map;            // upper bound of id in the hi32 part
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if ((uint32_t)(map_sorted[mid] >> 32) <= id) lo = mid + 1; else hi = mid;
+        }
+        int32_t c = 0;
+        if (lo > 0 && (uint32_t)(map_sorted[lo - 1] >> 32) == id) c = (int32_t)(uint32_t)map_sorted[lo - 1];
+        if (c < 0 || c >= K) { atomicOr(err, ERR_CLUSTER_RANGE); c = 0; }
+        ucluster[u] = c;
+    }
+}
+
+__global__ void k_slot_keys(int32_t nU, const int32_t* __restrict__ ucluster, const int32_t* __restrict__ udeg,
+                            uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, int32_t* __restrict__ csize) {
+    for (int32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < nU; u += gridDim.x * blockDim.x) {
+        keys[u] = ((uint64_t)(uint32_t)ucluster[u] << 32) | (0xFFFFFFFFu - (uint32_t)udeg[u]);
+        vals[u] = (uint32_t)u;
+        atomicAdd(&csize[ucluster[u]], 1);
+    }
+}
+
+__global__ void k_invert_perm(int32_t n, const uint32_t* __restrict__ perm, int32_t* __restrict__ fwd, int32_t* __restrict__ inv) {
+    for (int32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
+        fwd[s] = (int32_t)perm[s];
+        inv[perm[s]] = s;
+    }
+}
+
+// (cluster : raw item) key of every rating, payload = position in the user-major order
+__global__ void k_cluster_item_keys(int64_t n, const uint64_t* __restrict__ ukeys, const uint32_t* __restrict__ du1,
+                                    const int32_t* __restrict__ ucluster, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t c = (uint32_t)ucluster[du1[t] - 1];
+        keys[t] = ((uint64_t)c << 32) | (uint32_t)ukeys[t];
+        vals[t] = (uint32_t)t;
+    }
+}
+
+__global__ void k_scatter_pairs(int64_t n, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ head,
+                                const uint32_t* __restrict__ pr1, int32_t* __restrict__ pair_cluster,
+                                int32_t* __restrict__ pair_item, int32_t* __restrict__ pair_start, int32_t* __restrict__ pcount) {
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x)
+        if (head[t]) {
+            const uint32_t p = pr1[t] - 1;
+            const int32_t c = (int32_t)(keys[t] >> 32);
+            pair_cluster[p] = c;
+            pair_item[p] = (int32_t)(uint32_t)keys[t];
+            pair_start[p] = (int32_t)t;
+            atomicAdd(&pcount[c], 1);
+        }
+}
+
+__global__ void k_item_keys_of_pairs(int32_t nP, const int32_t* __restrict__ pair_item, uint64_t* __restrict__ keys,
+                                     uint32_t* __restrict__ vals) {
+    for (int32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < nP; p += gridDim.x * blockDim.x) {
+        keys[p] = (uint64_t)(uint32_t)pair_item[p];
+        vals[p] = (uint32_t)p;
+    }
+}
+
+__global__ void k_scatter_items(int32_t nP, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                const uint32_t* __restrict__ head, const uint32_t* __restrict__ di1,
+                                int32_t* __restrict__ iid, int32_t* __restrict__ pair_di) {
+    for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nP; q += gridDim.x * blockDim.x) {
+        const uint32_t d = di1[q] - 1;
+        if (head[q]) iid[d] = (int32_t)(uint32_t)keys[q];
+        pair_di[vals[q]] = (int32_t)d;
+    }
+}
+
+// CSC payload in pair order: slot of the rater, its raw rating, and the pair every entry belongs to
+__global__ void k_fill_csc(int64_t n, const uint32_t* __restrict__ t_sorted, const uint32_t* __restrict__ du1,
+                           const int32_t* __restrict__ du2slot, const float* __restrict__ score_um,
+                           const uint32_t* __restrict__ pr1, int32_t* __restrict__ csc_slot, float* __restrict__ csc_r,
+                           int32_t* __restrict__ csc_pair) {
+    for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t t = t_sorted[q];
+        csc_slot[q] = du2slot[du1[t] - 1];
+        csc_r[q] = score_um[t];
+        csc_pair[q] = (int32_t)(pr1[q] - 1);
+    }
+}
+
+__global__ void k_rank_keys(int32_t nP, const int32_t* __restrict__ pair_cluster, const int32_t* __restrict__ pair_start,
+                            uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    for (int32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < nP; p += gridDim.x * blockDim.x) {
+        const uint32_t cnt = (uint32_t)(pair_start[p + 1] - pair_start[p]);
+        keys[p] = ((uint64_t)(uint32_t)pair_cluster[p] << 32) | (0xFFFFFFFFu - cnt);
+        vals[p] = (uint32_t)p;
+    }
+}
+
+__global__ void k_scatter_ranks(int32_t nP, const uint32_t* __restrict__ rank_pair_u, const int32_t* __restrict__ pair_cluster,
+                                const int32_t* __restrict__ pcstart, const int32_t* __restrict__ pair_di,
+                                const int32_t* __restrict__ iid, int32_t* __restrict__ rank_pair,
+                                int32_t* __restrict__ pair_rank, int32_t* __restrict__ rank_item_raw) {
+    for (int32_t pos = blockIdx.x * blockDim.x + threadIdx.x; pos < nP; pos += gridDim.x * blockDim.x) {
+        const int32_t p = (int32_t)rank_pair_u[pos];
+        rank_pair[pos] = p;
+        pair_rank[p] = pos - pcstart[pair_cluster[p]];
+        rank_item_raw[pos] = iid[pair_di[p]];
+    }
+}
+
+__global__ void k_csr_keys(int64_t n, const int32_t* __restrict__ csc_slot, const int32_t* __restrict__ csc_pair,
+                           const int32_t* __restrict__ pair_rank, uint64_t* __restrict__ keys) {
+    for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x)
+        keys[q] = ((uint64_t)(uint32_t)csc_slot[q] << 32) | (uint32_t)pair_rank[csc_pair[q]];
+}
+
+__global__ void k_low32(int64_t n, const uint64_t* __restrict__ keys, int32_t* __restrict__ out) {
+    for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x)
+        out[q] = (int32_t)(uint32_t)keys[q];
+}
+
+__global__ void k_slot_degrees(int32_t nU, const int32_t* __restrict__ slot2du, const int32_t* __restrict__ udeg,
+                               const int32_t* __restrict__ ucluster, const int32_t* __restrict__ pcstart,
+                               int32_t* __restrict__ deg_slot, int64_t* __restrict__ work, int64_t* __restrict__ deg2) {
+    for (int32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < nU; s += gridDim.x * blockDim.x) {
+        const int32_t u = slot2du[s];
+        const int64_t n = udeg[u];
+        const int32_t c = ucluster[u];
+        const int64_t Ic = pcstart[c + 1] - pcstart[c];
+        deg_slot[s] = (int32_t)n;
+        work[s] = n * (Ic - n) + 1;   // +1 keeps the prefix strictly increasing
+        deg2[s] = n * n;
+    }
+}
+
+// ---------------------------------------------------------------- build
+void build_structure(Context* ctx, const fy_ratings* R, int32_t K, int64_t n_map, const int32_t* map_user,
+                     const int32_t* map_cluster, const int32_t* cluster_count, bool keep_nonpositive, Prepared& P) {
+    P.ctx = ctx;
+    P.K = K;
+    const int64_t n_in = R->nnz;
+    if (n_in >= (int64_t)0x7FFFFFF0) FY_FAIL(FY_ERR_UNSUPPORTED, "nnz = %lld exceeds the 2^31 offset limit", (long long)n_in);
+    hipStream_t st = ctx->stream;
+
+    DevBuf<int> err(ctx, 1);
+    err.zero();
+    DevBuf<unsigned long long> kept(ctx, 1);
+    kept.zero();
+
+    // ---- sort #1: user-major order, duplicates / negative ids detected
+    DevBuf<uint64_t> k1a(ctx, n_in), k1b(ctx, n_in);
+    DevBuf<float> sc_um(ctx, n_in);
+    if (n_in) {
+        k_user_item_keys<<<grid_for(n_in), 256, 0, st>>>(n_in, R->user.get(), R->item.get(), R->score.get(),
+                                                          keep_nonpositive ? 1 : 0, k1a.get(), kept.get(), err.get());
+        FY_KERNEL_CHECK();
+        sort_pairs_u64_f32(ctx, k1a.get(), k1b.get(), const_cast<float*>(R->score.get()), sc_um.get(), n_in);
+    }
+    const int64_t nnz = (int64_t)fetch(ctx, kept.get());
+    P.nnz = nnz;
+    if (fetch(ctx, err.get()) & ERR_NEG_ID) FY_FAIL(FY_ERR_NEGATIVE_ID, "negative user or item id in the ratings");
+    if (nnz == 0) {
+        P.nU = P.nI = P.nP = 0;
+        P.csize.assign(K, 0);
+        P.ucstart.assign(K + 1, 0);
+        P.pcstart.assign(K + 1, 0);
+        return;
+    }
+    k1a.release();
+    uint64_t* ukeys = k1b.get();   // (user:item) ascending, first nnz entries are the kept ratings
+
+    DevBuf<uint32_t> head(ctx, nnz), du1(ctx, nnz);
+    k_heads_hi32<<<grid_for(nnz), 256, 0, st>>>(nnz, ukeys, head.get(), 1, err.get());
+    FY_KERNEL_CHECK();
+    inclusive_scan_u32(ctx, head.get(), du1.get(), nnz);
+    const int32_t nU = (int32_t)fetch(ctx, du1.get() + (nnz - 1));
+    if (fetch(ctx, err.get()) & ERR_DUP) FY_FAIL(FY_ERR_DUPLICATE_RATING, "two ratings share one (user, item) key");
+    P.nU = nU;
+
+    P.uid.alloc(ctx, nU);
+    DevBuf<int32_t> ustart(ctx, (size_t)nU + 1);
+    k_scatter_users<<<grid_for(nnz), 256, 0, st>>>(nnz, ukeys, head.get(), du1.get(), P.uid.get(), ustart.get());
+    FY_KERNEL_CHECK();
+    {
+        const int32_t last = (int32_t)nnz;
+        h2d(ctx, ustart.get() + nU, &last, 1);
+        sync(ctx);
+    }
+    P.usum.alloc(ctx, nU);
+    P.udeg.alloc(ctx, nU);
+    k_user_sums<<<grid_for((int64_t)nU * 64, 256), 256, 0, st>>>(nU, ustart.get(), sc_um.get(), P.usum.get(), P.udeg.get());
+    FY_KERNEL_CHECK();
+
+    // ---- cluster routing
+    P.ucluster.alloc(ctx, nU);
+    {
+        std::vector<uint64_t> hm((size_t)n_map);
+        for (int64_t m = 0; m < n_map; m++) {
+            if (map_user[m] < 0) { hm[m] = ~0ull; continue; }   // can never match a kept rating
+            hm[m] = ((uint64_t)(uint32_t)map_user[m] << 32) | (uint32_t)map_cluster[m];
+        }
+        // stable by user: a later pair of the same user wins, like successive TIntIntHashMap.put calls
+        std::stable_sort(hm.begin(), hm.end(), [](uint64_t a, uint64_t b) { return (a >> 32) < (b >> 32); });
+        DevBuf<uint64_t> dm(ctx, (size_t)n_map);
+        h2d(ctx, dm.get(), hm.data(), (size_t)n_map);
+        k_lookup_cluster<<<grid_for(nU), 256, 0, st>>>(nU, P.uid.get(), n_map, dm.get(), K, P.ucluster.get(), err.get());
+        FY_KERNEL_CHECK();
+        sync(ctx);   // hm must outlive the copy
+    }
+    if (fetch(ctx, err.get()) & ERR_CLUSTER_RANGE)
+        FY_FAIL(FY_ERR_CLUSTER_RANGE, "a rated user is routed to a cluster outside [0, %d)", K);
+
+    // ---- slots: cluster-major, heavy rows first
+    P.d_csize.alloc(ctx, (size_t)K);
+    P.d_csize.zero();
+    {
+        DevBuf<uint64_t> ka(ctx, nU), kb(ctx, nU);
+        DevBuf<uint32_t> va(ctx, nU), vb(ctx, nU);
+        k_slot_keys<<<grid_for(nU), 256, 0, st>>>(nU, P.ucluster.get(), P.udeg.get(), ka.get(), va.get(), P.d_csize.get());
+        FY_KERNEL_CHECK();
+        sort_pairs_u64_u32(ctx, ka.get(), kb.get(), va.get(), vb.get(), nU);
+        P.slot2du.alloc(ctx, nU);
+        P.du2slot.alloc(ctx, nU);
+        k_invert_perm<<<grid_for(nU), 256, 0, st>>>(nU, vb.get(), P.slot2du.get(), P.du2slot.get());
+        FY_KERNEL_CHECK();
+    }
+    P.csize.resize(K);
+    d2h(ctx, P.csize.data(), P.d_csize.get(), (size_t)K);
+    sync(ctx);
+    P.ucstart.assign(K + 1, 0);
+    for (int c = 0; c < K; c++) P.ucstart[c + 1] = P.ucstart[c] + P.csize[c];
+    if (cluster_count)
+        for (int c = 0; c < K; c++)
+            if (P.csize[c] && cluster_count[c] != P.csize[c])
+                FY_FAIL(FY_ERR_CLUSTER_COUNT, "clusteringCount[%d] = %d but %d rated users are routed to that cluster", c,
+                        cluster_count[c], P.csize[c]);
+    P.d_ucstart.alloc(ctx, (size_t)K + 1);
+    h2d(ctx, P.d_ucstart.get(), P.ucstart.data(), (size_t)K + 1);
+
+    // ---- sort #3: (cluster, item) order = the CSC
+    DevBuf<uint64_t> k3b(ctx, nnz);
+    DevBuf<uint32_t> t_sorted(ctx, nnz);
+    {
+        DevBuf<uint64_t> k3a(ctx, nnz);
+        DevBuf<uint32_t> v3a(ctx, nnz);
+        k_cluster_item_keys<<<grid_for(nnz), 256, 0, st>>>(nnz, ukeys, du1.get(), P.ucluster.get(), k3a.get(), v3a.get());
+        FY_KERNEL_CHECK();
+        sort_pairs_u64_u32(ctx, k3a.get(), k3b.get(), v3a.get(), t_sorted.get(), nnz);
+    }
+    DevBuf<uint32_t> pr1(ctx, nnz);
+    k_heads_full<<<grid_for(nnz), 256, 0, st>>>(nnz, k3b.get(), head.get());
+    FY_KERNEL_CHECK();
+    inclusive_scan_u32(ctx, head.get(), pr1.get(), nnz);
+    const int32_t nP = (int32_t)fetch(ctx, pr1.get() + (nnz - 1));
+    P.nP = nP;
+    P.pair_cluster.alloc(ctx, nP);
+    P.pair_start.alloc(ctx, (size_t)nP + 1);
+    DevBuf<int32_t> pair_item(ctx, nP), pcount(ctx, (size_t)K);
+    pcount.zero();
+    k_scatter_pairs<<<grid_for(nnz), 256, 0, st>>>(nnz, k3b.get(), head.get(), pr1.get(), P.pair_cluster.get(),
+                                                    pair_item.get(), P.pair_start.get(), pcount.get());
+    FY_KERNEL_CHECK();
+    {
+        const int32_t last = (int32_t)nnz;
+        h2d(ctx, P.pair_start.get() + nP, &last, 1);
+    }
+    std::vector<int32_t> hpc(K);
+    d2h(ctx, hpc.data(), pcount.get(), (size_t)K);
+    sync(ctx);
+    P.pcstart.assign(K + 1, 0);
+    for (int c = 0; c < K; c++) P.pcstart[c + 1] = P.pcstart[c] + hpc[c];
+    P.d_pcstart.alloc(ctx, (size_t)K + 1);
+    h2d(ctx, P.d_pcstart.get(), P.pcstart.data(), (size_t)K + 1);
+
+    // ---- dense item index (ascending raw id)
+    P.pair_di.alloc(ctx, nP);
+    {
+        DevBuf<uint64_t> ka(ctx, nP), kb(ctx, nP);
+        DevBuf<uint32_t> va(ctx, nP), vb(ctx, nP), hd(ctx, nP), di1(ctx, nP);
+        k_item_keys_of_pairs<<<grid_for(nP), 256, 0, st>>>(nP, pair_item.get(), ka.get(), va.get());
+        FY_KERNEL_CHECK();
+        sort_pairs_u64_u32(ctx, ka.get(), kb.get(), va.get(), vb.get(), nP, 32);
+        k_heads_full<<<grid_for(nP), 256, 0, st>>>(nP, kb.get(), hd.get());
+        FY_KERNEL_CHECK();
+        inclusive_scan_u32(ctx, hd.get(), di1.get(), nP);
+        P.nI = (int32_t)fetch(ctx, di1.get() + (nP - 1));
+        P.iid.alloc(ctx, P.nI);
+        k_scatter_items<<<grid_for(nP), 256, 0, st>>>(nP, kb.get(), vb.get(), hd.get(), di1.get(), P.iid.get(), P.pair_di.get());
+        FY_KERNEL_CHECK();
+    }
+
+    // ---- CSC payload
+    P.csc_slot.alloc(ctx, nnz);
+    P.csc_r.alloc(ctx, nnz);
+    P.csc_pair.alloc(ctx, nnz);
+    k_fill_csc<<<grid_for(nnz), 256, 0, st>>>(nnz, t_sorted.get(), du1.get(), P.du2slot.get(), sc_um.get(), pr1.get(),
+                                               P.csc_slot.get(), P.csc_r.get(), P.csc_pair.get());
+    FY_KERNEL_CHECK();
+
+    // ---- popularity rank inside the cluster = compact item index
+    P.rank_pair.alloc(ctx, nP);
+    P.pair_rank.alloc(ctx, nP);
+    P.rank_item_raw.alloc(ctx, nP);
+    {
+        DevBuf<uint64_t> ka(ctx, nP), kb(ctx, nP);
+        DevBuf<uint32_t> va(ctx, nP), vb(ctx, nP);
+        k_rank_keys<<<grid_for(nP), 256, 0, st>>>(nP, P.pair_cluster.get(), P.pair_start.get(), ka.get(), va.get());
+        FY_KERNEL_CHECK();
+        sort_pairs_u64_u32(ctx, ka.get(), kb.get(), va.get(), vb.get(), nP);
+        k_scatter_ranks<<<grid_for(nP), 256, 0, st>>>(nP, vb.get(), P.pair_cluster.get(), P.d_pcstart.get(), P.pair_di.get(),
+                                                       P.iid.get(), P.rank_pair.get(), P.pair_rank.get(), P.rank_item_raw.get());
+        FY_KERNEL_CHECK();
+    }
+
+    // ---- sort #6: CSR in slot order, compact index ascending inside a row
+    {
+        DevBuf<uint64_t> ka(ctx, nnz), kb(ctx, nnz);
+        k_csr_keys<<<grid_for(nnz), 256, 0, st>>>(nnz, P.csc_slot.get(), P.csc_pair.get(), P.pair_rank.get(), ka.get());
+        FY_KERNEL_CHECK();
+        P.csr_r.alloc(ctx, nnz);
+        sort_pairs_u64_f32(ctx, ka.get(), kb.get(), P.csc_r.get(), P.csr_r.get(), nnz);
+        P.csr_idx.alloc(ctx, nnz);
+        k_low32<<<grid_for(nnz), 256, 0, st>>>(nnz, kb.get(), P.csr_idx.get());
+        FY_KERNEL_CHECK();
+    }
+
+    // ---- row pointers, work model
+    {
+        DevBuf<int32_t> deg_slot(ctx, (size_t)nU + 1);
+        DevBuf<int64_t> work(ctx, nU), deg2(ctx, nU), wpre(ctx, nU), d2pre(ctx, nU);
+        k_slot_degrees<<<grid_for(nU), 256, 0, st>>>(nU, P.slot2du.get(), P.udeg.get(), P.ucluster.get(), P.d_pcstart.get(),
+                                                      deg_slot.get(), work.get(), deg2.get());
+        FY_KERNEL_CHECK();
+        FY_HIP(hipMemsetAsync(deg_slot.get() + nU, 0, sizeof(int32_t), st));
+        P.rowptr.alloc(ctx, (size_t)nU + 1);
+        exclusive_scan_i32(ctx, deg_slot.get(), P.rowptr.get(), (size_t)nU + 1);
+        inclusive_scan_i64(ctx, work.get(), wpre.get(), nU);
+        inclusive_scan_i64(ctx, deg2.get(), d2pre.get(), nU);
+        P.work_prefix.resize(nU);
+        d2h(ctx, P.work_prefix.data(), wpre.get(), (size_t)nU);
+        d2h(ctx, &P.sum_deg2, d2pre.get() + (nU - 1), 1);
+        sync(ctx);
+    }
+}
+
+void rank_slot_range(const Prepared& P, int rank, int world, int32_t& lo, int32_t& hi) {
+    const int32_t n = P.nU;
+    if (world <= 1 || n == 0) { lo = 0; hi = n; return; }
+    const int64_t total = P.work_prefix[n - 1];
+    auto cut = [&](int r) -> int32_t {
+        if (r <= 0) return 0;
+        if (r >= world) return n;
+        // first slot whose inclusive prefix exceeds r/world of the work
+        const __int128 target = (__int128)total * r / world;
+        return (int32_t)(std::upper_bound(P.work_prefix.begin(), P.work_prefix.end(), (int64_t)target) - P.work_prefix.begin());
+    };
+    lo = cut(rank);
+    hi = cut(rank + 1);
+}
+
+}  // namespace fy

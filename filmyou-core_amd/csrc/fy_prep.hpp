@@ -1,0 +1,61 @@
+// fy_prep.hpp -- the rating matrix as it lives in HBM: cluster-major CSR (user rows) + CSC (item columns).
+//
+// Layout (all int32 offsets; nnz < 2^31):
+//   users   : dense index du = rank of the raw user id (ascending).  "slot" = position in cluster-major order,
+//             inside a cluster by descending degree (heavy rows first => balanced tail).  ucstart[c] .. ucstart[c+1]
+//             are the slots of cluster c.
+//   items   : per cluster only the items rated by somebody of that cluster exist (AbstractRM2Reducer.java:238-272).
+//             A (cluster, item) "pair" gets the compact index idx = popularity rank inside the cluster (0 = most
+//             rated; ties ascending raw id), so the hot rows of the co-rating matrix are the low rows.
+//             pcstart[c] + idx addresses per-cluster item arrays ("rank order").
+//   CSR     : rowptr[slot], csr_idx (compact idx, ascending inside a row), csr_r (raw rating), csr_x, csr_e.
+//   CSC     : pair order = (cluster, raw item) ascending; pair_start[pair] .. pair_start[pair+1] index csc_slot /
+//             csc_r / csc_x; inside a column ascending raw user id.
+#pragma once
+#include "fy_common.hpp"
+
+namespace fy {
+
+struct Prepared {
+    Context* ctx = nullptr;
+    int64_t nnz = 0;          // ratings kept (score > 0)
+    int32_t nU = 0, nI = 0, nP = 0, K = 0;
+    int64_t sum_deg2 = 0;     // sum_u n_u^2
+    // users, dense (ascending raw id)
+    DevBuf<int32_t> uid, ucluster, udeg, slot2du, du2slot;
+    DevBuf<double> usum;
+    // items, dense (ascending raw id)
+    DevBuf<int32_t> iid;
+    // cluster tables (host + device)
+    std::vector<int32_t> csize, ucstart, pcstart;   // K, K+1, K+1
+    DevBuf<int32_t> d_ucstart, d_pcstart, d_csize;
+    // pairs, (cluster, item) ascending
+    DevBuf<int32_t> pair_cluster, pair_di, pair_start /* nP+1 */, pair_rank, rank_pair;
+    // per-cluster item arrays in rank order (index pcstart[c] + idx)
+    DevBuf<int32_t> rank_item_raw;
+    // CSC (pair order)
+    DevBuf<int32_t> csc_slot, csc_pair;
+    DevBuf<float> csc_r;
+    // CSR (slot order)
+    DevBuf<int32_t> rowptr /* nU+1 */, csr_idx;
+    DevBuf<float> csr_r;
+    // per-slot work model n_u * (I_c - n_u), inclusive prefix (host copy, used to cut rank ranges)
+    std::vector<int64_t> work_prefix;
+};
+
+// Builds every structure that does not depend on the job's statistics.  map_* are host arrays (may be empty).
+// Throws fy::Failure.
+void build_structure(Context* ctx, const fy_ratings* R, int32_t n_clusters, int64_t n_map, const int32_t* map_user,
+                     const int32_t* map_cluster, const int32_t* cluster_count, bool keep_nonpositive, Prepared& P);
+
+// slot range [lo, hi) of `rank` out of `world`, cut on the work prefix (identical on every rank)
+void rank_slot_range(const Prepared& P, int rank, int world, int32_t& lo, int32_t& hi);
+
+// generic device helpers implemented with rocPRIM (radix sort / scan), all on ctx->stream
+void sort_pairs_u64_u32(Context*, uint64_t* kin, uint64_t* kout, uint32_t* vin, uint32_t* vout, size_t n, int end_bit = 64);
+void sort_pairs_u64_f32(Context*, uint64_t* kin, uint64_t* kout, float* vin, float* vout, size_t n, int end_bit = 64);
+void inclusive_scan_u32(Context*, const uint32_t* in, uint32_t* out, size_t n);
+void exclusive_scan_i32(Context*, const int32_t* in, int32_t* out, size_t n);
+void inclusive_scan_i64(Context*, const int64_t* in, int64_t* out, size_t n);
+
+}  // namespace fy

@@ -1,0 +1,690 @@
+// fy_rm2.hip -- the RM2 relevance-model job on MI355X: statistics, per-cluster M matrix, p(i|u) scoring, top-N.
+//
+// Math (SURVEY.md section 8a "RM2 in one place"; reference M/rm/AbstractRM2Reducer.java:185-190, 321-371, 384-389):
+//     c_vi       = (1-l) r_vi / s_v + l p_i                                  (probItemGivenUser, :384-389)
+//     score(u,i) = (n-1) ln M - n ln U_c + sum_{j in rated(u)} ln( sum_{v != u} c_vi c_vj )   for i unrated by u
+// The reference evaluates the inner sum with U_c - 1 multiply-adds per (i, j).  Here it is hoisted: for i NOT rated by u
+// (x_ui = 0, x = r/s)
+//     sum_{v != u} c_vi c_vj = M[j][i] + (l p_i) * e_uj
+//     M[j][i] = (1-l)^2 (X^T X)_ij + l (1-l) p_j b_i          per cluster, dense fp32 in HBM, b_i = sum_v x_vi
+//     e_uj    = (1-l) (b_j - x_uj) + l (U_c - 1) p_j           per rating of u (= sum_{v != u} c_vj), fp32
+// Every term of that form is non-negative, so there is no cancellation even for 2-user clusters; U_c = 1 gives
+// exactly 0 -> ln 0 = -inf like the reference (quirk Q7).  Logs are v_log_f32 (base 2, scaled by ln 2 at the end);
+// eight of them are added in fp32 and folded into an fp64 running sum, which keeps the relative error of a
+// 10^4-term score near 1e-7 (tolerance of north_star: 1e-5).
+#include <algorithm>
+#include <cmath>
+
+#include "fy_cooc.hpp"
+#include "fy_prep.hpp"
+#include "fy_rm2.hpp"
+
+namespace fy {
+
+static inline int grid_for(int64_t n, int block = 256, int cap = 256 * 16) {
+    int64_t g = ceil_div(n, block);
+    return (int)std::max<int64_t>(1, std::min<int64_t>(g, cap));
+}
+
+// ================================================================ statistics (jobs RM2-1 / RM2-2)
+// this rank's partial per-item sums: sum of (double) score over the ratings of the users in [lo, hi)
+__global__ void k_partial_item_sums(int64_t nnz, const int32_t* __restrict__ csc_slot, const int32_t* __restrict__ csc_pair,
+                                    const float* __restrict__ csc_r, const int32_t* __restrict__ pair_di, int32_t lo,
+                                    int32_t hi, double* __restrict__ partial) {
+    for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < nnz; q += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t s = csc_slot[q];
+        if (s >= lo && s < hi) atomicAdd(&partial[pair_di[csc_pair[q]]], (double)csc_r[q]);
+    }
+}
+
+// quirk Q1: the Hadoop counter adds (long) s_u * 100 per user and is divided by 100 afterwards
+// (DoubleSumAndCountReducer.java:41, RM2Job.java:95): the total is sum_u floor(s_u).
+__global__ void k_partial_total(int32_t lo, int32_t hi, const int32_t* __restrict__ slot2du, const double* __restrict__ usum,
+                                unsigned long long* __restrict__ counter) {
+    unsigned long long local = 0;
+    for (int32_t s = lo + blockIdx.x * blockDim.x + threadIdx.x; s < hi; s += gridDim.x * blockDim.x)
+        local += (unsigned long long)((long long)usum[slot2du[s]] * 100LL);
+    for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o, 64);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(counter, local);
+}
+__global__ void k_store_total(const unsigned long long* __restrict__ counter, double* __restrict__ dst) {
+    *dst = (double)*counter;   // exact below 2^53; the division by OFFSET = 100 happens after the exchange
+}
+
+// fixed rank order => bit-reproducible regardless of how the all-gather was scheduled
+__global__ void k_sum_gathered(int64_t len, int32_t world, const double* __restrict__ gathered, double* __restrict__ out) {
+    for (int64_t d = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; d < len; d += (int64_t)gridDim.x * blockDim.x) {
+        double s = 0.0;
+        for (int r = 0; r < world; r++) s += gathered[(int64_t)r * len + d];
+        out[d] = s;
+    }
+}
+
+// p(i|C) = itemsum / totalSum (DoubleSumAndDividerReducer.java:35-44); stats[nI] holds the counter (x100)
+__global__ void k_item_coll(int32_t nI, const double* __restrict__ stats, double* __restrict__ icoll, double* __restrict__ total_out) {
+    const double total = stats[nI] / 100.0;
+    for (int32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < nI; d += gridDim.x * blockDim.x) icoll[d] = stats[d] / total;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *total_out = total;
+}
+
+// one wave per (cluster, item) in rank order: b = sum_v r_vi / s_v (fixed order), p, a = l * p
+__global__ void k_pair_stats(int32_t nP, const int32_t* __restrict__ rank_pair, const int32_t* __restrict__ pair_start,
+                             const int32_t* __restrict__ pair_di, const int32_t* __restrict__ csc_slot,
+                             const float* __restrict__ csc_r, const int32_t* __restrict__ slot2du, const double* __restrict__ usum,
+                             const double* __restrict__ icoll, double lambda, double* __restrict__ p_rank,
+                             double* __restrict__ b_rank, float* __restrict__ a_rank) {
+    const int lane = threadIdx.x & 63;
+    const int wpb = blockDim.x >> 6;
+    for (int32_t pos = blockIdx.x * wpb + (threadIdx.x >> 6); pos < nP; pos += gridDim.x * wpb) {
+        const int32_t pr = rank_pair[pos];
+        const int32_t q0 = pair_start[pr], q1 = pair_start[pr + 1];
+        double b = 0.0;
+        for (int32_t q = q0 + lane; q < q1; q += 64) b += (double)csc_r[q] / usum[slot2du[csc_slot[q]]];
+        for (int o = 32; o > 0; o >>= 1) b += __shfl_down(b, o, 64);
+        if (lane == 0) {
+            const double p = icoll[pair_di[pr]];
+            p_rank[pos] = p;
+            b_rank[pos] = b;
+            a_rank[pos] = (float)(lambda * p);
+        }
+    }
+}
+
+__global__ void k_csc_x(int64_t nnz, const int32_t* __restrict__ csc_slot, const float* __restrict__ csc_r,
+                        const int32_t* __restrict__ slot2du, const double* __restrict__ usum, float* __restrict__ csc_x) {
+    for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < nnz; q += (int64_t)gridDim.x * blockDim.x)
+        csc_x[q] = (float)((double)csc_r[q] / usum[slot2du[csc_slot[q]]]);
+}
+
+// one wave per user row: x = r / s_u and e = (1-l)(b_j - x) + l (U_c - 1) p_j  (all fp64, rounded once)
+__global__ void k_csr_values(int32_t nU, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ csr_idx,
+                             const float* __restrict__ csr_r, const int32_t* __restrict__ slot2du,
+                             const int32_t* __restrict__ ucluster, const double* __restrict__ usum,
+                             const int32_t* __restrict__ csize, const int32_t* __restrict__ pcstart,
+                             const double* __restrict__ p_rank, const double* __restrict__ b_rank, double lambda,
+                             float* __restrict__ csr_x, float* __restrict__ csr_e) {
+    const int lane = threadIdx.x & 63;
+    const int wpb = blockDim.x >> 6;
+    for (int32_t s = blockIdx.x * wpb + (threadIdx.x >> 6); s < nU; s += gridDim.x * wpb) {
+        const int32_t du = slot2du[s];
+        const int32_t c = ucluster[du];
+        const double sum = usum[du];
+        const double Uc1 = (double)(csize[c] - 1);
+        const int32_t pb = pcstart[c];
+        for (int32_t f = rowptr[s] + lane; f < rowptr[s + 1]; f += 64) {
+            const int32_t j = csr_idx[f];
+            const double x = (double)csr_r[f] / sum;
+            double e = (1.0 - lambda) * (b_rank[pb + j] - x) + lambda * Uc1 * p_rank[pb + j];
+            if (!(e > 0.0)) e = 0.0;
+            csr_x[f] = (float)x;
+            csr_e[f] = (float)e;
+        }
+    }
+}
+
+// per slot of this rank: pvpi, whether the user gets a list, how many rows it emits
+__global__ void k_user_meta(int32_t lo, int32_t hi, const int32_t* __restrict__ slot2du, const int32_t* __restrict__ uid,
+                            const int32_t* __restrict__ ucluster, const int32_t* __restrict__ udeg,
+                            const int32_t* __restrict__ csize, const int32_t* __restrict__ pcstart, int32_t number_of_items,
+                            int32_t top_n, int32_t filter_users, double* __restrict__ pvpi, int32_t* __restrict__ n_out,
+                            unsigned long long* __restrict__ counters /* [0] log terms, [1] users scored */) {
+    unsigned long long terms = 0, scored = 0;
+    for (int32_t s = lo + blockIdx.x * blockDim.x + threadIdx.x; s < hi; s += gridDim.x * blockDim.x) {
+        const int32_t du = slot2du[s];
+        const int32_t c = ucluster[du];
+        const int32_t n = udeg[du];
+        const int32_t Ic = pcstart[c + 1] - pcstart[c];
+        const int32_t unrated = Ic - n;
+        // AbstractRM2Reducer.java:327-329
+        pvpi[s - lo] = (double)(n - 1) * log((double)number_of_items) - (double)n * log((double)csize[c]);
+        // :210-213 (no unrated item -> skipped with a warning), :221-223 (filterUsers)
+        const bool skip = unrated <= 0 || uid[du] < filter_users;
+        int32_t k = skip ? 0 : min(top_n, unrated);
+        if (k < 0) k = 0;
+        n_out[s - lo] = k;
+        if (!skip) { terms += (unsigned long long)n * (unsigned long long)unrated; scored++; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        terms += __shfl_down(terms, o, 64);
+        scored += __shfl_down(scored, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (terms) atomicAdd(&counters[0], terms);
+        if (scored) atomicAdd(&counters[1], scored);
+    }
+}
+
+// ================================================================ chunk offsets for the row kernel
+__global__ void k_chunk_offsets(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ csr_idx, int32_t slot_base,
+                                int32_t n_slots, int32_t CH, int32_t nch, int32_t* __restrict__ chunk_off) {
+    const int64_t total = (int64_t)n_slots * (nch + 1);
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t v = (int32_t)(t / (nch + 1)), ch = (int32_t)(t % (nch + 1));
+        const int32_t a = rowptr[slot_base + v], b = rowptr[slot_base + v + 1];
+        int32_t lo = a, hi = b;
+        const int32_t key = ch * CH;   // first entry with idx >= key
+        while (lo < hi) {
+            const int32_t mid = (lo + hi) >> 1;
+            if (csr_idx[mid] < key) lo = mid + 1; else hi = mid;
+        }
+        chunk_off[t] = (ch == nch) ? b : lo;
+    }
+}
+
+void build_chunk_offsets(Context* ctx, const int32_t* rowptr, const int32_t* csr_idx, int32_t slot_base, int32_t n_slots,
+                         int32_t CH, int32_t nch, int32_t* chunk_off) {
+    const int64_t total = (int64_t)n_slots * (nch + 1);
+    if (total == 0) return;
+    k_chunk_offsets<<<grid_for(total), 256, 0, ctx->stream>>>(rowptr, csr_idx, slot_base, n_slots, CH, nch, chunk_off);
+    FY_KERNEL_CHECK();
+}
+
+// ================================================================ M build: co-rating row kernel + RM2 epilogue
+struct MEpilogue {
+    float* __restrict__ M;
+    int64_t ldm;
+    const double* __restrict__ p_rank;   // already offset by pbase
+    const double* __restrict__ b_rank;
+    double w2;    // (1-l)^2
+    double w1;    // l (1-l)
+};
+
+__global__ void k_cooc_rm2(CoocArgs A, MEpilogue E) {
+    extern __shared__ double acc[];
+    const int row = A.row0 + blockIdx.x / A.nch;
+    const int ch = blockIdx.x % A.nch;
+    for (int t = threadIdx.x; t < A.CH; t += blockDim.x) acc[t] = 0.0;
+    __syncthreads();
+    cooc_accumulate_row(A, row, ch, acc);
+    __syncthreads();
+    const int c0 = ch * A.CH;
+    // the last chunk also writes the padding columns [Ic, ldm) so the scoring kernel may load whole 256-wide chunks
+    const int c1 = (ch == A.nch - 1) ? (int)E.ldm : min(c0 + A.CH, (int)E.ldm);
+    const double pj = E.p_rank[row];
+    float* __restrict__ out = E.M + (int64_t)row * E.ldm;
+    for (int col = c0 + threadIdx.x; col < c1; col += blockDim.x) {
+        float v = 0.0f;
+        if (col < A.Ic) v = (float)(E.w2 * acc[col - c0] + E.w1 * pj * E.b_rank[col]);
+        out[col] = v;
+    }
+}
+
+// ================================================================ scoring kernel (the dominant kernel)
+// Work item = (user, 256-column chunk): the wave walks the user's CSR row (wave-uniform scalar loads of idx and e) and
+// for every rated item j streams the 1 KiB segment M[j][chunk] (16 B per lane, coalesced), adding
+// log2(M[j][i] + a_i * e_uj) to the lane's four candidate items.  No cross-lane traffic at all.
+// Grid order is chunk-major, so at any time the resident workgroups read the same column panel of M: the panel
+// (I_c KiB) lives in the Infinity Cache and its popular low rows in the XCD L2s.
+struct ScoreArgs {
+    const float* __restrict__ M;
+    int64_t ldm;
+    int32_t Ic;
+    const float* __restrict__ a_rank;      // l * p_i in rank order, offset by pbase
+    const int32_t* __restrict__ rowptr;
+    const int32_t* __restrict__ csr_idx;
+    const float* __restrict__ csr_e;
+    const double* __restrict__ pvpi;       // indexed by slot - slot_lo
+    const int32_t* __restrict__ n_out;     // indexed by slot - slot_lo; 0 = user gets no list
+    int32_t slot_lo;                       // first slot of this rank
+    int32_t slot0;                         // first slot of this batch
+    int32_t n_users;                       // users in the batch
+    float* __restrict__ S;                 // [n_users][ldS]
+    int64_t ldS;
+    int32_t n_slices;
+};
+
+__device__ __forceinline__ float fy_log2(float x) { return __builtin_amdgcn_logf(x); }   // v_log_f32
+
+#define FY_SCORE_STEP(J, E)                                                              \
+    {                                                                                    \
+        const float4 g = *reinterpret_cast<const float4*>(Mcol + (int64_t)(J) * A.ldm);  \
+        p0 += fy_log2(fmaf(a.x, (E), g.x));                                              \
+        p1 += fy_log2(fmaf(a.y, (E), g.y));                                              \
+        p2 += fy_log2(fmaf(a.z, (E), g.z));                                              \
+        p3 += fy_log2(fmaf(a.w, (E), g.w));                                              \
+        const unsigned d = (unsigned)((J) - col0);                                       \
+        if (d < 256u && (int)(d >> 2) == lane) mask |= 1u << (d & 3u);                   \
+    }
+
+__global__ __launch_bounds__(256) void k_score(ScoreArgs A) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int chunk = blockIdx.x / A.n_slices;
+    const int slice = blockIdx.x - chunk * A.n_slices;
+    const int col0 = chunk * 256;
+    const int col = col0 + lane * 4;
+    float4 a;
+    a.x = col + 0 < A.Ic ? A.a_rank[col + 0] : 0.0f;
+    a.y = col + 1 < A.Ic ? A.a_rank[col + 1] : 0.0f;
+    a.z = col + 2 < A.Ic ? A.a_rank[col + 2] : 0.0f;
+    a.w = col + 3 < A.Ic ? A.a_rank[col + 3] : 0.0f;
+    const float* __restrict__ Mcol = A.M + col;
+    const double LN2 = 0.69314718055994530942;
+    const float qnan = __builtin_nanf("");
+    for (int u = slice * 4 + wave; u < A.n_users; u += A.n_slices * 4) {
+        const int slot = A.slot0 + u;
+        if (A.n_out[slot - A.slot_lo] == 0) continue;
+        const int beg = A.rowptr[slot], end = A.rowptr[slot + 1];
+        double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+        unsigned mask = 0;
+        int k = beg;
+        for (; k + 8 <= end; k += 8) {
+            float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; q++) FY_SCORE_STEP(A.csr_idx[k + q], A.csr_e[k + q]);
+            t0 += (double)p0; t1 += (double)p1; t2 += (double)p2; t3 += (double)p3;
+        }
+        {
+            float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+            for (; k < end; k++) FY_SCORE_STEP(A.csr_idx[k], A.csr_e[k]);
+            t0 += (double)p0; t1 += (double)p1; t2 += (double)p2; t3 += (double)p3;
+        }
+        const double base = A.pvpi[slot - A.slot_lo];
+        float4 o;
+        o.x = (mask & 1u) ? qnan : (float)(base + LN2 * t0);
+        o.y = (mask & 2u) ? qnan : (float)(base + LN2 * t1);
+        o.z = (mask & 4u) ? qnan : (float)(base + LN2 * t2);
+        o.w = (mask & 8u) ? qnan : (float)(base + LN2 * t3);
+        if (col + 0 >= A.Ic) o.x = qnan;
+        if (col + 1 >= A.Ic) o.y = qnan;
+        if (col + 2 >= A.Ic) o.z = qnan;
+        if (col + 3 >= A.Ic) o.w = qnan;
+        *reinterpret_cast<float4*>(A.S + (int64_t)u * A.ldS + col) = o;
+    }
+}
+
+// ================================================================ top-N (PriorityQueue + poll loop, AbstractRM2Reducer.java:325, 358-369)
+// One workgroup per user.  NaN marks "not a candidate" (rated by the user / padding).  Order: larger score first
+// (IntDouble.compareTo, M/util/IntDouble.java:31-34); ties, unspecified in the reference, by ascending raw item id
+// (at the cut-off of a truncated list: by ascending popularity rank).  Radix select on the order-preserving integer
+// image of the float finds the K-th value in three passes over the row (L2 resident), a fourth pass collects.
+struct TopNArgs {
+    const float* __restrict__ S;
+    int64_t ldS;
+    int32_t Ic;
+    const int32_t* __restrict__ n_out;     // by slot - slot_lo
+    const int32_t* __restrict__ out_off;   // by slot - slot_lo (exclusive prefix of n_out)
+    const int32_t* __restrict__ rank_item_raw;   // offset by pbase
+    const int32_t* __restrict__ slot2du;
+    const int32_t* __restrict__ uid;
+    int32_t slot_lo, slot0, cluster;
+    int32_t* __restrict__ out_user;
+    int32_t* __restrict__ out_item;
+    float* __restrict__ out_score;
+    int32_t* __restrict__ out_cluster;
+};
+
+__device__ __forceinline__ uint32_t fy_order_key(float f) {
+    const uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float fy_order_unkey(uint32_t k) {
+    const uint32_t b = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+    return __uint_as_float(b);
+}
+
+constexpr int TOPN_MAX = 2048;
+constexpr int TOPN_BINS = 4096;
+
+__global__ __launch_bounds__(256) void k_topn(TopNArgs A) {
+    __shared__ uint32_t hist[TOPN_BINS];
+    __shared__ uint64_t cand[TOPN_MAX];
+    __shared__ uint32_t sh_prefix, sh_need, sh_count, sh_eq_taken;
+    const int u = blockIdx.x;
+    const int slot = A.slot0 + u;
+    const int K = A.n_out[slot - A.slot_lo];
+    if (K == 0) return;
+    const float* __restrict__ row = A.S + (int64_t)u * A.ldS;
+    const int tid = threadIdx.x;
+
+    // ---- radix select: 12 + 10 + 10 bits, most significant first
+    uint32_t prefix = 0, prefix_mask = 0, need = (uint32_t)K;
+    const int shifts[3] = {20, 10, 0};
+    const int widths[3] = {12, 10, 10};
+    for (int pass = 0; pass < 3; pass++) {
+        const int nb = 1 << widths[pass];
+        for (int b = tid; b < nb; b += blockDim.x) hist[b] = 0;
+        __syncthreads();
+        for (int i = tid; i < A.Ic; i += blockDim.x) {
+            const float f = row[i];
+            if (f != f) continue;
+            const uint32_t key = fy_order_key(f);
+            if ((key & prefix_mask) == prefix) atomicAdd(&hist[(key >> shifts[pass]) & (nb - 1)], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t cum = 0;
+            int b = nb - 1;
+            for (; b > 0; b--) {
+                if (cum + hist[b] >= need) break;
+                cum += hist[b];
+            }
+            sh_prefix = prefix | ((uint32_t)b << shifts[pass]);
+            sh_need = need - cum;
+        }
+        __syncthreads();
+        prefix = sh_prefix;
+        need = sh_need;
+        prefix_mask |= (uint32_t)(nb - 1) << shifts[pass];
+        __syncthreads();
+    }
+    const uint32_t T = prefix;      // key of the K-th largest candidate; `need` of the entries equal to T are taken
+    // after the last pass hist[] counts exact keys: how many candidates tie with the K-th value
+    const uint32_t eq_total = hist[T & 1023u];
+    const bool take_all_eq = (eq_total == need);   // block-uniform; the common case (no tie across the cut-off)
+    __syncthreads();
+
+    // ---- collect everything above T (and the ties when all of them fit); order is fixed by the sort below
+    if (tid == 0) { sh_count = 0; sh_eq_taken = 0; }
+    __syncthreads();
+    for (int i = tid; i < A.Ic; i += blockDim.x) {
+        const float f = row[i];
+        if (f != f) continue;
+        const uint32_t key = fy_order_key(f);
+        if (key > T || (take_all_eq && key == T)) {
+            const uint32_t pos = atomicAdd(&sh_count, 1u);
+            if (pos < (uint32_t)TOPN_MAX) cand[pos] = ((uint64_t)key << 32) | (uint32_t)(0x7FFFFFFF - A.rank_item_raw[i]);
+        }
+    }
+    __syncthreads();
+    if (!take_all_eq) {
+        // a tie straddles the cut-off: take the first `need` tied entries in index (popularity-rank) order.
+        // Block-uniform loop: every thread reaches every barrier.
+        uint32_t* wave_cnt = hist;   // reuse
+        const int w = tid >> 6, ln = tid & 63, nw = blockDim.x >> 6;
+        for (int base = 0; base < A.Ic; base += blockDim.x) {
+            const int i = base + tid;
+            bool eq = false;
+            if (i < A.Ic) {
+                const float f = row[i];
+                eq = (f == f) && fy_order_key(f) == T;
+            }
+            const unsigned long long bal = __ballot(eq);
+            if (ln == 0) wave_cnt[w] = (uint32_t)__popcll(bal);
+            __syncthreads();
+            uint32_t off = sh_eq_taken, all = 0;
+            for (int x = 0; x < nw; x++) {
+                if (x < w) off += wave_cnt[x];
+                all += wave_cnt[x];
+            }
+            off += (uint32_t)__popcll(bal & ((1ull << ln) - 1ull));
+            if (eq && off < need) {
+                const uint32_t pos = atomicAdd(&sh_count, 1u);
+                if (pos < (uint32_t)TOPN_MAX) cand[pos] = ((uint64_t)T << 32) | (uint32_t)(0x7FFFFFFF - A.rank_item_raw[i]);
+            }
+            __syncthreads();
+            if (tid == 0) sh_eq_taken += all;
+            __syncthreads();
+            if (sh_eq_taken >= need) break;   // uniform: read after the barrier
+        }
+        __syncthreads();
+    }
+    const int n = min((int)sh_count, K);     // == K
+    int P2 = 1;
+    while (P2 < n) P2 <<= 1;
+    for (int i = n + tid; i < P2; i += blockDim.x) cand[i] = 0ull;
+    __syncthreads();
+    // ---- bitonic sort, descending on (score key, ~item)
+    for (int k = 2; k <= P2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < P2; i += blockDim.x) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const uint64_t x = cand[i], y = cand[l];
+                    const bool desc = (i & k) == 0;
+                    if (desc ? (x < y) : (x > y)) { cand[i] = y; cand[l] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const int off = A.out_off[slot - A.slot_lo];
+    const int user_raw = A.uid[A.slot2du[slot]];
+    for (int i = tid; i < n; i += blockDim.x) {
+        const uint64_t c = cand[i];
+        A.out_user[off + i] = user_raw;
+        A.out_item[off + i] = 0x7FFFFFFF - (int32_t)(uint32_t)c;
+        A.out_score[off + i] = fy_order_unkey((uint32_t)(c >> 32));   // already the (float) cast of RM2HDFSReducer.java:48
+        A.out_cluster[off + i] = A.cluster;
+    }
+}
+
+}  // namespace fy
+
+// ================================================================ job orchestration
+using namespace fy;
+
+struct fy_rm2_job {
+    Context* ctx = nullptr;
+    fy_rm2_params prm{};
+    Prepared P;
+    int32_t slot_lo = 0, slot_hi = 0;
+    DevBuf<double> partial;     // nI + 1 : this rank's exchange buffer
+    DevBuf<double> stats;       // nI + 1 : global sums (+ counter)
+    bool have_global = false;
+    double ms_prepare = 0;
+};
+
+static void validate_params(const fy_rm2_params* p) {
+    if (!p) FY_FAIL(FY_ERR_INVALID_ARGUMENT, "params is NULL");
+    if (p->number_of_clusters <= 0) FY_FAIL(FY_ERR_INVALID_ARGUMENT, "numberOfClusters must be > 0 (got %d)", p->number_of_clusters);
+    if (p->number_of_items <= 0) FY_FAIL(FY_ERR_INVALID_ARGUMENT, "numberOfItems must be > 0 (got %d)", p->number_of_items);
+    if (!(p->lambda >= 0.0 && p->lambda <= 1.0)) FY_FAIL(FY_ERR_INVALID_ARGUMENT, "lambda must be in [0, 1]");
+    if (p->world <= 0 || p->rank < 0 || p->rank >= p->world) FY_FAIL(FY_ERR_INVALID_ARGUMENT, "rank %d of world %d", p->rank, p->world);
+    if (p->number_of_recommendations < 0) FY_FAIL(FY_ERR_INVALID_ARGUMENT, "numberOfRecommendations must be >= 0");
+}
+
+fy_rm2_job* fy::rm2_prepare(Context* ctx, const fy_rm2_params* prm, const fy_ratings* R, int64_t n_map, const int32_t* map_user,
+                            const int32_t* map_cluster, const int32_t* cluster_count) {
+    validate_params(prm);
+    if (n_map < 0 || (n_map > 0 && (!map_user || !map_cluster))) FY_FAIL(FY_ERR_INVALID_ARGUMENT, "clustering map is NULL");
+    std::unique_ptr<fy_rm2_job> J(new fy_rm2_job);
+    J->ctx = ctx;
+    J->prm = *prm;
+    EventTimer tm(ctx);
+    const size_t span = tm.begin();
+    build_structure(ctx, R, prm->number_of_clusters, n_map, map_user, map_cluster, cluster_count, false, J->P);
+    Prepared& P = J->P;
+    rank_slot_range(P, prm->rank, prm->world, J->slot_lo, J->slot_hi);
+    J->partial.alloc(ctx, (size_t)P.nI + 1);
+    J->partial.zero();
+    if (P.nnz > 0) {
+        DevBuf<unsigned long long> counter(ctx, 1);
+        counter.zero();
+        k_partial_item_sums<<<grid_for(P.nnz), 256, 0, ctx->stream>>>(P.nnz, P.csc_slot.get(), P.csc_pair.get(), P.csc_r.get(),
+                                                                      P.pair_di.get(), J->slot_lo, J->slot_hi, J->partial.get());
+        FY_KERNEL_CHECK();
+        if (J->slot_hi > J->slot_lo) {
+            k_partial_total<<<grid_for(J->slot_hi - J->slot_lo), 256, 0, ctx->stream>>>(J->slot_lo, J->slot_hi, P.slot2du.get(),
+                                                                                         P.usum.get(), counter.get());
+            FY_KERNEL_CHECK();
+        }
+        k_store_total<<<1, 1, 0, ctx->stream>>>(counter.get(), J->partial.get() + P.nI);
+        FY_KERNEL_CHECK();
+    }
+    tm.end(span);
+    sync(ctx);
+    J->ms_prepare = tm.total_ms();
+    return J.release();
+}
+
+void fy::rm2_set_global_stats(fy_rm2_job* J, const double* gathered, int32_t world) {
+    Context* ctx = J->ctx;
+    if (world != J->prm.world) FY_FAIL(FY_ERR_INVALID_ARGUMENT, "gathered world %d != params.world %d", world, J->prm.world);
+    const int64_t len = (int64_t)J->P.nI + 1;
+    J->stats.alloc(ctx, (size_t)len);
+    k_sum_gathered<<<grid_for(len), 256, 0, ctx->stream>>>(len, world, gathered, J->stats.get());
+    FY_KERNEL_CHECK();
+    J->have_global = true;
+}
+
+fy_result* fy::rm2_score(fy_rm2_job* J) {
+    Context* ctx = J->ctx;
+    Prepared& P = J->P;
+    const fy_rm2_params& prm = J->prm;
+    hipStream_t st = ctx->stream;
+    if (!J->have_global) {
+        if (prm.world != 1) FY_FAIL(FY_ERR_STATE, "fy_rm2_set_global_stats must be called before fy_rm2_score when world > 1");
+        rm2_set_global_stats(J, J->partial.get(), 1);
+    }
+    std::unique_ptr<fy_result> R(new fy_result);
+    R->ctx = ctx;
+    R->kind = 0;
+    R->st.nnz = P.nnz;
+    R->st.n_users = P.nU;
+    R->st.n_items = P.nI;
+    R->st.ms_prepare = J->ms_prepare;
+    EventTimer t_total(ctx), t_cooc(ctx), t_score(ctx), t_topn(ctx);
+    const size_t span_total = t_total.begin();
+    if (P.nnz == 0) {
+        t_total.end(span_total);
+        sync(ctx);
+        return R.release();
+    }
+    const int32_t nU = P.nU, nP = P.nP, nI = P.nI, K = P.K;
+    const double lambda = prm.lambda;
+
+    // ---- p(i|C), per-(cluster,item) statistics, per-rating values
+    R->d_icoll.alloc(ctx, nI);
+    DevBuf<double> d_total(ctx, 1);
+    k_item_coll<<<grid_for(nI), 256, 0, st>>>(nI, J->stats.get(), R->d_icoll.get(), d_total.get());
+    FY_KERNEL_CHECK();
+    DevBuf<double> p_rank(ctx, nP), b_rank(ctx, nP);
+    DevBuf<float> a_rank(ctx, nP);
+    k_pair_stats<<<grid_for((int64_t)nP * 64, 256), 256, 0, st>>>(nP, P.rank_pair.get(), P.pair_start.get(), P.pair_di.get(),
+                                                                   P.csc_slot.get(), P.csc_r.get(), P.slot2du.get(), P.usum.get(),
+                                                                   R->d_icoll.get(), lambda, p_rank.get(), b_rank.get(), a_rank.get());
+    FY_KERNEL_CHECK();
+    DevBuf<float> csc_x(ctx, P.nnz), csr_x(ctx, P.nnz), csr_e(ctx, P.nnz);
+    k_csc_x<<<grid_for(P.nnz), 256, 0, st>>>(P.nnz, P.csc_slot.get(), P.csc_r.get(), P.slot2du.get(), P.usum.get(), csc_x.get());
+    FY_KERNEL_CHECK();
+    k_csr_values<<<grid_for((int64_t)nU * 64, 256), 256, 0, st>>>(nU, P.rowptr.get(), P.csr_idx.get(), P.csr_r.get(), P.slot2du.get(),
+                                                                   P.ucluster.get(), P.usum.get(), P.d_csize.get(), P.d_pcstart.get(),
+                                                                   p_rank.get(), b_rank.get(), lambda, csr_x.get(), csr_e.get());
+    FY_KERNEL_CHECK();
+
+    // ---- per-user meta for this rank's slots, output offsets
+    const int32_t lo = J->slot_lo, hi = J->slot_hi, nmine = hi - lo;
+    DevBuf<double> pvpi(ctx, (size_t)nmine + 1);
+    DevBuf<int32_t> n_out(ctx, (size_t)nmine + 1), out_off(ctx, (size_t)nmine + 1);
+    DevBuf<unsigned long long> counters(ctx, 2);
+    counters.zero();
+    n_out.zero();
+    if (nmine > 0) {
+        k_user_meta<<<grid_for(nmine), 256, 0, st>>>(lo, hi, P.slot2du.get(), P.uid.get(), P.ucluster.get(), P.udeg.get(),
+                                                      P.d_csize.get(), P.d_pcstart.get(), prm.number_of_items,
+                                                      prm.number_of_recommendations, prm.filter_users, pvpi.get(), n_out.get(), counters.get());
+        FY_KERNEL_CHECK();
+    }
+    exclusive_scan_i32(ctx, n_out.get(), out_off.get(), (size_t)nmine + 1);
+    const int64_t n_recs = fetch(ctx, out_off.get() + nmine);
+    {
+        unsigned long long hc[2];
+        d2h(ctx, hc, counters.get(), 2);
+        sync(ctx);
+        R->st.log_terms = (int64_t)hc[0];
+        R->st.users_scored = (int64_t)hc[1];
+    }
+    R->n = n_recs;
+    R->st.recs = n_recs;
+    R->d_key0.alloc(ctx, (size_t)n_recs);
+    R->d_key1.alloc(ctx, (size_t)n_recs);
+    R->d_value.alloc(ctx, (size_t)n_recs);
+    R->d_aux.alloc(ctx, (size_t)n_recs);
+
+    // ---- clusters that hold users of this rank
+    int64_t max_Ic = 0;
+    for (int c = 0; c < K; c++) {
+        if (P.csize[c] == 0) continue;
+        R->st.n_clusters_nonempty++;
+        const int32_t a = std::max(lo, P.ucstart[c]), b = std::min(hi, P.ucstart[c + 1]);
+        if (a < b) max_Ic = std::max<int64_t>(max_Ic, P.pcstart[c + 1] - P.pcstart[c]);
+    }
+    const int32_t eff_top = (int32_t)std::min<int64_t>(prm.number_of_recommendations, max_Ic);
+    if (eff_top > TOPN_MAX)
+        FY_FAIL(FY_ERR_UNSUPPORTED, "min(numberOfRecommendations, items per cluster) = %d exceeds the top-N kernel limit %d", eff_top, TOPN_MAX);
+    if (n_recs > 0 && max_Ic > 0) {
+        const int64_t ldm_max = round_up(max_Ic, 256);
+        DevBuf<float> M(ctx, (size_t)(max_Ic * ldm_max));
+        const int64_t ws = prm.workspace_bytes > 0 ? prm.workspace_bytes : (int64_t)16 << 30;
+        const int max_ch_lds = 16384;   // fp64 accumulators: 128 KiB of the 160 KiB LDS
+        FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cooc_rm2), hipFuncAttributeMaxDynamicSharedMemorySize, max_ch_lds * 8));
+
+        for (int c = 0; c < K; c++) {
+            const int32_t Uc = P.csize[c];
+            if (Uc == 0) continue;
+            const int32_t sbase = P.ucstart[c], pbase = P.pcstart[c];
+            const int32_t Ic = P.pcstart[c + 1] - pbase;
+            const int32_t a = std::max(lo, sbase), b = std::min(hi, sbase + Uc);
+            if (a >= b || Ic == 0) continue;
+            const int64_t ldm = round_up(Ic, 256);
+
+            // -- M build
+            int32_t CH, nch;
+            pick_chunks(Ic, max_ch_lds, CH, nch);
+            DevBuf<int32_t> chunk_off(ctx, (size_t)Uc * (nch + 1));
+            build_chunk_offsets(ctx, P.rowptr.get(), P.csr_idx.get(), sbase, Uc, CH, nch, chunk_off.get());
+            CoocArgs CA{P.rank_pair.get(), P.pair_start.get(), P.csc_slot.get(), csc_x.get(), chunk_off.get(), P.csr_idx.get(),
+                        csr_x.get(), pbase, sbase, Ic, CH, nch, 0, Ic};
+            MEpilogue ME{M.get(), ldm, p_rank.get() + pbase, b_rank.get() + pbase, (1.0 - lambda) * (1.0 - lambda), lambda * (1.0 - lambda)};
+            const int block = (CH * 8 > 48 * 1024) ? 1024 : 256;
+            const size_t sp = t_cooc.begin();
+            k_cooc_rm2<<<Ic * nch, block, (size_t)CH * 8, st>>>(CA, ME);
+            FY_KERNEL_CHECK();
+            t_cooc.end(sp);
+            R->st.cooc_launches++;
+
+            // -- scoring + top-N in user batches that fit the score scratch
+            const int64_t ldS = ldm;
+            int64_t B = std::max<int64_t>(1, ws / (ldS * 4));
+            B = std::min<int64_t>(B, b - a);
+            DevBuf<float> S(ctx, (size_t)(B * ldS));
+            const int n_chunks = (int)(ldm / 256);
+            for (int32_t s0 = a; s0 < b; s0 += (int32_t)B) {
+                const int32_t nb = (int32_t)std::min<int64_t>(B, b - s0);
+                int n_slices = (int)std::max<int64_t>(1, std::min<int64_t>(1024, ceil_div(nb, 4 * 16)));
+                ScoreArgs SA{M.get(), ldm, Ic, a_rank.get() + pbase, P.rowptr.get(), P.csr_idx.get(), csr_e.get(), pvpi.get(),
+                             n_out.get(), lo, s0, nb, S.get(), ldS, n_slices};
+                const size_t ss = t_score.begin();
+                k_score<<<n_chunks * n_slices, 256, 0, st>>>(SA);
+                FY_KERNEL_CHECK();
+                t_score.end(ss);
+                R->st.score_launches++;
+                TopNArgs TA{S.get(), ldS, Ic, n_out.get(), out_off.get(), P.rank_item_raw.get() + pbase, P.slot2du.get(), P.uid.get(),
+                            lo, s0, c, R->d_key0.get(), R->d_key1.get(), R->d_value.get(), R->d_aux.get()};
+                const size_t tt = t_topn.begin();
+                k_topn<<<nb, 256, 0, st>>>(TA);
+                FY_KERNEL_CHECK();
+                t_topn.end(tt);
+            }
+        }
+    }
+    // rm2/userSum and rm2/itemColl stay in HBM until somebody asks for them
+    R->d_user_id.alloc(ctx, nU);
+    R->d_user_sum.alloc(ctx, nU);
+    d2d(ctx, R->d_user_id.get(), P.uid.get(), nU);
+    d2d(ctx, R->d_user_sum.get(), P.usum.get(), nU);
+    R->d_item_id.alloc(ctx, nI);
+    d2d(ctx, R->d_item_id.get(), P.iid.get(), nI);
+    t_total.end(span_total);
+    d2h(ctx, &R->total_sum, d_total.get(), 1);
+    sync(ctx);
+    R->st.pair_contribs = P.sum_deg2;
+    R->st.ms_cooc = t_cooc.total_ms();
+    R->st.ms_score = t_score.total_ms();
+    R->st.ms_topn = t_topn.total_ms();
+    R->st.ms_total = t_total.total_ms();
+    return R.release();
+}
+
+void fy::rm2_partial_stats(fy_rm2_job* J, double** buf, int64_t* len) {
+    *buf = J->partial.get();
+    *len = (int64_t)J->P.nI + 1;
+}
+
+void fy::rm2_job_destroy(fy_rm2_job* J) {
+    if (!J) return;
+    Context* ctx = J->ctx;
+    delete J;
+    (void)hipStreamSynchronize(ctx->stream);
+}

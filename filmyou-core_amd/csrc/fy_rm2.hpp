@@ -1,0 +1,33 @@
+// fy_rm2.hpp -- internal interface between the C ABI (fy_api.hip) and the job implementations.
+#pragma once
+#include <memory>
+
+#include "fy_common.hpp"
+
+// result rows live in HBM until an accessor asks for them
+struct fy_result {
+    fy::Context* ctx = nullptr;
+    int kind = 0;   // 0 = RM2, 1 = item-sim
+    int64_t n = 0;
+    fy::DevBuf<int32_t> d_key0, d_key1, d_aux;
+    fy::DevBuf<float> d_value;
+    fy::DevBuf<int32_t> d_user_id, d_item_id;
+    fy::DevBuf<double> d_user_sum, d_icoll;
+    double total_sum = 0.0;
+    fy_stats st{};
+    // host mirrors, filled on first access
+    bool rows_on_host = false, sums_on_host = false;
+    std::vector<int32_t> h_key0, h_key1, h_aux, h_user_id, h_item_id;
+    std::vector<float> h_value;
+    std::vector<double> h_user_sum, h_icoll;
+};
+
+namespace fy {
+fy_rm2_job* rm2_prepare(Context*, const fy_rm2_params*, const fy_ratings*, int64_t n_map, const int32_t* map_user,
+                        const int32_t* map_cluster, const int32_t* cluster_count);
+void rm2_partial_stats(fy_rm2_job*, double** buf, int64_t* len);
+void rm2_set_global_stats(fy_rm2_job*, const double* gathered, int32_t world);
+fy_result* rm2_score(fy_rm2_job*);
+void rm2_job_destroy(fy_rm2_job*);
+fy_result* itemsim_build(Context*, const fy_itemsim_params*, const fy_ratings*);
+}  // namespace fy

@@ -1,0 +1,338 @@
+"""Host side of the drop-in: the reference's job interface re-stated over the C ABI.
+
+Mirrors (same names, argument meaning, error behaviour):
+  * Hadoop ``Configuration`` with the keys of M/rmrecommender/RMRecommenderDriver.java:49-120
+  * ``RM2Job.run`` (M/rm/RM2Job.java:76-100): returns 0-equivalent (a result object) or raises
+    ``RuntimeError("<job> failed!: ...")`` like RM2Job.java:144-147
+  * ``RowSimilarityJob.run`` with the option names passed at M/baselinerecommender/BaselineRecommenderJob.java:241-253
+The reference's Cassandra / HDFS readers and writers stay on the Java side (north_star: unchanged); this layer takes
+the rating triples they produce and returns the rows they consume.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native
+
+SIMILARITY_COSINE = "SIMILARITY_COSINE"
+SIMILARITY_COOCCURRENCE = "SIMILARITY_COOCCURRENCE"
+_SIMILARITY = {SIMILARITY_COSINE: 0, SIMILARITY_COOCCURRENCE: 1}
+
+
+class FilmYouError(RuntimeError):
+    """A non-zero fy_status from the native library."""
+
+    def __init__(self, code, message):
+        super().__init__("fy_status %d: %s" % (code, message))
+        self.code = code
+        self.message = message
+
+
+def _check(rc):
+    if rc != 0:
+        raise FilmYouError(rc, _native.load().fy_last_error().decode(errors="replace"))
+
+
+class Configuration(dict):
+    """The slice of org.apache.hadoop.conf.Configuration the jobs read: string values, typed getters with defaults."""
+
+    # option names of RMRecommenderDriver (M/rmrecommender/RMRecommenderDriver.java:49-120) and their defaults
+    DEFAULTS = {"lambda": "0.1", "numberOfRecommendations": "1000", "clusterSplit": "400", "splitSize": "100",
+                "filterUsers": "0", "directory": "recommendation", "clustering": "clustering",
+                "clusteringCount": "clusteringCount"}
+
+    def set(self, key, value):
+        self[key] = str(value)
+
+    def setInt(self, key, value):
+        self[key] = str(int(value))
+
+    def setFloat(self, key, value):
+        # Configuration.setFloat stores Float.toString(value): 0.5f -> "0.5" (quirk Q3)
+        self[key] = str(np.float32(value))
+
+    def setBoolean(self, key, value):
+        self[key] = "true" if value else "false"
+
+    def get(self, key, default=None):
+        if key in self:
+            return dict.get(self, key)
+        return self.DEFAULTS.get(key, default)
+
+    def getInt(self, key, default):
+        v = self.get(key)
+        return int(v) if v is not None else default
+
+    def getDouble(self, key, default):
+        v = self.get(key)
+        return float(v) if v is not None else default
+
+    def getBoolean(self, key, default):
+        v = self.get(key)
+        return (str(v).lower() == "true") if v is not None else default
+
+
+class Context:
+    """One GPU, one HIP stream (fy_context)."""
+
+    def __init__(self, device=0):
+        self._lib = _native.load()
+        h = C.c_void_p()
+        _check(self._lib.fy_context_create(int(device), C.byref(h)))
+        self._h = h
+        self.device = int(device)
+
+    def synchronize(self):
+        _check(self._lib.fy_context_synchronize(self._h))
+
+    @property
+    def stream(self):
+        return self._lib.fy_context_stream(self._h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.fy_context_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _is_torch_tensor(x):
+    return type(x).__module__.startswith("torch") and hasattr(x, "data_ptr")
+
+
+class Ratings:
+    """Rating triples in HBM.  Accepts numpy arrays (copied over PCIe) or torch tensors already on the context's GPU."""
+
+    def __init__(self, ctx, user, item, score):
+        self._lib = _native.load()
+        self.ctx = ctx
+        if _is_torch_tensor(user):
+            import torch
+            assert user.is_cuda and item.is_cuda and score.is_cuda, "device tensors expected"
+            assert user.dtype == torch.int32 and item.dtype == torch.int32 and score.dtype == torch.float32
+            user, item, score = user.contiguous(), item.contiguous(), score.contiguous()
+            torch.cuda.current_stream(user.device).synchronize()   # producer stream != the context's stream
+            n, ptrs, loc = user.numel(), (user.data_ptr(), item.data_ptr(), score.data_ptr()), 1
+        else:
+            user = np.ascontiguousarray(user, dtype=np.int32)
+            item = np.ascontiguousarray(item, dtype=np.int32)
+            score = np.ascontiguousarray(score, dtype=np.float32)
+            n, ptrs, loc = len(user), (user.ctypes.data, item.ctypes.data, score.ctypes.data), 0
+        assert n == len(item) == len(score)
+        self._keep = (user, item, score)
+        h = C.c_void_p()
+        _check(self._lib.fy_ratings_create(ctx._h, n, ptrs[0], ptrs[1], ptrs[2], loc, C.byref(h)))
+        self._h = h
+        self._keep = None
+        self.nnz = n
+
+    def close(self):
+        if getattr(self, "_h", None):
+            if self.ctx._h:
+                self._lib.fy_ratings_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _np(ptr, n, dtype):
+    if not ptr or n == 0:
+        return np.zeros(0, dtype=dtype)
+    buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype).copy()
+
+
+class _Result:
+    def __init__(self, handle, ctx=None):
+        self._lib = _native.load()
+        self._h = handle
+        self._ctx = ctx   # rows are downloaded through the context's stream: keep it alive
+
+    def _stats(self):
+        st = _native.Stats()
+        _check(self._lib.fy_result_stats(self._h, C.byref(st)))
+        return st.as_dict()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            if self._ctx is None or self._ctx._h:   # a result must not outlive its context's stream
+                self._lib.fy_result_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Recommendations(_Result):
+    """Rows of the `recommendations` table / output SequenceFile: (user, item, relevance float32, cluster),
+    grouped by user, best first -- plus the job's side outputs rm2/userSum and rm2/itemColl."""
+
+    def __init__(self, handle, ctx=None):
+        super().__init__(handle, ctx)
+        L = self._lib
+        self.stats = self._stats()
+        self.size = L.fy_result_size(handle)
+        self._rows = None
+        self._sums = None
+
+    def rows(self):
+        if self._rows is None:
+            L, h, n = self._lib, self._h, self.size
+            self._rows = {"user": _np(L.fy_result_key0(h), n, np.int32), "item": _np(L.fy_result_key1(h), n, np.int32),
+                          "score": _np(L.fy_result_value(h), n, np.float32),
+                          "cluster": _np(L.fy_result_aux(h), n, np.int32)}
+        return self._rows
+
+    def sums(self):
+        if self._sums is None:
+            L, h = self._lib, self._h
+            nu, ni = L.fy_result_n_users(h), L.fy_result_n_items(h)
+            self._sums = {"user_id": _np(L.fy_result_user_id(h), nu, np.int32),
+                          "user_sum": _np(L.fy_result_user_sum(h), nu, np.float64),
+                          "item_id": _np(L.fy_result_item_id(h), ni, np.int32),
+                          "item_coll": _np(L.fy_result_item_coll(h), ni, np.float64),
+                          "total_sum": L.fy_result_total_sum(h)}
+        return self._sums
+
+
+class ItemSimilarities(_Result):
+    """Rows of the similarity matrix: (item, other item, similarity), grouped by item, best first."""
+
+    def __init__(self, handle, ctx=None):
+        super().__init__(handle, ctx)
+        self.stats = self._stats()
+        self.size = self._lib.fy_result_size(handle)
+        self._rows = None
+
+    def rows(self):
+        if self._rows is None:
+            L, h, n = self._lib, self._h, self.size
+            self._rows = {"item": _np(L.fy_result_key0(h), n, np.int32), "other": _np(L.fy_result_key1(h), n, np.int32),
+                          "sim": _np(L.fy_result_value(h), n, np.float32)}
+        return self._rows
+
+
+def _i32(a):
+    return np.ascontiguousarray(a if a is not None else [], dtype=np.int32)
+
+
+class RM2Job:
+    """Relevance Model 2 job (M/rm/RM2Job.java:54-272) on one MI355X (or one rank of several).
+
+    ``conf`` carries the reference's keys: lambda, numberOfItems, numberOfClusters, numberOfRecommendations,
+    filterUsers (clusterSplit / splitSize are accepted and ignored: they only partition the reference's reduce groups
+    and never change a score -- M/common/AbstractByClusterAndCountMapper.java:86-102)."""
+
+    JOB_NAME = "RM2"
+
+    def __init__(self, conf, ctx=None):
+        self.conf = conf
+        self.ctx = ctx
+
+    def _params(self, rank, world, workspace_bytes):
+        conf = self.conf
+        n_clusters = conf.getInt("numberOfClusters", -1)
+        n_items = conf.getInt("numberOfItems", -1)
+        if n_clusters is None or n_clusters <= 0 or n_items is None or n_items <= 0:
+            # AbstractJob.parseArguments rejects a missing required option (TestRMRecommenderJob.java:39-74)
+            raise ValueError("numberOfClusters and numberOfItems are required")
+        lam = float(conf.get("lambda"))    # Double.valueOf(conf.get("lambda")), AbstractRM2Reducer.java:108
+        return _native.RM2Params(lam, n_items, conf.getInt("numberOfRecommendations", 1000),
+                                 conf.getInt("filterUsers", 0), n_clusters, int(rank), int(world), 0,
+                                 int(workspace_bytes))
+
+    def run(self, ratings, clustering=None, clustering_count=None, rank=0, world=1, exchange=None,
+            workspace_bytes=0):
+        """ratings: a ``Ratings`` or a (user, item, score) triple of arrays.
+        clustering: (users, clusters) arrays = the reference's `clustering` file; None routes everyone to cluster 0.
+        clustering_count: array of numberOfClusters sizes = the `clusteringCount` file (validated when given).
+        exchange(device_ptr, length) -> device_ptr of world*length doubles: the all-gather of the per-item statistics
+        (see parallel.StatsExchange); required when world > 1.
+        Raises RuntimeError("RM2 failed!: ...") on any failure, like RM2Job.java:144-147."""
+        lib = _native.load()
+        p = self._params(rank, world, workspace_bytes)
+        ctx = self.ctx or Context(0)
+        self.ctx = ctx
+        own_ratings = not isinstance(ratings, Ratings)
+        job = C.c_void_p()
+        res = C.c_void_p()
+        try:
+            r = Ratings(ctx, *ratings) if own_ratings else ratings
+            mu, mc = (_i32(clustering[0]), _i32(clustering[1])) if clustering is not None else (_i32(None), _i32(None))
+            if len(mu) != len(mc):
+                raise ValueError("clustering users / clusters differ in length")
+            cc = None
+            if clustering_count is not None:
+                cc = np.zeros(p.number_of_clusters, dtype=np.int32)
+                k = min(len(clustering_count), p.number_of_clusters)
+                cc[:k] = np.asarray(clustering_count, dtype=np.int32)[:k]
+            try:
+                _check(lib.fy_rm2_prepare(ctx._h, C.byref(p), r._h, len(mu), mu.ctypes.data, mc.ctypes.data,
+                                          cc.ctypes.data if cc is not None else None, C.byref(job)))
+                if world > 1:
+                    if exchange is None:
+                        raise ValueError("world > 1 needs an exchange (all-gather of the item statistics)")
+                    buf, n = C.c_void_p(), C.c_int64()
+                    _check(lib.fy_rm2_partial_stats(job, C.byref(buf), C.byref(n)))
+                    gathered = exchange(buf.value, n.value)
+                    _check(lib.fy_rm2_set_global_stats(job, gathered, world))
+                _check(lib.fy_rm2_score(job, C.byref(res)))
+            except FilmYouError as e:
+                raise RuntimeError("%s failed!: %s" % (self.JOB_NAME, e.message)) from e
+            return Recommendations(res, ctx)
+        finally:
+            if job:
+                lib.fy_rm2_job_destroy(job)
+            if own_ratings and "r" in locals():
+                r.close()
+
+
+class RowSimilarityJob:
+    """Item-item similarity build with the options the reference passes to Mahout's RowSimilarityJob
+    (M/baselinerecommender/BaselineRecommenderJob.java:241-253)."""
+
+    JOB_NAME = "RowSimilarityJob"
+
+    def __init__(self, ctx=None):
+        self.ctx = ctx
+
+    def run(self, ratings, similarityClassname=SIMILARITY_COSINE, maxSimilaritiesPerRow=100,
+            excludeSelfSimilarity=True, threshold=None, rank=0, world=1):
+        lib = _native.load()
+        if similarityClassname not in _SIMILARITY:
+            raise ValueError("similarityClassname must be SIMILARITY_COSINE or SIMILARITY_COOCCURRENCE")
+        p = _native.ItemSimParams(_SIMILARITY[similarityClassname], int(maxSimilaritiesPerRow),
+                                  1 if excludeSelfSimilarity else 0, 0 if threshold is None else 1,
+                                  0.0 if threshold is None else float(threshold), int(rank), int(world), 0)
+        ctx = self.ctx or Context(0)
+        self.ctx = ctx
+        own_ratings = not isinstance(ratings, Ratings)
+        r = Ratings(ctx, *ratings) if own_ratings else ratings
+        res = C.c_void_p()
+        try:
+            try:
+                _check(lib.fy_itemsim_build(ctx._h, C.byref(p), r._h, C.byref(res)))
+            except FilmYouError as e:
+                raise RuntimeError("%s failed!: %s" % (self.JOB_NAME, e.message)) from e
+            return ItemSimilarities(res, ctx)
+        finally:
+            if own_ratings:
+                r.close()

@@ -1,0 +1,166 @@
+/*
+ * filmyou.h -- C ABI of the MI355X-native replacement for filmyou-core's two recommendation jobs.
+ *
+ * This is the drop-in boundary: the entry points below are what a JNI shim binds in place of the reference's
+ * MapReduce Driver/Mapper/Reducer classes (binding shown in INTEGRATION.md).  Plain pointers and sizes only.
+ * M/ = src/main/java/es/udc/fi/dc/irlab/ in dvalcarce/filmyou-core.
+ *
+ *   fy_rm2_*      replaces  ToolRunner.run(conf, new RM2Job(), args)   M/rmrecommender/RMRecommenderDriver.java:200-201
+ *                 i.e. M/rm/RM2Job.java:76-100 (jobs RM2-1, RM2-2, RM2-3) and everything they run:
+ *                 the M/rm mappers, the M/rm DoubleSum reducers, M/rm/AbstractRM2Reducer.java:129-389,
+ *                 M/common/AbstractByCluster*Mapper.java (routing), M/util/IntDouble.java (ordering).
+ *   fy_itemsim_*  replaces  ToolRunner.run(getConf(), new RowSimilarityJob(), {...})
+ *                 M/baselinerecommender/BaselineRecommenderJob.java:241-253 (Mahout 0.8 RowSimilarityJob).
+ *
+ * Conventions: no exceptions cross the ABI; every function returns FY_OK (0) or a negative fy_status and leaves a
+ * message for fy_last_error() (thread-local).  Input arrays are caller-owned and may be freed as soon as the call
+ * returns.  Results are library-owned until fy_result_free.  One fy_context drives one GPU; a process uses one
+ * context per device (one process per GPU under torch.distributed / a Hadoop task per GPU).  A context is not
+ * re-entrant: calls on one context must not overlap; distinct contexts may be used from distinct threads.
+ * There is NO CPU fallback: without a gfx950 device every compute entry point fails with FY_ERR_NO_DEVICE.
+ */
+#ifndef FILMYOU_H
+#define FILMYOU_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FY_ABI_VERSION 1
+
+typedef enum {
+    FY_OK = 0,
+    FY_ERR_INVALID_ARGUMENT = -1,
+    FY_ERR_NO_DEVICE = -2,       /* no HIP device / not gfx950 */
+    FY_ERR_HIP = -3,             /* a HIP runtime call failed */
+    FY_ERR_OUT_OF_MEMORY = -4,
+    FY_ERR_CLUSTER_RANGE = -5,   /* a user is routed to a cluster outside [0, numberOfClusters): the reference would
+                                    throw ArrayIndexOutOfBounds at M/common/AbstractByClusterAndCountMapper.java:88 */
+    FY_ERR_CLUSTER_COUNT = -6,   /* clusteringCount disagrees with the rated users routed to a cluster: the reference
+                                    reducer reads exactly clusterSizes[c] user-sum records first (AbstractRM2Reducer.java:153-160) */
+    FY_ERR_DUPLICATE_RATING = -7,/* two ratings for one (user, item): Cassandra's PRIMARY KEY (user, item) forbids it */
+    FY_ERR_NEGATIVE_ID = -8,     /* user / item ids must be >= 0 */
+    FY_ERR_STATE = -9,           /* calls made out of order */
+    FY_ERR_UNSUPPORTED = -10
+} fy_status;
+
+typedef struct fy_context fy_context;
+typedef struct fy_ratings fy_ratings;
+typedef struct fy_rm2_job fy_rm2_job;
+typedef struct fy_result fy_result;
+
+/* ------------------------------------------------------------------ context */
+int fy_abi_version(void);
+const char* fy_last_error(void);
+/* Binds the calling process to GPU `device_ordinal`, creates the HIP stream every kernel of this context runs on. */
+int fy_context_create(int device_ordinal, fy_context** out);
+void fy_context_destroy(fy_context*);
+int fy_context_synchronize(fy_context*);
+/* The hipStream_t of the context (as void*), e.g. to order caller-side copies against the job. */
+void* fy_context_stream(fy_context*);
+
+/* ------------------------------------------------------------------ ratings
+ * COO triples with the caller's raw int32 ids (1-based in the reference's data) exactly as the reference's
+ * mappers receive them: table ratings(user int, item int, score float) (test/.../util/CassandraUtils.java:93-94) or
+ * SequenceFile<IntPairWritable(user,item), FloatWritable> (M/util/DataInitialization.java:164-172).
+ * `location`: FY_HOST pointers are copied over PCIe; FY_DEVICE pointers (HBM of the context's GPU) are copied
+ * device-to-device, so the caller keeps ownership either way. */
+enum { FY_HOST = 0, FY_DEVICE = 1 };
+int fy_ratings_create(fy_context*, int64_t nnz, const int32_t* user, const int32_t* item, const float* score,
+                      int location, fy_ratings** out);
+void fy_ratings_destroy(fy_ratings*);
+int64_t fy_ratings_nnz(const fy_ratings*);
+
+/* ------------------------------------------------------------------ RM2 job
+ * Field names follow the Hadoop Configuration keys of M/rmrecommender/RMRecommenderDriver.java:49-120. */
+typedef struct {
+    double lambda;                      /* "lambda" (default 0.1), Jelinek-Mercer smoothing */
+    int32_t number_of_items;            /* "numberOfItems": global item count, used only in pvpi (AbstractRM2Reducer.java:327-329) */
+    int32_t number_of_recommendations;  /* "numberOfRecommendations" (default 1000) */
+    int32_t filter_users;               /* "filterUsers": users with id < this get no list (AbstractRM2Reducer.java:221-223) */
+    int32_t number_of_clusters;         /* "numberOfClusters" */
+    int32_t rank;                       /* this process scores user shard `rank` of `world` (1 GPU: 0 of 1) */
+    int32_t world;
+    uint32_t flags;                     /* reserved, 0 */
+    int64_t workspace_bytes;            /* cap for the per-batch score scratch in HBM; 0 = default (16 GiB) */
+} fy_rm2_params;
+
+/* Stage 1 (jobs RM2-1/RM2-2 up to the exchange): score > 0 filter, CSR/CSC in HBM, cluster routing, user sums,
+ * and this rank's PARTIAL per-item rating sums + partial floor-sum total.
+ * Clustering = the reference's `clustering` file as (user, cluster) pairs; n_map = 0 routes every user to
+ * cluster 0 (Trove default, quirk Q2).  cluster_count (numberOfClusters ints, the `clusteringCount` file) may be
+ * NULL; when given it is validated.  map_* / cluster_count are HOST pointers. */
+int fy_rm2_prepare(fy_context*, const fy_rm2_params*, const fy_ratings*, int64_t n_map, const int32_t* map_user,
+                   const int32_t* map_cluster, const int32_t* cluster_count, fy_rm2_job** out);
+/* The exchange buffer of this rank, in HBM: `*len` doubles = per-item partial sums in ascending raw item id order
+ * followed by one double holding this rank's partial sum of floor(s_u) (quirk Q1).  All ranks hold the same item set
+ * (the ratings are replicated), so `*len` agrees across ranks: all-gather it (RCCL) into world * len doubles. */
+int fy_rm2_partial_stats(fy_rm2_job*, double** device_buf, int64_t* len);
+/* `gathered` = world * len doubles in HBM, rank-major.  Summed in rank order (bit-reproducible).  Optional when world == 1. */
+int fy_rm2_set_global_stats(fy_rm2_job*, const double* gathered_device, int32_t world);
+/* Stage 2 (job RM2-3): per-cluster co-rating matrix, p(i|u) scoring of this rank's users, top-N. */
+int fy_rm2_score(fy_rm2_job*, fy_result** out);
+void fy_rm2_job_destroy(fy_rm2_job*);
+
+/* One call = one complete single-GPU job on host buffers (what the JNI shim calls): context on device 0. */
+int fy_rm2_run(const fy_rm2_params*, int64_t nnz, const int32_t* user, const int32_t* item, const float* score,
+               int64_t n_map, const int32_t* map_user, const int32_t* map_cluster, const int32_t* cluster_count,
+               fy_result** out);
+
+/* ------------------------------------------------------------------ item-item similarity build */
+enum { FY_SIMILARITY_COSINE = 0, FY_SIMILARITY_COOCCURRENCE = 1 };
+typedef struct {
+    int32_t similarity;                 /* --similarityClassname SIMILARITY_COSINE | SIMILARITY_COOCCURRENCE */
+    int32_t max_similarities_per_item;  /* --maxSimilaritiesPerRow (default 100, BaselineRecommenderJob.java:67) */
+    int32_t exclude_self;               /* --excludeSelfSimilarity (call site passes true) */
+    int32_t has_threshold;              /* 0 = RowSimilarityJob.NO_THRESHOLD */
+    double threshold;                   /* --threshold */
+    int32_t rank;                       /* this process builds item-row shard `rank` of `world` */
+    int32_t world;
+    uint32_t flags;
+} fy_itemsim_params;
+int fy_itemsim_build(fy_context*, const fy_itemsim_params*, const fy_ratings*, fy_result** out);
+int fy_itemsim_run(const fy_itemsim_params*, int64_t nnz, const int32_t* user, const int32_t* item,
+                   const float* score, fy_result** out);
+
+/* ------------------------------------------------------------------ results
+ * Rows as the reference writes them: RM2 (user, item, (float) relevance, cluster) -- RM2HDFSReducer.java:48 /
+ * RM2CassandraReducer.java:49-63 -- grouped by user, best first; item-sim (item, other item, similarity) grouped by
+ * item, best first.  Accessors return HOST pointers (the first accessor call downloads from HBM and synchronises). */
+int64_t fy_result_size(fy_result*);
+const int32_t* fy_result_key0(fy_result*);      /* user (RM2) | item (item-sim) */
+const int32_t* fy_result_key1(fy_result*);      /* item (RM2) | other item (item-sim) */
+const float* fy_result_value(fy_result*);       /* relevance | similarity */
+const int32_t* fy_result_aux(fy_result*);       /* cluster (RM2) | 0 */
+/* rm2/userSum and rm2/itemColl (what TestHDFSRM2.java:70-71 asserts), ascending raw id; RM2 only */
+int64_t fy_result_n_users(fy_result*);
+const int32_t* fy_result_user_id(fy_result*);
+const double* fy_result_user_sum(fy_result*);
+int64_t fy_result_n_items(fy_result*);
+const int32_t* fy_result_item_id(fy_result*);
+const double* fy_result_item_coll(fy_result*);
+double fy_result_total_sum(fy_result*);
+void fy_result_free(fy_result*);
+
+typedef struct {
+    int64_t nnz;               /* ratings kept (score > 0) */
+    int64_t n_users, n_items, n_clusters_nonempty;
+    int64_t users_scored;      /* users that received a list (this rank) */
+    int64_t recs;              /* rows in the result (this rank) */
+    int64_t log_terms;         /* RM2: (u, i unrated, j rated) terms evaluated by the scoring kernel (this rank) */
+    int64_t pair_contribs;     /* ordered co-rating pair contributions accumulated by the row kernel (= sum n_u^2 walked) */
+    int64_t unordered_pairs;   /* item-sim unit: sum_u n_u (n_u - 1) / 2 over the rows this rank builds */
+    double ms_prepare;         /* HIP-event milliseconds on the context's stream, per phase */
+    double ms_cooc;            /* co-rating row kernel (RM2: dense M build; item-sim: whole build) */
+    double ms_score;           /* RM2 scoring kernel, summed over launches */
+    double ms_topn;
+    double ms_total;
+    int64_t score_launches;    /* launches of the dominant kernel and bytes of its algorithmic traffic model */
+    int64_t cooc_launches;
+} fy_stats;
+int fy_result_stats(fy_result*, fy_stats* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FILMYOU_H */

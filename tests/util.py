@@ -1,0 +1,69 @@
+"""Shared checks for the parity tests."""
+import importlib
+
+import numpy as np
+
+RTOL = 1e-5   # north_star: top-N lists match the reference within 1e-5 relative
+
+
+def pkg():
+    return importlib.import_module("filmyou-core_amd")
+
+
+def synth():
+    return importlib.import_module("filmyou-core_amd.synth")
+
+
+def full_ranking(ref):
+    """oracle output (run with an unbounded numberOfRecommendations) -> {user: (items, scores float64 as float32)}"""
+    out = {}
+    order = np.argsort(ref["rec_user"], kind="stable")
+    users = ref["rec_user"][order]
+    bounds = np.flatnonzero(np.diff(users)) + 1
+    for idx in np.split(order, bounds):
+        out[int(ref["rec_user"][idx[0]])] = (ref["rec_item"][idx], ref["rec_score"][idx].astype(np.float64),
+                                             int(ref["rec_cluster"][idx[0]]))
+    return out
+
+
+def assert_topn_matches(rows, ref_full, top_n, rtol=RTOL):
+    """Tie-tolerant comparison of GPU top-N rows with the oracle's full ranking.
+
+    The reference's PriorityQueue leaves the order of equal scores unspecified, and two scores closer
+    than the tolerance may legitimately swap.  So: (1) same users, same row counts; (2) every returned (user, item)
+    carries the oracle's score for that pair within rtol; (3) scores are non-increasing; (4) the k-th returned score
+    equals the oracle's k-th best within rtol (so nothing better was left out); (5) cluster column matches."""
+    ranking = full_ranking(ref_full)
+    gu = rows["user"]
+    assert len(gu) == sum(min(top_n, len(v[0])) for v in ranking.values()), "row count"
+    order = np.argsort(gu, kind="stable")
+    bounds = np.flatnonzero(np.diff(gu[order])) + 1
+    seen = set()
+    worst = 0.0
+    for idx in np.split(order, bounds):
+        u = int(gu[idx[0]])
+        seen.add(u)
+        items, scores, cluster = ranking[u]
+        k = min(top_n, len(items))
+        assert len(idx) == k, (u, len(idx), k)
+        assert np.all(np.diff(idx) == 1), "rows of a user must be contiguous"
+        gi, gs = rows["item"][idx], rows["score"][idx].astype(np.float64)
+        assert len(set(gi.tolist())) == k, "duplicate item in a list"
+        assert np.all(rows["cluster"][idx] == cluster)
+        lookup = dict(zip(items.tolist(), scores.tolist()))
+        want = np.array([lookup[int(i)] for i in gi])          # KeyError = an item the oracle never scored
+        fin = np.isfinite(want)
+        assert np.array_equal(np.isfinite(gs), fin)
+        assert np.array_equal(gs[~fin], want[~fin])            # -inf stays -inf
+        if fin.any():
+            err = np.abs(gs[fin] - want[fin]) / np.abs(want[fin])
+            worst = max(worst, float(err.max()))
+            assert err.max() <= rtol, (u, err.max())
+        assert np.all(gs[:-1] >= gs[1:]), "scores must be non-increasing"
+        best = scores[:k]
+        fb = np.isfinite(best)
+        assert np.array_equal(np.isfinite(gs), fb)
+        if fb.any():
+            assert np.all(np.abs(gs[fb] - best[fb]) <= rtol * np.abs(best[fb])), (u, "k-th best mismatch")
+    assert seen == set(ranking.keys())
+    return worst
