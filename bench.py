@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py -- whole-job throughput of the RM2 top-N scorer (and the item-item similarity build) on MI355X.
+
+Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`, one rank per GPU over RCCL.
+One "step" = one complete RM2 job over the ML-25M-shaped synthetic ratings, which are resident in HBM when the timed
+region starts: COO -> CSR/CSC, statistics, (all-gather), per-cluster co-rating matrix, scoring, top-N.
+Rank 0 prints ONE JSON line.  `value` = top-N recommendation rows produced by all ranks per second.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--shape", default="ml25m", help="ml100k | ml1m | ml25m | netflix")
+    ap.add_argument("--clusters", type=int, default=1, help="numberOfClusters (users hashed to clusters); 1 = one neighbourhood")
+    ap.add_argument("--top-n", type=int, default=None)
+    ap.add_argument("--lam", type=float, default=0.1)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-itemsim", action="store_true", help="skip the item-item similarity leg")
+    ap.add_argument("--cpu-users", type=int, default=0, help="users in the CPU sample cluster (0 = auto)")
+    return ap.parse_args()
+
+
+def cpu_baseline(S, shape, facts, lam, top_n, n_users_sample):
+    """The faithful CPU oracle (kind "port": this image has no JVM for the reference itself) timed on a bounded
+    sample: one cluster of `n_users_sample` users drawn from the same synthetic data set, scored with the reference's
+    brute-force loop nest on the host cores."""
+    import oracle
+    cores = max(1, min(16, os.cpu_count() or 1))
+    rng = np.random.Generator(np.random.PCG64(7))
+    users = np.sort(rng.choice(facts["n_users"], size=min(n_users_sample, facts["n_users"]), replace=False)) + 1
+    u, i, s, _ = S.generate(shape, users=users, device="cpu")
+    u, i, s = u.numpy(), i.numpy(), s.numpy()
+    t0 = time.time()
+    ref = oracle.rm2(u, i, s, lam=lam, number_of_items=facts["n_items"], number_of_recommendations=top_n,
+                     number_of_clusters=1, n_threads=cores)
+    dt = time.time() - t0
+    recs = len(ref["rec_user"])
+    return {"value": recs / dt, "unit": "recs/s", "cores": cores, "kind": "port",
+            "sample": "one %d-user cluster sampled from the same %s-shaped data (%d ratings, %d candidate items, "
+                      "%.3g log-terms x %d neighbours), oracle/rm2_oracle.c with %d OpenMP threads, %.1f s; the "
+                      "reference's cost per term grows with the cluster size, the GPU path's does not"
+                      % (len(users), shape, len(u), len(ref["item_id"]), ref["log_terms"], len(users) - 1, cores, dt),
+            "seconds": dt, "log_terms_per_s": ref["log_terms"] / dt}
+
+
+def main():
+    a = parse()
+    P = importlib.import_module("filmyou-core_amd")
+    S = importlib.import_module("filmyou-core_amd.synth")
+    par = importlib.import_module("filmyou-core_amd.parallel")
+    rank, local_rank, world = par.init_distributed()
+    if world != a.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    top_n = a.top_n if a.top_n is not None else (100 if a.shape == "netflix" else 50)
+
+    # ---- synthetic ratings, generated on the GPU with the device-independent hash (identical on every rank)
+    t0 = time.time()
+    user, item, score, facts = S.generate(a.shape, device=dev)
+    torch.cuda.synchronize()
+    gen_s = time.time() - t0
+    K = a.clusters
+    clustering = None
+    if K > 1:
+        uu = np.arange(1, facts["n_users"] + 1, dtype=np.int32)
+        clustering = (uu, S.hash_clustering(uu, K))
+
+    conf = P.Configuration()
+    conf.set("lambda", repr(a.lam))
+    conf.setInt("numberOfItems", facts["n_items"])
+    conf.setInt("numberOfClusters", K)
+    conf.setInt("numberOfRecommendations", top_n)
+    ctx = P.Context(local_rank)
+    ratings = P.Ratings(ctx, user, item, score)       # resident in HBM before the timed region
+    exchange = par.StatsExchange(local_rank) if world > 1 else None
+    job = P.RM2Job(conf, ctx)
+
+    def step():
+        rec = job.run(ratings, clustering=clustering, rank=rank, world=world, exchange=exchange)
+        st = rec.stats
+        rec.close()
+        return st
+
+    def fence():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    stats = [step() for _ in range(a.steps)]
+    fence()
+    elapsed = time.perf_counter() - t0
+    tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    recs = torch.tensor([float(stats[-1]["recs"]), float(stats[-1]["log_terms"]), float(stats[-1]["users_scored"])],
+                        dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(recs, op=dist.ReduceOp.SUM)
+    elapsed = float(tt.item())
+    total_recs, total_terms, total_users = (float(x) for x in recs.tolist())
+    ms_per_step = 1e3 * elapsed / a.steps
+
+    # ---- roofline of the dominant kernel (k_score), from HIP events the library records on ITS stream
+    st = stats[-1]
+    ms_score = float(np.mean([s["ms_score"] for s in stats]))
+    launches = st["score_launches"]
+    alg_bytes = 4.0 * st["log_terms"]                  # 4 B (one fp32 matrix element) per log-term
+    achieved = alg_bytes / (ms_score * 1e-3) / 1e9 if ms_score > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": "k_score", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "launches_per_step": launches, "avg_launch_ms": ms_score / max(1, launches),
+                "algorithmic_bytes_per_launch": alg_bytes / max(1, launches),
+                "log_terms_per_s": st["log_terms"] / (ms_score * 1e-3) if ms_score > 0 else 0.0,
+                "note": "frac > 1 means the column panels of M are served from L2 / Infinity Cache, not HBM"}
+
+    out = {
+        "metric": "top-N recs/sec (RM2), %s shape" % a.shape, "value": total_recs / (elapsed / a.steps), "unit": "recs/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s-shaped synthetic ratings (%d users x %d items, %d nnz), RM2 top-%d, lambda %g, "
+                               "numberOfClusters %d, users range-sharded over %d GPU(s)"
+                               % (a.shape, facts["n_users"], facts["n_items"], facts["nnz"], top_n, a.lam, K, world),
+                   "shape": a.shape, "top_n": top_n, "clusters": K, "lambda": a.lam, "nnz": facts["nnz"]},
+        "lists_per_s": total_users / (elapsed / a.steps), "log_terms_per_step": total_terms,
+        "phase_ms_rank0": {k: float(np.mean([s[k] for s in stats])) for k in ("ms_prepare", "ms_cooc", "ms_score", "ms_topn", "ms_total")},
+        "datagen_s": gen_s, "roofline": roofline,
+    }
+
+    # ---- item-item similarity build on the same ratings (second headline unit: pairs/s)
+    if not a.no_itemsim:
+        try:
+            sim_job = P.RowSimilarityJob(ctx)
+            sim_job.run(ratings, maxSimilaritiesPerRow=100, rank=rank, world=world).close()
+            fence()
+            t0 = time.perf_counter()
+            res = sim_job.run(ratings, maxSimilaritiesPerRow=100, rank=rank, world=world)
+            fence()
+            dt = time.perf_counter() - t0
+            sst = res.stats
+            res.close()
+            pp = torch.tensor([float(sst["unordered_pairs"]), dt], dtype=torch.float64, device=dev)
+            if world > 1:
+                tmax = pp[1:2].clone()
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                dist.all_reduce(pp[0:1], op=dist.ReduceOp.SUM)
+                dt = float(tmax.item())
+            out["itemsim"] = {"metric": "item-sim pairs/sec (cosine, top-100)", "value": float(pp[0].item()) / dt,
+                              "unit": "pairs/s", "seconds": dt, "ms_kernel_rank0": sst["ms_cooc"],
+                              "roofline": {"bound": "hbm", "kernel": "k_cooc_itemsim",
+                                           "achieved": 8.0 * sst["unordered_pairs"] / (sst["ms_cooc"] * 1e-3) / 1e9 if sst["ms_cooc"] > 0 else 0.0,
+                                           "peak": HBM_PEAK_GBS, "unit": "GB/s"}}
+            out["itemsim"]["roofline"]["frac"] = out["itemsim"]["roofline"]["achieved"] / HBM_PEAK_GBS
+        except RuntimeError as e:
+            out["itemsim"] = {"error": str(e)}
+
+    if rank == 0 and world == 1 and not a.no_cpu:
+        n_cpu = a.cpu_users or {"ml25m": 120, "netflix": 100, "ml1m": 250, "ml100k": 300}.get(a.shape, 200)
+        out["cpu_baseline"] = cpu_baseline(S, a.shape, facts, a.lam, top_n, n_cpu)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out))
+    ratings.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

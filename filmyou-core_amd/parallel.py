@@ -1,0 +1,74 @@
+"""Multi-GPU plumbing: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on ROCm).
+
+The RM2 job shards its TARGET USERS across ranks (a work-balanced range of the cluster-major user order, cut inside
+the native library identically on every rank).  Scores of different users are independent given the global item
+statistics, so the only exchange step is the all-gather of every rank's partial per-item rating sums plus its partial
+floor-sum total (jobs RM2-1 / RM2-2 and the Hadoop counter of the reference, M/rm/RM2Job.java:130-149, 184-198):
+(n_items + 1) doubles per rank, summed in rank order inside the library so the result is bit-reproducible.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def init_distributed(backend=None):
+    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment (torch.distributed.run sets them)."""
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {}
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            kw["device_id"] = torch.device("cuda", local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+    return rank, local_rank, world
+
+
+def all_gather_stats(local):
+    """local: 1-D float64 tensor (CPU with gloo, GPU with nccl/RCCL) -> (world * n) tensor, rank-major."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if world == 1:
+        return local.clone()
+    out = torch.empty(world * local.numel(), dtype=local.dtype, device=local.device)
+    if local.is_cuda:
+        dist.all_gather_into_tensor(out, local.contiguous())
+    else:
+        dist.all_gather(list(out.view(world, -1).unbind(0)), local.contiguous())
+    return out
+
+
+def combine_in_rank_order(gathered, world):
+    """What fy_rm2_set_global_stats does on the GPU, restated for host-side tests: a fixed-order sum over ranks."""
+    g = gathered.view(world, -1)
+    total = g[0].clone()
+    for r in range(1, world):
+        total += g[r]
+    return total
+
+
+class _DevicePointer:
+    """A raw HBM pointer dressed as a CUDA-array-interface object so torch can view it without a copy."""
+
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+class StatsExchange:
+    """Callable handed to RM2Job.run(exchange=...): all-gathers the library's HBM buffer over RCCL."""
+
+    def __init__(self, device_index):
+        self.device = torch.device("cuda", device_index)
+        self._keep = None
+
+    def __call__(self, ptr, n):
+        local = torch.as_tensor(_DevicePointer(ptr, n, "<f8"), device=self.device)
+        gathered = all_gather_stats(local)
+        torch.cuda.current_stream(self.device).synchronize()   # the library continues on its own stream
+        self._keep = gathered
+        return gathered.data_ptr()
