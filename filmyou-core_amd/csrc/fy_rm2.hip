@@ -14,6 +14,7 @@
 // 10^4-term score near 1e-7 (tolerance of north_star: 1e-5).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "fy_cooc.hpp"
 #include "fy_prep.hpp"
@@ -190,12 +191,12 @@ struct MEpilogue {
 };
 
 __global__ void k_cooc_rm2(CoocArgs A, MEpilogue E) {
-    extern __shared__ double acc[];
+    double* acc = fy_cooc_acc;
     const int row = A.row0 + blockIdx.x / A.nch;
     const int ch = blockIdx.x % A.nch;
     for (int t = threadIdx.x; t < A.CH; t += blockDim.x) acc[t] = 0.0;
     __syncthreads();
-    cooc_accumulate_row(A, row, ch, acc);
+    cooc_accumulate_row(A, row, ch);
     __syncthreads();
     const int c0 = ch * A.CH;
     // the last chunk also writes the padding columns [Ic, ldm) so the scoring kernel may load whole 256-wide chunks
@@ -210,86 +211,125 @@ __global__ void k_cooc_rm2(CoocArgs A, MEpilogue E) {
 }
 
 // ================================================================ scoring kernel (the dominant kernel)
-// Work item = (user, 256-column chunk): the wave walks the user's CSR row (wave-uniform scalar loads of idx and e) and
-// for every rated item j streams the 1 KiB segment M[j][chunk] (16 B per lane, coalesced), adding
-// log2(M[j][i] + a_i * e_uj) to the lane's four candidate items.  No cross-lane traffic at all.
-// Grid order is chunk-major, so at any time the resident workgroups read the same column panel of M: the panel
-// (I_c KiB) lives in the Infinity Cache and its popular low rows in the XCD L2s.
+// Work item = (user, column chunk of 64*VEC items, row block): the wave walks the slice of the user's CSR row that falls
+// into the row block (wave-uniform scalar loads of idx and e) and for every rated item j streams the segment
+// M[j][chunk] (4*VEC bytes per lane, coalesced), adding log2(M[j][i] + a_i * e_uj) to the lane's VEC candidates.
+// No cross-lane traffic at all.
+//
+// Cache blocking (rocprof, round 1: one launch over all rows ran at 41 % L2 hit rate and 7.1 TB/s of fabric traffic,
+// i.e. it was bound by the L2-miss path): the rows are cut into blocks of `rb_rows`, one launch per block, and the grid
+// is chunk-major, so the resident workgroups of a launch touch only the tile M[row block][chunk] (rb_rows * 256 * VEC
+// bytes <= half an XCD L2).  Every tile is fetched from HBM once per XCD and all re-reads are L2 hits; the price is a
+// read-modify-write of the score row per non-empty (user, row block), a few percent of the row traffic.
 struct ScoreArgs {
     const float* __restrict__ M;
     int64_t ldm;
     int32_t Ic;
     const float* __restrict__ a_rank;      // l * p_i in rank order, offset by pbase
-    const int32_t* __restrict__ rowptr;
+    const int32_t* __restrict__ rb_off;    // [(slot - slot_base) * (nrb + 1) + rb] first CSR entry with idx >= rb * rb_rows
     const int32_t* __restrict__ csr_idx;
     const float* __restrict__ csr_e;
     const double* __restrict__ pvpi;       // indexed by slot - slot_lo
     const int32_t* __restrict__ n_out;     // indexed by slot - slot_lo; 0 = user gets no list
     int32_t slot_lo;                       // first slot of this rank
+    int32_t slot_base;                     // first slot of the cluster (rb_off origin)
     int32_t slot0;                         // first slot of this batch
     int32_t n_users;                       // users in the batch
     float* __restrict__ S;                 // [n_users][ldS]
     int64_t ldS;
     int32_t n_slices;
+    int32_t rb;                            // row block of this launch
+    int32_t nrb;                           // row blocks per row
 };
 
 __device__ __forceinline__ float fy_log2(float x) { return __builtin_amdgcn_logf(x); }   // v_log_f32
 
-#define FY_SCORE_STEP(J, E)                                                              \
-    {                                                                                    \
-        const float4 g = *reinterpret_cast<const float4*>(Mcol + (int64_t)(J) * A.ldm);  \
-        p0 += fy_log2(fmaf(a.x, (E), g.x));                                              \
-        p1 += fy_log2(fmaf(a.y, (E), g.y));                                              \
-        p2 += fy_log2(fmaf(a.z, (E), g.z));                                              \
-        p3 += fy_log2(fmaf(a.w, (E), g.w));                                              \
-        const unsigned d = (unsigned)((J) - col0);                                       \
-        if (d < 256u && (int)(d >> 2) == lane) mask |= 1u << (d & 3u);                   \
-    }
+template <int VEC> struct VecT;
+template <> struct VecT<1> { using type = float; };
+template <> struct VecT<2> { using type = float2; };
+template <> struct VecT<4> { using type = float4; };
 
-__global__ __launch_bounds__(256) void k_score(ScoreArgs A) {
+// The read-only arrays are separate `const T* __restrict__` kernel arguments (not struct members): only then does hipcc
+// prove them invariant and fetch the wave-uniform idx / e / offsets with scalar loads (s_load) instead of a vector
+// load + v_readfirstlane in front of every row-segment load.
+template <int VEC>
+__global__ __launch_bounds__(256) void k_score(const float* __restrict__ M_, const float* __restrict__ a_rank_,
+                                               const int32_t* __restrict__ rb_off_, const int32_t* __restrict__ csr_idx_,
+                                               const float* __restrict__ csr_e_, const double* __restrict__ pvpi_,
+                                               const int32_t* __restrict__ n_out_, float* __restrict__ S_, ScoreArgs A) {
+    using V = typename VecT<VEC>::type;
+    constexpr int CW = 64 * VEC;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int chunk = blockIdx.x / A.n_slices;
     const int slice = blockIdx.x - chunk * A.n_slices;
-    const int col0 = chunk * 256;
-    const int col = col0 + lane * 4;
-    float4 a;
-    a.x = col + 0 < A.Ic ? A.a_rank[col + 0] : 0.0f;
-    a.y = col + 1 < A.Ic ? A.a_rank[col + 1] : 0.0f;
-    a.z = col + 2 < A.Ic ? A.a_rank[col + 2] : 0.0f;
-    a.w = col + 3 < A.Ic ? A.a_rank[col + 3] : 0.0f;
-    const float* __restrict__ Mcol = A.M + col;
+    const int col0 = chunk * CW;
+    const int col = col0 + lane * VEC;
+    float a[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; v++) a[v] = col + v < A.Ic ? a_rank_[col + v] : 0.0f;
+    const float* __restrict__ Mcol = M_ + col;
     const double LN2 = 0.69314718055994530942;
     const float qnan = __builtin_nanf("");
+    const bool first = A.rb == 0;
+    const int stride = A.nrb + 1;
     for (int u = slice * 4 + wave; u < A.n_users; u += A.n_slices * 4) {
         const int slot = A.slot0 + u;
-        if (A.n_out[slot - A.slot_lo] == 0) continue;
-        const int beg = A.rowptr[slot], end = A.rowptr[slot + 1];
-        double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
-        unsigned mask = 0;
-        int k = beg;
-        for (; k + 8 <= end; k += 8) {
-            float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+        if (n_out_[slot - A.slot_lo] == 0) continue;
+        const int32_t* __restrict__ ro = rb_off_ + (int64_t)(slot - A.slot_base) * stride + A.rb;
+        const int beg = ro[0], end = ro[1];
+        if (!first && beg == end) continue;
+        float* __restrict__ dst = S_ + (int64_t)u * A.ldS + col;
+        V old;
+        if (!first) old = *reinterpret_cast<const V*>(dst);      // issued early: its latency hides under the row loads
+        double t[VEC];
 #pragma unroll
-            for (int q = 0; q < 8; q++) FY_SCORE_STEP(A.csr_idx[k + q], A.csr_e[k + q]);
-            t0 += (double)p0; t1 += (double)p1; t2 += (double)p2; t3 += (double)p3;
+        for (int v = 0; v < VEC; v++) t[v] = 0.0;
+        unsigned mask = 0;
+        // batches of 8 rows: all eight segment loads are issued before the first use, also for a short tail
+        // (out-of-range slots re-load the last valid row -- an L1 hit -- and are skipped by a wave-uniform test)
+        for (int k = beg; k < end; k += 8) {
+            V g[8];
+            float e[8];
+            int jj[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int kk = min(k + q, end - 1);
+                jj[q] = csr_idx_[kk];
+                e[q] = csr_e_[kk];
+                g[q] = *reinterpret_cast<const V*>(Mcol + (int64_t)jj[q] * A.ldm);
+            }
+            float p[VEC];
+#pragma unroll
+            for (int v = 0; v < VEC; v++) p[v] = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                if (k + q < end) {
+                    const float* gv = reinterpret_cast<const float*>(&g[q]);
+#pragma unroll
+                    for (int v = 0; v < VEC; v++) p[v] += fy_log2(fmaf(a[v], e[q], gv[v]));
+                    const unsigned d = (unsigned)(jj[q] - col0);
+                    if (d < (unsigned)CW && (int)(d / VEC) == lane) mask |= 1u << (d % VEC);
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < VEC; v++) t[v] += (double)p[v];
         }
-        {
-            float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
-            for (; k < end; k++) FY_SCORE_STEP(A.csr_idx[k], A.csr_e[k]);
-            t0 += (double)p0; t1 += (double)p1; t2 += (double)p2; t3 += (double)p3;
+        V o;
+        float* ov = reinterpret_cast<float*>(&o);
+        if (first) {
+            const double base = pvpi_[slot - A.slot_lo];
+#pragma unroll
+            for (int v = 0; v < VEC; v++) ov[v] = (float)(base + LN2 * t[v]);
+        } else {
+            const float* oldv = reinterpret_cast<const float*>(&old);
+#pragma unroll
+            for (int v = 0; v < VEC; v++) ov[v] = (float)((double)oldv[v] + LN2 * t[v]);
         }
-        const double base = A.pvpi[slot - A.slot_lo];
-        float4 o;
-        o.x = (mask & 1u) ? qnan : (float)(base + LN2 * t0);
-        o.y = (mask & 2u) ? qnan : (float)(base + LN2 * t1);
-        o.z = (mask & 4u) ? qnan : (float)(base + LN2 * t2);
-        o.w = (mask & 8u) ? qnan : (float)(base + LN2 * t3);
-        if (col + 0 >= A.Ic) o.x = qnan;
-        if (col + 1 >= A.Ic) o.y = qnan;
-        if (col + 2 >= A.Ic) o.z = qnan;
-        if (col + 3 >= A.Ic) o.w = qnan;
-        *reinterpret_cast<float4*>(A.S + (int64_t)u * A.ldS + col) = o;
+#pragma unroll
+        for (int v = 0; v < VEC; v++)
+            if ((mask >> v) & 1u || col + v >= A.Ic) ov[v] = qnan;
+        *reinterpret_cast<V*>(dst) = o;
     }
 }
 
@@ -325,12 +365,118 @@ __device__ __forceinline__ float fy_order_unkey(uint32_t k) {
 
 constexpr int TOPN_MAX = 2048;
 constexpr int TOPN_BINS = 4096;
+constexpr int TOPN_SAMPLE = 1024;
 
-__global__ __launch_bounds__(256) void k_topn(TopNArgs A) {
+// descending bitonic sort of P2 (power of two) 64-bit keys in LDS; every thread of the block calls it
+__device__ __forceinline__ void fy_bitonic_desc(uint64_t* v, int P2) {
+    for (int k = 2; k <= P2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < P2; i += blockDim.x) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const uint64_t x = v[i], y = v[l];
+                    const bool desc = (i & k) == 0;
+                    if (desc ? (x < y) : (x > y)) { v[i] = y; v[l] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// Fast path, one pass over the score row.  The columns are in popularity order and RM2 scores grow with the
+// popularity of the candidate, so the K-th best of the first TOPN_SAMPLE columns is a tight LOWER bound tau of the
+// true K-th best: sort the sample in LDS, keep its top K, then stream the rest of the row (16-byte loads) and keep
+// only scores >= tau.  Every member of the true top K is among the kept ones (a member of the overall top K is in the
+// top K of any subset that contains it), so an exact sort of the kept set gives the exact list, ties broken by
+// ascending raw item id.  If more than TOPN_MAX entries survive (massive ties, e.g. a row of -inf) the user is
+// flagged and k_topn_select below redoes it with a radix select.
+__global__ __launch_bounds__(256) void k_topn_fast(TopNArgs A, int32_t* __restrict__ overflow, int32_t* __restrict__ any_overflow,
+                                                   int force_select) {
+    __shared__ uint64_t cand[TOPN_MAX];
+    __shared__ uint32_t sh_count, sh_nvalid;
+    const int u = blockIdx.x;
+    const int slot = A.slot0 + u;
+    const int K = A.n_out[slot - A.slot_lo];
+    if (threadIdx.x == 0) overflow[u] = 0;
+    if (K == 0) return;
+    if (force_select) {   // test hook (FY_TOPN_FORCE_SELECT=1): exercise the radix-select path for every user
+        if (threadIdx.x == 0) { overflow[u] = 1; atomicAdd(any_overflow, 1); }
+        return;
+    }
+    const float* __restrict__ row = A.S + (int64_t)u * A.ldS;
+    const int tid = threadIdx.x;
+    const int Ls = min(A.Ic, TOPN_SAMPLE);
+    if (tid == 0) sh_nvalid = 0;
+    __syncthreads();
+    int myvalid = 0;
+    for (int i = tid; i < TOPN_SAMPLE; i += blockDim.x) {
+        uint64_t c = 0ull;
+        if (i < Ls) {
+            const float f = row[i];
+            if (f == f) { c = ((uint64_t)fy_order_key(f) << 32) | (uint32_t)(0x7FFFFFFF - A.rank_item_raw[i]); myvalid++; }
+        }
+        cand[i] = c;
+    }
+    if (myvalid) atomicAdd(&sh_nvalid, (uint32_t)myvalid);
+    __syncthreads();
+    fy_bitonic_desc(cand, TOPN_SAMPLE);
+    const int nvalid = (int)sh_nvalid;
+    const uint32_t tau = nvalid >= K ? (uint32_t)(cand[K - 1] >> 32) : 0u;   // valid keys are > 0
+    const int keep = min(K, nvalid);
+    __syncthreads();
+    if (tid == 0) sh_count = (uint32_t)keep;
+    __syncthreads();
+    // stream the rest of the row
+    const int i4_end = (A.Ic + 3) >> 2;
+    for (int i4 = (TOPN_SAMPLE >> 2) + tid; i4 < i4_end; i4 += blockDim.x) {
+        const float4 f4 = *reinterpret_cast<const float4*>(row + 4 * i4);
+        const float fv[4] = {f4.x, f4.y, f4.z, f4.w};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float f = fv[q];
+            const int i = 4 * i4 + q;
+            if (f == f && i < A.Ic) {
+                const uint32_t key = fy_order_key(f);
+                if (key >= tau) {
+                    const uint32_t pos = atomicAdd(&sh_count, 1u);
+                    if (pos < (uint32_t)TOPN_MAX) cand[pos] = ((uint64_t)key << 32) | (uint32_t)(0x7FFFFFFF - A.rank_item_raw[i]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int n = (int)sh_count;
+    if (n > TOPN_MAX) {   // block-uniform
+        if (tid == 0) { overflow[u] = 1; atomicAdd(any_overflow, 1); }
+        return;
+    }
+    int P2 = 1;
+    while (P2 < n) P2 <<= 1;
+    for (int i = n + tid; i < P2; i += blockDim.x) cand[i] = 0ull;
+    __syncthreads();
+    if (n > keep) fy_bitonic_desc(cand, P2);     // nothing survived beyond the sorted sample head: already in order
+    const int off = A.out_off[slot - A.slot_lo];
+    const int user_raw = A.uid[A.slot2du[slot]];
+    for (int i = tid; i < K; i += blockDim.x) {
+        const uint64_t c = cand[i];
+        A.out_user[off + i] = user_raw;
+        A.out_item[off + i] = 0x7FFFFFFF - (int32_t)(uint32_t)c;
+        A.out_score[off + i] = fy_order_unkey((uint32_t)(c >> 32));
+        A.out_cluster[off + i] = A.cluster;
+    }
+}
+
+
+// Fallback: exact radix select (three histogram passes + collect).  Runs only for users k_topn_fast flagged.
+__global__ __launch_bounds__(256) void k_topn_select(TopNArgs A, const int32_t* __restrict__ overflow,
+                                                     const int32_t* __restrict__ any_overflow) {
     __shared__ uint32_t hist[TOPN_BINS];
     __shared__ uint64_t cand[TOPN_MAX];
     __shared__ uint32_t sh_prefix, sh_need, sh_count, sh_eq_taken;
+    if (*any_overflow == 0) return;
     const int u = blockIdx.x;
+    if (overflow[u] == 0) return;
     const int slot = A.slot0 + u;
     const int K = A.n_out[slot - A.slot_lo];
     if (K == 0) return;
@@ -465,6 +611,20 @@ struct fy_rm2_job {
     double ms_prepare = 0;
 };
 
+// launch-shape knobs; environment overrides exist only for the tuning sweeps recorded in DESIGN.md
+struct ScoreTune {
+    int vec = 4;                       // floats per lane: column chunk = 64 * vec items
+    int force_select = 0;              // test hook: route every user through k_topn_select
+    int64_t tile_bytes = (int64_t)1 << 40;   // M[row block][chunk] tile; default: one row block (sweep r1)
+};
+static ScoreTune score_tune() {
+    ScoreTune t;
+    if (const char* e = getenv("FY_SCORE_VEC")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) t.vec = v; }
+    if (const char* e = getenv("FY_TOPN_FORCE_SELECT")) t.force_select = atoi(e) != 0;
+    if (const char* e = getenv("FY_SCORE_TILE_KB")) { long v = atol(e); if (v >= 16) t.tile_bytes = (int64_t)v << 10; }
+    return t;
+}
+
 static void validate_params(const fy_rm2_params* p) {
     if (!p) FY_FAIL(FY_ERR_INVALID_ARGUMENT, "params is NULL");
     if (p->number_of_clusters <= 0) FY_FAIL(FY_ERR_INVALID_ARGUMENT, "numberOfClusters must be > 0 (got %d)", p->number_of_clusters);
@@ -543,6 +703,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
     }
     const int32_t nU = P.nU, nP = P.nP, nI = P.nI, K = P.K;
     const double lambda = prm.lambda;
+    const ScoreTune tune = score_tune();
 
     // ---- p(i|C), per-(cluster,item) statistics, per-rating values
     R->d_icoll.alloc(ctx, nI);
@@ -639,21 +800,37 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             int64_t B = std::max<int64_t>(1, ws / (ldS * 4));
             B = std::min<int64_t>(B, b - a);
             DevBuf<float> S(ctx, (size_t)(B * ldS));
-            const int n_chunks = (int)(ldm / 256);
+            DevBuf<int32_t> overflow(ctx, (size_t)B), any_overflow(ctx, 1);
+            const int VEC = tune.vec;
+            const int n_chunks = (int)ceil_div(Ic, 64 * VEC);
+            // row blocks: tile = rb_rows x (256 * VEC) bytes <= tune.tile_bytes; one block when the cluster is small
+            int32_t rb_rows = (int32_t)std::max<int64_t>(64, tune.tile_bytes / (256 * VEC));
+            int32_t nrb = (int32_t)ceil_div(Ic, rb_rows);
+            if (nrb <= 1) { nrb = 1; rb_rows = Ic; }
+            DevBuf<int32_t> rb_off(ctx, (size_t)Uc * (nrb + 1));
+            build_chunk_offsets(ctx, P.rowptr.get(), P.csr_idx.get(), sbase, Uc, rb_rows, nrb, rb_off.get());
             for (int32_t s0 = a; s0 < b; s0 += (int32_t)B) {
                 const int32_t nb = (int32_t)std::min<int64_t>(B, b - s0);
                 int n_slices = (int)std::max<int64_t>(1, std::min<int64_t>(1024, ceil_div(nb, 4 * 16)));
-                ScoreArgs SA{M.get(), ldm, Ic, a_rank.get() + pbase, P.rowptr.get(), P.csr_idx.get(), csr_e.get(), pvpi.get(),
-                             n_out.get(), lo, s0, nb, S.get(), ldS, n_slices};
                 const size_t ss = t_score.begin();
-                k_score<<<n_chunks * n_slices, 256, 0, st>>>(SA);
-                FY_KERNEL_CHECK();
+                for (int32_t rb = 0; rb < nrb; rb++) {
+                    ScoreArgs SA{M.get(), ldm, Ic, a_rank.get() + pbase, rb_off.get(), P.csr_idx.get(), csr_e.get(), pvpi.get(),
+                                 n_out.get(), lo, sbase, s0, nb, S.get(), ldS, n_slices, rb, nrb};
+#define FY_LAUNCH_SCORE(V_) k_score<V_><<<n_chunks * n_slices, 256, 0, st>>>(SA.M, SA.a_rank, SA.rb_off, SA.csr_idx, SA.csr_e, SA.pvpi, SA.n_out, SA.S, SA)
+                    if (VEC == 4) FY_LAUNCH_SCORE(4);
+                    else if (VEC == 2) FY_LAUNCH_SCORE(2);
+                    else FY_LAUNCH_SCORE(1);
+                    FY_KERNEL_CHECK();
+                    R->st.score_launches++;
+                }
                 t_score.end(ss);
-                R->st.score_launches++;
                 TopNArgs TA{S.get(), ldS, Ic, n_out.get(), out_off.get(), P.rank_item_raw.get() + pbase, P.slot2du.get(), P.uid.get(),
                             lo, s0, c, R->d_key0.get(), R->d_key1.get(), R->d_value.get(), R->d_aux.get()};
                 const size_t tt = t_topn.begin();
-                k_topn<<<nb, 256, 0, st>>>(TA);
+                FY_HIP(hipMemsetAsync(any_overflow.get(), 0, sizeof(int32_t), st));
+                k_topn_fast<<<nb, 256, 0, st>>>(TA, overflow.get(), any_overflow.get(), tune.force_select);
+                FY_KERNEL_CHECK();
+                k_topn_select<<<nb, 256, 0, st>>>(TA, overflow.get(), any_overflow.get());
                 FY_KERNEL_CHECK();
                 t_topn.end(tt);
             }
