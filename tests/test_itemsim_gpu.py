@@ -1,0 +1,88 @@
+"""Item-item similarity build on the GPU vs the CPU oracle.
+
+PARITY UNPINNED against the reference (no golden vector exists for this path: its arithmetic is Mahout 0.8's, see
+oracle/itemsim_oracle.c); the HIP path and the oracle implement the same published definition and must agree to
+float32 rounding of the similarity (the oracle works in fp64, the library accumulates in fp64 and emits float32).
+"""
+import numpy as np
+import pytest
+
+import oracle
+from util import pkg, synth
+
+pytestmark = pytest.mark.gpu
+RTOL = 2e-6
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = pkg().Context(0)
+    yield c
+    c.close()
+
+
+def check(rows, ref_full, K):
+    full = {}
+    for a, b, s in zip(ref_full["item"], ref_full["other"], ref_full["sim"]):
+        full.setdefault(int(a), []).append((int(b), float(s)))
+    got = {}
+    for a, b, s in zip(rows["item"], rows["other"], rows["sim"]):
+        got.setdefault(int(a), []).append((int(b), float(s)))
+    assert set(got) == {a for a, v in full.items() if v}
+    for a, lst in got.items():
+        ref = full[a]
+        k = min(K, len(ref))
+        assert len(lst) == k, (a, len(lst), k)
+        lookup = dict(ref)
+        sims = np.array([s for _, s in lst])
+        want = np.array([lookup[b] for b, _ in lst])
+        assert len({b for b, _ in lst}) == k and all(b != a for b, _ in lst)
+        np.testing.assert_allclose(sims, want, rtol=RTOL)
+        assert np.all(sims[:-1] >= sims[1:])
+        best = np.array([s for _, s in ref[:k]])
+        np.testing.assert_allclose(sims, best, rtol=RTOL)          # nothing better was left out
+
+
+@pytest.mark.parametrize("similarity,K,threshold", [("SIMILARITY_COSINE", 10, None), ("SIMILARITY_COOCCURRENCE", 5, None),
+                                                     ("SIMILARITY_COSINE", 100, 0.15)])
+def test_reference_matrix(ctx, rm_golden, similarity, K, threshold):
+    user, item, score = rm_golden["coo"]
+    keep = score > 0
+    user, item, score = user[keep], item[keep], score[keep]
+    res = pkg().RowSimilarityJob(ctx).run((user, item, score), similarityClassname=similarity, maxSimilaritiesPerRow=K,
+                                          threshold=threshold)
+    sim_id = oracle.COSINE if similarity == "SIMILARITY_COSINE" else oracle.COOCCURRENCE
+    ref = oracle.itemsim(user, item, score, similarity=sim_id, max_similarities_per_item=1 << 30, threshold=threshold)
+    check(res.rows(), ref, K)
+    n = np.bincount(user)
+    assert res.stats["unordered_pairs"] == int((n * (n - 1) // 2).sum()) == ref["pairs"]
+
+
+@pytest.mark.parametrize("shape,K", [("tiny", 20), ("ml100k", 100)])
+def test_synthetic(ctx, shape, K):
+    u, i, s, _ = synth().generate(shape)
+    u, i, s = u.numpy(), i.numpy(), s.numpy()
+    res = pkg().RowSimilarityJob(ctx).run((u, i, s), maxSimilaritiesPerRow=K)
+    ref = oracle.itemsim(u, i, s, max_similarities_per_item=1 << 30, n_threads=8)
+    check(res.rows(), ref, K)
+
+
+def test_item_row_shards_partition_the_result(ctx):
+    u, i, s, _ = synth().generate("tiny")
+    u, i, s = u.numpy(), i.numpy(), s.numpy()
+    job = pkg().RowSimilarityJob(ctx)
+    whole = job.run((u, i, s), maxSimilaritiesPerRow=10).rows()
+    parts = [job.run((u, i, s), maxSimilaritiesPerRow=10, rank=r, world=3).rows() for r in range(3)]
+    key = lambda rows: sorted(zip(rows["item"].tolist(), rows["other"].tolist(), rows["sim"].tolist()))
+    merged = {k: np.concatenate([p[k] for p in parts]) for k in ("item", "other", "sim")}
+    assert key(merged) == key(whole)
+    assert len({int(x) for p in parts for x in np.unique(p["item"])}) == len(np.unique(whole["item"]))
+
+
+def test_bad_arguments(ctx):
+    job = pkg().RowSimilarityJob(ctx)
+    u = np.array([1, 2], dtype=np.int32)
+    with pytest.raises(ValueError):
+        job.run((u, u, u.astype(np.float32)), similarityClassname="class org.apache.mahout...CooccurrenceCountSimilarity")
+    with pytest.raises(RuntimeError, match="RowSimilarityJob failed!"):
+        job.run((u, u, u.astype(np.float32)), maxSimilaritiesPerRow=0)
