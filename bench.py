@@ -180,7 +180,7 @@ def main():
             out["itemsim"] = {"error": str(e)}
 
     if rank == 0 and world == 1 and not a.no_cpu:
-        n_cpu = a.cpu_users or {"ml25m": 300, "netflix": 250, "ml1m": 600, "ml100k": 943}.get(a.shape, 200)
+        n_cpu = a.cpu_users or {"ml25m": 180, "netflix": 150, "ml1m": 600, "ml100k": 943}.get(a.shape, 200)
         out["cpu_baseline"] = cpu_baseline(S, a.shape, facts, a.lam, top_n, n_cpu)
     elif rank == 0:
         out["cpu_baseline"] = None

@@ -259,23 +259,16 @@ class RM2Job:
                                  conf.getInt("filterUsers", 0), n_clusters, int(rank), int(world), 0,
                                  int(workspace_bytes))
 
-    def run(self, ratings, clustering=None, clustering_count=None, rank=0, world=1, exchange=None,
-            workspace_bytes=0):
-        """ratings: a ``Ratings`` or a (user, item, score) triple of arrays.
-        clustering: (users, clusters) arrays = the reference's `clustering` file; None routes everyone to cluster 0.
-        clustering_count: array of numberOfClusters sizes = the `clusteringCount` file (validated when given).
-        exchange(device_ptr, length) -> device_ptr of world*length doubles: the all-gather of the per-item statistics
-        (see parallel.StatsExchange); required when world > 1.
-        Raises RuntimeError("RM2 failed!: ...") on any failure, like RM2Job.java:144-147."""
+    def prepare(self, ratings, clustering=None, clustering_count=None, rank=0, world=1, workspace_bytes=0):
+        """Stage 1 (jobs RM2-1 / RM2-2 up to the exchange).  Returns a PreparedRM2 holding this rank's partial item
+        statistics in HBM; see RM2Job.run for the arguments."""
         lib = _native.load()
         p = self._params(rank, world, workspace_bytes)
         ctx = self.ctx or Context(0)
         self.ctx = ctx
         own_ratings = not isinstance(ratings, Ratings)
-        job = C.c_void_p()
-        res = C.c_void_p()
+        r = Ratings(ctx, *ratings) if own_ratings else ratings
         try:
-            r = Ratings(ctx, *ratings) if own_ratings else ratings
             mu, mc = (_i32(clustering[0]), _i32(clustering[1])) if clustering is not None else (_i32(None), _i32(None))
             if len(mu) != len(mc):
                 raise ValueError("clustering users / clusters differ in length")
@@ -284,25 +277,75 @@ class RM2Job:
                 cc = np.zeros(p.number_of_clusters, dtype=np.int32)
                 k = min(len(clustering_count), p.number_of_clusters)
                 cc[:k] = np.asarray(clustering_count, dtype=np.int32)[:k]
+            job = C.c_void_p()
             try:
                 _check(lib.fy_rm2_prepare(ctx._h, C.byref(p), r._h, len(mu), mu.ctypes.data, mc.ctypes.data,
                                           cc.ctypes.data if cc is not None else None, C.byref(job)))
-                if world > 1:
-                    if exchange is None:
-                        raise ValueError("world > 1 needs an exchange (all-gather of the item statistics)")
-                    buf, n = C.c_void_p(), C.c_int64()
-                    _check(lib.fy_rm2_partial_stats(job, C.byref(buf), C.byref(n)))
-                    gathered = exchange(buf.value, n.value)
-                    _check(lib.fy_rm2_set_global_stats(job, gathered, world))
-                _check(lib.fy_rm2_score(job, C.byref(res)))
             except FilmYouError as e:
                 raise RuntimeError("%s failed!: %s" % (self.JOB_NAME, e.message)) from e
-            return Recommendations(res, ctx)
+            return PreparedRM2(job, ctx, world)
         finally:
-            if job:
-                lib.fy_rm2_job_destroy(job)
-            if own_ratings and "r" in locals():
+            if own_ratings:
                 r.close()
+
+    def run(self, ratings, clustering=None, clustering_count=None, rank=0, world=1, exchange=None,
+            workspace_bytes=0):
+        """ratings: a ``Ratings`` or a (user, item, score) triple of arrays.
+        clustering: (users, clusters) arrays = the reference's `clustering` file; None routes everyone to cluster 0.
+        clustering_count: array of numberOfClusters sizes = the `clusteringCount` file (validated when given).
+        exchange(device_ptr, length) -> device_ptr of world*length doubles: the all-gather of the per-item statistics
+        (see parallel.StatsExchange); required when world > 1.
+        Raises RuntimeError("RM2 failed!: ...") on any failure, like RM2Job.java:144-147."""
+        if world > 1 and exchange is None:
+            raise ValueError("world > 1 needs an exchange (all-gather of the item statistics)")
+        prepared = self.prepare(ratings, clustering, clustering_count, rank, world, workspace_bytes)
+        try:
+            if world > 1:
+                ptr, n = prepared.partial_stats()
+                prepared.set_global_stats(exchange(ptr, n))
+            return prepared.score()
+        finally:
+            prepared.close()
+
+
+class PreparedRM2:
+    """A job between its two stages (fy_rm2_job): the CSR/CSC and this rank's partial statistics are in HBM."""
+
+    def __init__(self, handle, ctx, world):
+        self._lib = _native.load()
+        self._h = handle
+        self._ctx = ctx
+        self.world = world
+
+    def partial_stats(self):
+        """(device pointer, length in doubles) of the exchange buffer: per-item partial rating sums in ascending raw
+        item id order + this rank's partial of the floor-sum counter (x100)."""
+        buf, n = C.c_void_p(), C.c_int64()
+        _check(self._lib.fy_rm2_partial_stats(self._h, C.byref(buf), C.byref(n)))
+        return buf.value, n.value
+
+    def set_global_stats(self, gathered_device_ptr):
+        _check(self._lib.fy_rm2_set_global_stats(self._h, gathered_device_ptr, self.world))
+
+    def score(self):
+        res = C.c_void_p()
+        try:
+            _check(self._lib.fy_rm2_score(self._h, C.byref(res)))
+        except FilmYouError as e:
+            raise RuntimeError("%s failed!: %s" % (RM2Job.JOB_NAME, e.message)) from e
+        return Recommendations(res, self._ctx)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            if self._ctx._h:
+                self._lib.fy_rm2_job_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class RowSimilarityJob:

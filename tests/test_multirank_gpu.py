@@ -1,0 +1,98 @@
+"""The user-sharded (multi-GPU) RM2 path, rehearsed on ONE GPU: every rank's stage 1 runs in turn, the all-gather of
+the partial item statistics is played by hand (concatenation in rank order -- exactly the layout RCCL's all-gather
+produces), every rank's stage 2 runs, and the union of the ranks' rows must equal the single-rank result."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from util import assert_topn_matches, pkg, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = pkg().Context(0)
+    yield c
+    c.close()
+
+
+def device_doubles(ptr, n):
+    par = __import__("importlib").import_module("filmyou-core_amd.parallel")
+    return torch.as_tensor(par._DevicePointer(ptr, n, "<f8"), device="cuda:0")
+
+
+@pytest.mark.parametrize("shape,K,world", [("tiny", 1, 2), ("tiny", 5, 3), ("ml100k", 1, 4), ("ml100k", 12, 8)])
+def test_sharded_equals_single(ctx, shape, K, world):
+    P, S = pkg(), synth()
+    u, i, s, facts = S.generate(shape)
+    u, i, s = u.numpy(), i.numpy(), s.numpy()
+    uu = np.unique(u)
+    clustering = (uu, S.hash_clustering(uu, K))
+    conf = P.Configuration()
+    conf.set("lambda", "0.1")
+    conf.setInt("numberOfItems", facts["n_items"])
+    conf.setInt("numberOfClusters", K)
+    conf.setInt("numberOfRecommendations", 20)
+    ratings = P.Ratings(ctx, u, i, s)
+    job = P.RM2Job(conf, ctx)
+    single = job.run(ratings, clustering=clustering)
+
+    prepared = [job.prepare(ratings, clustering=clustering, rank=r, world=world) for r in range(world)]
+    parts = []
+    for pr in prepared:
+        ptr, n = pr.partial_stats()
+        parts.append(device_doubles(ptr, n).clone())
+    torch.cuda.synchronize()
+    gathered = torch.cat(parts).contiguous()                       # rank-major, like all_gather_into_tensor
+    # the partials really are partial: each is a strict part of the total, and they add up to the item sums
+    total = torch.stack(parts).sum(0).cpu().numpy()
+    sums = single.sums()
+    np.testing.assert_array_equal(total[:-1] / (total[-1] / 100.0), sums["item_coll"])
+    assert total[-1] / 100.0 == sums["total_sum"]
+    if world > 1:
+        assert all(float(p[:-1].sum()) < float(total[:-1].sum()) for p in parts)
+    results = []
+    for pr in prepared:
+        pr.set_global_stats(gathered.data_ptr())
+        results.append(pr.score())
+        pr.close()
+    rows = {k: np.concatenate([r.rows()[k] for r in results]) for k in ("user", "item", "score", "cluster")}
+    # ranks own disjoint users, together all of them
+    owners = [set(r.rows()["user"].tolist()) for r in results]
+    assert sum(len(o) for o in owners) == len(set().union(*owners)) == len(np.unique(single.rows()["user"]))
+    ref = oracle.rm2(u, i, s, lam=0.1, number_of_items=facts["n_items"], number_of_recommendations=1 << 30,
+                     number_of_clusters=K, map_user=clustering[0], map_cluster=clustering[1], n_threads=8)
+    assert_topn_matches(rows, ref, 20)
+    # and the shards agree with the one-GPU run row for row (same kernels, same statistics)
+    key = lambda r: sorted(zip(r["user"].tolist(), r["item"].tolist()))
+    assert key(rows) == key(single.rows())
+    a = dict(zip(zip(rows["user"].tolist(), rows["item"].tolist()), rows["score"].tolist()))
+    b = dict(zip(zip(single.rows()["user"].tolist(), single.rows()["item"].tolist()), single.rows()["score"].tolist()))
+    assert max(abs(a[k] - b[k]) / abs(b[k]) for k in a) < 1e-6
+    st = [r.stats for r in results]
+    assert sum(x["users_scored"] for x in st) == single.stats["users_scored"]
+    assert sum(x["log_terms"] for x in st) == single.stats["log_terms"]
+    ratings.close()
+
+
+def test_stats_exchange_wraps_the_library_buffer(ctx, rm_golden):
+    """parallel.StatsExchange with world == 1 degenerates to a copy; the pointer round-trips through torch."""
+    P = pkg()
+    par = __import__("importlib").import_module("filmyou-core_amd.parallel")
+    conf = P.Configuration()
+    conf.setFloat("lambda", 0.5)
+    conf.setInt("numberOfItems", 100)
+    conf.setInt("numberOfClusters", 10)
+    pr = P.RM2Job(conf, ctx).prepare(rm_golden["coo"], clustering=(rm_golden["map_user"], rm_golden["map_cluster"]))
+    ptr, n = pr.partial_stats()
+    assert n == 101
+    ex = par.StatsExchange(0)
+    g = ex(ptr, n)
+    t = device_doubles(g, n).cpu().numpy()
+    np.testing.assert_array_equal(t[:-1], np.asarray(rm_golden["itemSum"]))
+    assert t[-1] == rm_golden["totalSum"] * 100
+    pr.set_global_stats(g)
+    assert pr.score().size == 507
+    pr.close()
