@@ -39,6 +39,7 @@ def _stale():
 def build(force=False, verbose=False):
     """hipcc cross-compiles for gfx950 without a GPU (about half a minute).  Returns the .so path."""
     if not force and not _stale():
+        build_host_driver()
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -48,7 +49,23 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
+    build_host_driver()
     return LIB_PATH
+
+
+HOST_DIR = os.path.join(_HERE, "host")
+HOST_DRIVER = os.path.join(HOST_DIR, "rm2_main")
+
+
+def build_host_driver():
+    """g++ build of the C++ host-side mirror's driver (filmyou-core_amd/host/rm2_main.cpp) against the library."""
+    src = os.path.join(HOST_DIR, "rm2_main.cpp")
+    hdr = os.path.join(HOST_DIR, "filmyou_job.hpp")
+    if os.path.exists(HOST_DRIVER) and all(os.path.getmtime(HOST_DRIVER) >= os.path.getmtime(p) for p in (src, hdr, LIB_PATH)):
+        return HOST_DRIVER
+    subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-o", HOST_DRIVER, src, "-L" + LIB_DIR, "-lfilmyou_hip",
+                    "-Wl,-rpath,$ORIGIN/../lib"], check=True)
+    return HOST_DRIVER
 
 
 class RM2Params(C.Structure):
