@@ -132,8 +132,17 @@ def main():
     launches = st["score_launches"]
     alg_bytes = 4.0 * st["log_terms"]                  # 4 B (one fp32 matrix element) per log-term
     achieved = alg_bytes / (ms_score * 1e-3) / 1e9 if ms_score > 0 else 0.0
+    traffic = None
+    if a.shape == "ml25m" and K == 1:
+        # HBM-side bytes per launch from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same command
+        # (tools/profile_round.sh), corrected as MI355X_MICROARCH.md prescribes; committed under profiles/
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic_k_score.json")))
+        if cands:
+            with open(cands[-1]) as f:
+                traffic = json.load(f)["hbm_bytes_per_launch"]
     roofline = {"bound": "hbm", "kernel": "k_score", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "launches_per_step": launches, "avg_launch_ms": ms_score / max(1, launches),
                 "algorithmic_bytes_per_launch": alg_bytes / max(1, launches),
                 "log_terms_per_s": st["log_terms"] / (ms_score * 1e-3) if ms_score > 0 else 0.0,
@@ -179,6 +188,17 @@ def main():
         except RuntimeError as e:
             out["itemsim"] = {"error": str(e)}
 
+    if world == 1:
+        # the boundary also takes host buffers (fy_ratings_create FY_HOST + result download): PCIe-inclusive rate, reported
+        # beside the headline value, never as it
+        hu, hi_, hs = user.cpu().numpy(), item.cpu().numpy(), score.cpu().numpy()
+        t0 = time.perf_counter()
+        rec = job.run((hu, hi_, hs), clustering=clustering)
+        n_rows = len(rec.rows()["user"])
+        dt = time.perf_counter() - t0
+        rec.close()
+        out["pcie_inclusive"] = {"value": n_rows / dt, "unit": "recs/s", "ms": 1e3 * dt,
+                                 "note": "host COO -> HBM -> job -> rows back in host memory, one run"}
     if rank == 0 and world == 1 and not a.no_cpu:
         n_cpu = a.cpu_users or {"ml25m": 180, "netflix": 150, "ml1m": 600, "ml100k": 943}.get(a.shape, 200)
         out["cpu_baseline"] = cpu_baseline(S, a.shape, facts, a.lam, top_n, n_cpu)
