@@ -59,9 +59,6 @@ int fy_context_create(int device_ordinal, fy_context** out) {
     c->c.num_cus = prop.multiProcessorCount;
     c->c.total_mem = prop.totalGlobalMem;
     FY_HIP(hipStreamCreateWithFlags(&c->c.stream, hipStreamNonBlocking));
-    FY_HIP(hipDeviceGetDefaultMemPool(&c->c.pool, device_ordinal));
-    uint64_t keep = ~0ull;   // keep freed blocks in the pool: repeated jobs do not pay hipMalloc again
-    FY_HIP(hipMemPoolSetAttribute(c->c.pool, hipMemPoolAttrReleaseThreshold, &keep));
     *out = c.release();
     FY_CATCH
 }
@@ -71,6 +68,9 @@ void fy_context_destroy(fy_context* c) {
     (void)hipSetDevice(c->c.device);
     if (c->c.stream) {
         (void)hipStreamSynchronize(c->c.stream);
+        c->c.trim();
+        for (auto& kv : c->c.capacity) (void)hipFree(kv.first);   // blocks still held by live objects: caller error, reclaimed anyway
+        c->c.capacity.clear();
         (void)hipStreamDestroy(c->c.stream);
     }
     delete c;

@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <string>
 #include <utility>
 #include <vector>
@@ -40,13 +41,55 @@ struct Failure {
 #define FY_KERNEL_CHECK() FY_HIP(hipGetLastError())
 
 // ---------------------------------------------------------------- context
+// One GPU, one stream, and a caching HBM allocator.  Every kernel and copy of a context runs on `stream`, so a block
+// released by the host while work is still queued may be handed to a later allocation: the later user is ordered behind
+// the earlier one by the stream (the semantics of hipFreeAsync, without the driver's pool: hipMallocAsync re-grew its
+// pool at unpredictable steps and stalled whole jobs by 0.3-0.9 s when 14-16 GB buffers were split and re-requested).
+// After the first job every request is served from the cache; fy_context_destroy returns the memory.
 struct Context {
     int device = -1;
     hipStream_t stream = nullptr;
-    hipMemPool_t pool = nullptr;
     int num_cus = 256;
     size_t lds_per_block = 160 * 1024;
     size_t total_mem = 0;
+    std::multimap<size_t, void*> free_blocks;   // capacity -> block
+    std::map<void*, size_t> capacity;            // every block ever handed out
+
+    void* alloc(size_t bytes) {
+        const size_t want = (bytes + 255) & ~size_t(255);
+        auto it = free_blocks.lower_bound(want);
+        if (it != free_blocks.end() && it->first <= want + want / 4 + (1u << 20)) {
+            void* p = it->second;
+            free_blocks.erase(it);
+            return p;
+        }
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {   // give cached blocks back to the driver and retry once
+            (void)hipGetLastError();
+            (void)hipStreamSynchronize(stream);
+            trim();
+            e = hipMalloc(&p, want);
+        }
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("HBM allocation of %zu bytes failed: %s", want, hipGetErrorString(e));
+            throw Failure{FY_ERR_OUT_OF_MEMORY};
+        }
+        capacity[p] = want;
+        return p;
+    }
+    void release(void* p) {
+        auto it = capacity.find(p);
+        if (it != capacity.end()) free_blocks.emplace(it->second, p);
+    }
+    void trim() {   // the stream must be idle
+        for (auto& kv : free_blocks) {
+            (void)hipFree(kv.second);
+            capacity.erase(kv.second);
+        }
+        free_blocks.clear();
+    }
 };
 
 // ---------------------------------------------------------------- HBM buffer (stream-ordered alloc / free)
@@ -74,18 +117,11 @@ struct DevBuf {
         ctx = c;
         n = count;
         size_t bytes = (count ? count : 1) * sizeof(T);
-        void* q = nullptr;
-        hipError_t e = hipMallocAsync(&q, bytes, c->stream);
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            set_error("HBM allocation of %zu bytes failed: %s", bytes, hipGetErrorString(e));
-            throw Failure{FY_ERR_OUT_OF_MEMORY};
-        }
-        p = static_cast<T*>(q);
+        p = static_cast<T*>(c->alloc(bytes));
     }
     void zero() { FY_HIP(hipMemsetAsync(p, 0, (n ? n : 1) * sizeof(T), ctx->stream)); }
     void release() {
-        if (p) (void)hipFreeAsync(p, ctx->stream);
+        if (p) ctx->release(p);
         p = nullptr;
         n = 0;
     }

@@ -391,10 +391,8 @@ void build_structure(Context* ctx, const fy_ratings* R, int32_t K, int64_t n_map
     k_scatter_pairs<<<grid_for(nnz), 256, 0, st>>>(nnz, k3b.get(), head.get(), pr1.get(), P.pair_cluster.get(),
                                                     pair_item.get(), P.pair_start.get(), pcount.get());
     FY_KERNEL_CHECK();
-    {
-        const int32_t last = (int32_t)nnz;
-        h2d(ctx, P.pair_start.get() + nP, &last, 1);
-    }
+    const int32_t last_pair = (int32_t)nnz;   // must outlive the copy (synchronised just below)
+    h2d(ctx, P.pair_start.get() + nP, &last_pair, 1);
     std::vector<int32_t> hpc(K);
     d2h(ctx, hpc.data(), pcount.get(), (size_t)K);
     sync(ctx);

@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 #include "fy_cooc.hpp"
 #include "fy_prep.hpp"
@@ -188,6 +189,7 @@ struct MEpilogue {
     const double* __restrict__ b_rank;
     double w2;    // (1-l)^2
     double w1;    // l (1-l)
+    int pack24;   // 3 bytes per element: 8 exponent + 16 mantissa bits of the (non-negative) fp32, rounded to nearest
 };
 
 __global__ void k_cooc_rm2(CoocArgs A, MEpilogue E) {
@@ -202,6 +204,24 @@ __global__ void k_cooc_rm2(CoocArgs A, MEpilogue E) {
     // the last chunk also writes the padding columns [Ic, ldm) so the scoring kernel may load whole 256-wide chunks
     const int c1 = (ch == A.nch - 1) ? (int)E.ldm : min(c0 + A.CH, (int)E.ldm);
     const double pj = E.p_rank[row];
+    if (E.pack24) {
+        // four columns -> three dwords (c0 and c1 are multiples of 64)
+        uint32_t* __restrict__ out3 = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(E.M) + (int64_t)row * E.ldm * 3);
+        for (int c4 = (c0 >> 2) + threadIdx.x; 4 * c4 < c1; c4 += blockDim.x) {
+            uint32_t v[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int col = 4 * c4 + q;
+                float f = 0.0f;
+                if (col < A.Ic) f = (float)(E.w2 * acc[col - c0] + E.w1 * pj * E.b_rank[col]);
+                v[q] = ((__float_as_uint(f) << 1) + 0x80u) >> 8;   // M >= 0: drop the sign, keep 8 exponent + 16 mantissa bits, round to nearest
+            }
+            out3[3 * c4 + 0] = v[0] | (v[1] << 24);
+            out3[3 * c4 + 1] = (v[1] >> 8) | (v[2] << 16);
+            out3[3 * c4 + 2] = (v[2] >> 16) | (v[3] << 8);
+        }
+        return;
+    }
     float* __restrict__ out = E.M + (int64_t)row * E.ldm;
     for (int col = c0 + threadIdx.x; col < c1; col += blockDim.x) {
         float v = 0.0f;
@@ -252,12 +272,25 @@ template <> struct VecT<4> { using type = float4; };
 // The read-only arrays are separate `const T* __restrict__` kernel arguments (not struct members): only then does hipcc
 // prove them invariant and fetch the wave-uniform idx / e / offsets with scalar loads (s_load) instead of a vector
 // load + v_readfirstlane in front of every row-segment load.
-template <int VEC>
+struct U3 {
+    uint32_t a, b, c;
+};
+// four packed 24-bit values (12 bytes; exponent + 16 mantissa bits, no sign) -> four floats: v_perm_b32 + shift each
+__device__ __forceinline__ void fy_unpack24(const U3& d, float* f) {
+    f[0] = __uint_as_float(__builtin_amdgcn_perm(0u, d.a, 0x0201000cu) >> 1);
+    f[1] = __uint_as_float(__builtin_amdgcn_perm(d.b, d.a, 0x0504030cu) >> 1);
+    f[2] = __uint_as_float(__builtin_amdgcn_perm(d.c, d.b, 0x0403020cu) >> 1);
+    f[3] = __uint_as_float(__builtin_amdgcn_perm(0u, d.c, 0x0302010cu) >> 1);
+}
+
+template <int VEC, bool P24>
 __global__ __launch_bounds__(256) void k_score(const float* __restrict__ M_, const float* __restrict__ a_rank_,
                                                const int32_t* __restrict__ rb_off_, const int32_t* __restrict__ csr_idx_,
                                                const float* __restrict__ csr_e_, const double* __restrict__ pvpi_,
                                                const int32_t* __restrict__ n_out_, float* __restrict__ S_, ScoreArgs A) {
     using V = typename VecT<VEC>::type;
+    using G = typename std::conditional<P24, U3, V>::type;   // what one lane loads per row
+    static_assert(!P24 || VEC == 4, "24-bit rows are packed four columns to three dwords");
     constexpr int CW = 64 * VEC;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -268,7 +301,9 @@ __global__ __launch_bounds__(256) void k_score(const float* __restrict__ M_, con
     float a[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; v++) a[v] = col + v < A.Ic ? a_rank_[col + v] : 0.0f;
-    const float* __restrict__ Mcol = M_ + col;
+    // byte address of this lane's part of row 0; the row pitch is ldm * (P24 ? 3 : 4) bytes
+    const char* __restrict__ Mcol = reinterpret_cast<const char*>(M_) + (int64_t)col * (P24 ? 3 : 4);
+    const int64_t pitch = A.ldm * (P24 ? 3 : 4);
     const double LN2 = 0.69314718055994530942;
     const float qnan = __builtin_nanf("");
     const bool first = A.rb == 0;
@@ -289,7 +324,7 @@ __global__ __launch_bounds__(256) void k_score(const float* __restrict__ M_, con
         // batches of 8 rows: all eight segment loads are issued before the first use, also for a short tail
         // (out-of-range slots re-load the last valid row -- an L1 hit -- and are skipped by a wave-uniform test)
         for (int k = beg; k < end; k += 8) {
-            V g[8];
+            G g[8];
             float e[8];
             int jj[8];
 #pragma unroll
@@ -297,7 +332,7 @@ __global__ __launch_bounds__(256) void k_score(const float* __restrict__ M_, con
                 const int kk = min(k + q, end - 1);
                 jj[q] = csr_idx_[kk];
                 e[q] = csr_e_[kk];
-                g[q] = *reinterpret_cast<const V*>(Mcol + (int64_t)jj[q] * A.ldm);
+                g[q] = *reinterpret_cast<const G*>(Mcol + (int64_t)jj[q] * pitch);
             }
             float p[VEC];
 #pragma unroll
@@ -305,7 +340,13 @@ __global__ __launch_bounds__(256) void k_score(const float* __restrict__ M_, con
 #pragma unroll
             for (int q = 0; q < 8; q++) {
                 if (k + q < end) {
-                    const float* gv = reinterpret_cast<const float*>(&g[q]);
+                    float gv[VEC];
+                    if constexpr (P24) fy_unpack24(g[q], gv);
+                    else {
+                        const float* gp = reinterpret_cast<const float*>(&g[q]);
+#pragma unroll
+                        for (int v = 0; v < VEC; v++) gv[v] = gp[v];
+                    }
 #pragma unroll
                     for (int v = 0; v < VEC; v++) p[v] += fy_log2(fmaf(a[v], e[q], gv[v]));
                     const unsigned d = (unsigned)(jj[q] - col0);
@@ -615,11 +656,15 @@ struct fy_rm2_job {
 struct ScoreTune {
     int vec = 4;                       // floats per lane: column chunk = 64 * vec items
     int force_select = 0;              // test hook: route every user through k_topn_select
+    int pack24 = 1;                    // M rows as 24-bit floats (3 bytes per element): -25 % of the dominant traffic
+    int pack24_min_items = 4096;       // ... for clusters with at least this many items
     int64_t tile_bytes = (int64_t)1 << 40;   // M[row block][chunk] tile; default: one row block (sweep r1)
 };
 static ScoreTune score_tune() {
     ScoreTune t;
     if (const char* e = getenv("FY_SCORE_VEC")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) t.vec = v; }
+    if (const char* e = getenv("FY_M24")) t.pack24 = atoi(e) != 0;
+    if (const char* e = getenv("FY_M24_MIN_ITEMS")) t.pack24_min_items = atoi(e);
     if (const char* e = getenv("FY_TOPN_FORCE_SELECT")) t.force_select = atoi(e) != 0;
     if (const char* e = getenv("FY_SCORE_TILE_KB")) { long v = atol(e); if (v >= 16) t.tile_bytes = (int64_t)v << 10; }
     return t;
@@ -704,6 +749,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
     const int32_t nU = P.nU, nP = P.nP, nI = P.nI, K = P.K;
     const double lambda = prm.lambda;
     const ScoreTune tune = score_tune();
+    const bool pack24_allowed = tune.pack24 && tune.vec == 4;
 
     // ---- p(i|C), per-(cluster,item) statistics, per-rating values
     R->d_icoll.alloc(ctx, nI);
@@ -779,6 +825,9 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             const int32_t a = std::max(lo, sbase), b = std::min(hi, sbase + Uc);
             if (a >= b || Ic == 0) continue;
             const int64_t ldm = round_up(Ic, 256);
+            // 24-bit rows only where bandwidth matters: small clusters keep exact fp32 rows (their scores are small, and the
+            // reference's own fixture is asserted with an ABSOLUTE 1e-4, T/util/HadoopIntegrationTest.java:53)
+            const bool pack24 = pack24_allowed && Ic >= tune.pack24_min_items;
 
             // -- M build
             int32_t CH, nch;
@@ -787,7 +836,8 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             build_chunk_offsets(ctx, P.rowptr.get(), P.csr_idx.get(), sbase, Uc, CH, nch, chunk_off.get());
             CoocArgs CA{P.rank_pair.get(), P.pair_start.get(), P.csc_slot.get(), csc_x.get(), chunk_off.get(), P.csr_idx.get(),
                         csr_x.get(), pbase, sbase, Ic, CH, nch, 0, Ic};
-            MEpilogue ME{M.get(), ldm, p_rank.get() + pbase, b_rank.get() + pbase, (1.0 - lambda) * (1.0 - lambda), lambda * (1.0 - lambda)};
+            MEpilogue ME{M.get(), ldm, p_rank.get() + pbase, b_rank.get() + pbase, (1.0 - lambda) * (1.0 - lambda), lambda * (1.0 - lambda),
+                         pack24 ? 1 : 0};
             const int block = (CH * 8 > 48 * 1024) ? 1024 : 256;
             const size_t sp = t_cooc.begin();
             k_cooc_rm2<<<Ic * nch, block, (size_t)CH * 8, st>>>(CA, ME);
@@ -816,10 +866,11 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 for (int32_t rb = 0; rb < nrb; rb++) {
                     ScoreArgs SA{M.get(), ldm, Ic, a_rank.get() + pbase, rb_off.get(), P.csr_idx.get(), csr_e.get(), pvpi.get(),
                                  n_out.get(), lo, sbase, s0, nb, S.get(), ldS, n_slices, rb, nrb};
-#define FY_LAUNCH_SCORE(V_) k_score<V_><<<n_chunks * n_slices, 256, 0, st>>>(SA.M, SA.a_rank, SA.rb_off, SA.csr_idx, SA.csr_e, SA.pvpi, SA.n_out, SA.S, SA)
-                    if (VEC == 4) FY_LAUNCH_SCORE(4);
-                    else if (VEC == 2) FY_LAUNCH_SCORE(2);
-                    else FY_LAUNCH_SCORE(1);
+#define FY_LAUNCH_SCORE(V_, P_) k_score<V_, P_><<<n_chunks * n_slices, 256, 0, st>>>(SA.M, SA.a_rank, SA.rb_off, SA.csr_idx, SA.csr_e, SA.pvpi, SA.n_out, SA.S, SA)
+                    if (pack24) FY_LAUNCH_SCORE(4, true);
+                    else if (VEC == 4) FY_LAUNCH_SCORE(4, false);
+                    else if (VEC == 2) FY_LAUNCH_SCORE(2, false);
+                    else FY_LAUNCH_SCORE(1, false);
                     FY_KERNEL_CHECK();
                     R->st.score_launches++;
                 }
