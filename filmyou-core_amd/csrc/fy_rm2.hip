@@ -283,7 +283,7 @@ __device__ __forceinline__ void fy_unpack24(const U3& d, float* f) {
     f[3] = __uint_as_float(__builtin_amdgcn_perm(0u, d.c, 0x0302010cu) >> 1);
 }
 
-template <int VEC, bool P24>
+template <int VEC, bool P24, int SB>
 __global__ __launch_bounds__(256) void k_score(const float* __restrict__ M_, const float* __restrict__ a_rank_,
                                                const int32_t* __restrict__ rb_off_, const int32_t* __restrict__ csr_idx_,
                                                const float* __restrict__ csr_e_, const double* __restrict__ pvpi_,
@@ -323,12 +323,12 @@ __global__ __launch_bounds__(256) void k_score(const float* __restrict__ M_, con
         unsigned mask = 0;
         // batches of 8 rows: all eight segment loads are issued before the first use, also for a short tail
         // (out-of-range slots re-load the last valid row -- an L1 hit -- and are skipped by a wave-uniform test)
-        for (int k = beg; k < end; k += 8) {
-            G g[8];
-            float e[8];
-            int jj[8];
+        for (int k = beg; k < end; k += SB) {
+            G g[SB];
+            float e[SB];
+            int jj[SB];
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
+            for (int q = 0; q < SB; q++) {
                 const int kk = min(k + q, end - 1);
                 jj[q] = csr_idx_[kk];
                 e[q] = csr_e_[kk];
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256) void k_score(const float* __restrict__ M_, con
 #pragma unroll
             for (int v = 0; v < VEC; v++) p[v] = 0.f;
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
+            for (int q = 0; q < SB; q++) {
                 if (k + q < end) {
                     float gv[VEC];
                     if constexpr (P24) fy_unpack24(g[q], gv);
@@ -371,6 +371,123 @@ __global__ __launch_bounds__(256) void k_score(const float* __restrict__ M_, con
         for (int v = 0; v < VEC; v++)
             if ((mask >> v) & 1u || col + v >= A.Ic) ov[v] = qnan;
         *reinterpret_cast<V*>(dst) = o;
+    }
+}
+
+// ---------------------------------------------------------------- variant with the hottest rows resident in LDS
+// One 1024-thread workgroup per CU keeps the `H` most popular rows of its column chunk (popularity rank = row index) in
+// LDS as fp32 -- 128 rows x 1 KiB -- for its whole life and scores many users against them; those rows carry ~22 % of
+// all row reads of the ML-25M-shaped workload, which then never leave the CU.  The cold remainder of every user's row
+// is streamed from global memory exactly like k_score.  hot_off[(slot - slot_base) * 3 + {0,1,2}] = {row begin,
+// first entry with idx >= H, row end}.
+constexpr int SCORE_HOT_ROWS = 128;
+
+template <bool P24>
+__global__ __launch_bounds__(1024) void k_score_hot(const float* __restrict__ M_, const float* __restrict__ a_rank_,
+                                                    const int32_t* __restrict__ hot_off_, const int32_t* __restrict__ csr_idx_,
+                                                    const float* __restrict__ csr_e_, const double* __restrict__ pvpi_,
+                                                    const int32_t* __restrict__ n_out_, float* __restrict__ S_, ScoreArgs A) {
+    extern __shared__ float4 fy_hot_tile[];   // [H][64] float4
+    using G = typename std::conditional<P24, U3, float4>::type;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwaves = blockDim.x >> 6;
+    const int chunk = blockIdx.x / A.n_slices;
+    const int slice = blockIdx.x - chunk * A.n_slices;
+    const int col0 = chunk * 256;
+    const int col = col0 + lane * 4;
+    const int H = min(SCORE_HOT_ROWS, A.Ic);
+    const char* __restrict__ Mcol = reinterpret_cast<const char*>(M_) + (int64_t)col * (P24 ? 3 : 4);
+    const int64_t pitch = A.ldm * (P24 ? 3 : 4);
+    // stage the hot rows: wave w loads rows w, w + nwaves, ... (one coalesced row segment per instruction)
+    for (int r = wave; r < H; r += nwaves) {
+        const G g = *reinterpret_cast<const G*>(Mcol + (int64_t)r * pitch);
+        float4 f;
+        if constexpr (P24) {
+            float t4[4];
+            fy_unpack24(g, t4);
+            f = make_float4(t4[0], t4[1], t4[2], t4[3]);
+        } else {
+            f = g;
+        }
+        fy_hot_tile[r * 64 + lane] = f;
+    }
+    float a[4];
+#pragma unroll
+    for (int v = 0; v < 4; v++) a[v] = col + v < A.Ic ? a_rank_[col + v] : 0.0f;
+    const double LN2 = 0.69314718055994530942;
+    const float qnan = __builtin_nanf("");
+    __syncthreads();
+    for (int u = slice * nwaves + wave; u < A.n_users; u += A.n_slices * nwaves) {
+        const int slot = A.slot0 + u;
+        if (n_out_[slot - A.slot_lo] == 0) continue;
+        const int32_t* __restrict__ ho = hot_off_ + (int64_t)(slot - A.slot_base) * 3;
+        const int beg = ho[0], hot_end = ho[1], end = ho[2];
+        double t[4] = {0.0, 0.0, 0.0, 0.0};
+        unsigned mask = 0;
+        // hot part: rows from LDS
+        for (int k = beg; k < hot_end; k += 8) {
+            float4 g[8];
+            float e[8];
+            int jj[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int kk = min(k + q, hot_end - 1);
+                jj[q] = csr_idx_[kk];
+                e[q] = csr_e_[kk];
+                g[q] = fy_hot_tile[jj[q] * 64 + lane];
+            }
+            float p[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                if (k + q < hot_end) {
+                    p[0] += fy_log2(fmaf(a[0], e[q], g[q].x));
+                    p[1] += fy_log2(fmaf(a[1], e[q], g[q].y));
+                    p[2] += fy_log2(fmaf(a[2], e[q], g[q].z));
+                    p[3] += fy_log2(fmaf(a[3], e[q], g[q].w));
+                    const unsigned d = (unsigned)(jj[q] - col0);
+                    if (d < 256u && (int)(d >> 2) == lane) mask |= 1u << (d & 3u);
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < 4; v++) t[v] += (double)p[v];
+        }
+        // cold part: rows streamed from global memory, sixteen segment loads in flight per wave (16 waves per CU)
+        constexpr int CB = 16;
+        for (int k = hot_end; k < end; k += CB) {
+            G g[CB];
+            float e[CB];
+            int jj[CB];
+#pragma unroll
+            for (int q = 0; q < CB; q++) {
+                const int kk = min(k + q, end - 1);
+                jj[q] = csr_idx_[kk];
+                e[q] = csr_e_[kk];
+                g[q] = *reinterpret_cast<const G*>(Mcol + (int64_t)jj[q] * pitch);
+            }
+            float p[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < CB; q++) {
+                if (k + q < end) {
+                    float gv[4];
+                    if constexpr (P24) fy_unpack24(g[q], gv);
+                    else { gv[0] = g[q].x; gv[1] = g[q].y; gv[2] = g[q].z; gv[3] = g[q].w; }
+#pragma unroll
+                    for (int v = 0; v < 4; v++) p[v] += fy_log2(fmaf(a[v], e[q], gv[v]));
+                    const unsigned d = (unsigned)(jj[q] - col0);
+                    if (d < 256u && (int)(d >> 2) == lane) mask |= 1u << (d & 3u);
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < 4; v++) t[v] += (double)p[v];
+        }
+        const double base = pvpi_[slot - A.slot_lo];
+        float4 o;
+        o.x = ((mask & 1u) || col + 0 >= A.Ic) ? qnan : (float)(base + LN2 * t[0]);
+        o.y = ((mask & 2u) || col + 1 >= A.Ic) ? qnan : (float)(base + LN2 * t[1]);
+        o.z = ((mask & 4u) || col + 2 >= A.Ic) ? qnan : (float)(base + LN2 * t[2]);
+        o.w = ((mask & 8u) || col + 3 >= A.Ic) ? qnan : (float)(base + LN2 * t[3]);
+        *reinterpret_cast<float4*>(S_ + (int64_t)u * A.ldS + col) = o;
     }
 }
 
@@ -658,6 +775,9 @@ struct ScoreTune {
     int force_select = 0;              // test hook: route every user through k_topn_select
     int pack24 = 1;                    // M rows as 24-bit floats (3 bytes per element): -25 % of the dominant traffic
     int pack24_min_items = 4096;       // ... for clusters with at least this many items
+    int batch = 8;                     // row-segment loads in flight per wave
+    int hot_lds = 0;                   // k_score_hot: the 128 most popular rows of a chunk stay in LDS (slower: 16 waves/CU)
+    int hot_min_items = 2048;
     int64_t tile_bytes = (int64_t)1 << 40;   // M[row block][chunk] tile; default: one row block (sweep r1)
 };
 static ScoreTune score_tune() {
@@ -665,6 +785,9 @@ static ScoreTune score_tune() {
     if (const char* e = getenv("FY_SCORE_VEC")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) t.vec = v; }
     if (const char* e = getenv("FY_M24")) t.pack24 = atoi(e) != 0;
     if (const char* e = getenv("FY_M24_MIN_ITEMS")) t.pack24_min_items = atoi(e);
+    if (const char* e = getenv("FY_HOT_LDS")) t.hot_lds = atoi(e) != 0;
+    if (const char* e = getenv("FY_SCORE_BATCH")) t.batch = atoi(e);
+    if (const char* e = getenv("FY_HOT_MIN_ITEMS")) t.hot_min_items = atoi(e);
     if (const char* e = getenv("FY_TOPN_FORCE_SELECT")) t.force_select = atoi(e) != 0;
     if (const char* e = getenv("FY_SCORE_TILE_KB")) { long v = atol(e); if (v >= 16) t.tile_bytes = (int64_t)v << 10; }
     return t;
@@ -816,6 +939,8 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
         const int64_t ws = prm.workspace_bytes > 0 ? prm.workspace_bytes : (int64_t)16 << 30;
         const int max_ch_lds = 16384;   // fp64 accumulators: 128 KiB of the 160 KiB LDS
         FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cooc_rm2), hipFuncAttributeMaxDynamicSharedMemorySize, max_ch_lds * 8));
+        FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_score_hot<true>), hipFuncAttributeMaxDynamicSharedMemorySize, SCORE_HOT_ROWS * 1024));
+        FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_score_hot<false>), hipFuncAttributeMaxDynamicSharedMemorySize, SCORE_HOT_ROWS * 1024));
 
         for (int c = 0; c < K; c++) {
             const int32_t Uc = P.csize[c];
@@ -859,18 +984,34 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             if (nrb <= 1) { nrb = 1; rb_rows = Ic; }
             DevBuf<int32_t> rb_off(ctx, (size_t)Uc * (nrb + 1));
             build_chunk_offsets(ctx, P.rowptr.get(), P.csr_idx.get(), sbase, Uc, rb_rows, nrb, rb_off.get());
+            const bool use_hot = tune.hot_lds && VEC == 4 && nrb == 1 && Ic >= tune.hot_min_items;
+            DevBuf<int32_t> hot_off(ctx, use_hot ? (size_t)Uc * 3 : 1);
+            if (use_hot) build_chunk_offsets(ctx, P.rowptr.get(), P.csr_idx.get(), sbase, Uc, SCORE_HOT_ROWS, 2, hot_off.get());
             for (int32_t s0 = a; s0 < b; s0 += (int32_t)B) {
                 const int32_t nb = (int32_t)std::min<int64_t>(B, b - s0);
                 int n_slices = (int)std::max<int64_t>(1, std::min<int64_t>(1024, ceil_div(nb, 4 * 16)));
                 const size_t ss = t_score.begin();
-                for (int32_t rb = 0; rb < nrb; rb++) {
+                if (use_hot) {
+                    // one 16-wave workgroup per CU (128 KiB of LDS); every wave gets >= 8 users to amortise the tile load
+                    const int hs = (int)std::max<int64_t>(1, std::min<int64_t>(256, ceil_div(nb, 16 * 8)));
+                    ScoreArgs SA{M.get(), ldm, Ic, a_rank.get() + pbase, hot_off.get(), P.csr_idx.get(), csr_e.get(), pvpi.get(),
+                                 n_out.get(), lo, sbase, s0, nb, S.get(), ldS, hs, 0, 1};
+                    const size_t lds = (size_t)SCORE_HOT_ROWS * 1024;
+                    if (pack24) k_score_hot<true><<<(int)(ldm / 256) * hs, 1024, lds, st>>>(SA.M, SA.a_rank, SA.rb_off, SA.csr_idx, SA.csr_e, SA.pvpi, SA.n_out, SA.S, SA);
+                    else k_score_hot<false><<<(int)(ldm / 256) * hs, 1024, lds, st>>>(SA.M, SA.a_rank, SA.rb_off, SA.csr_idx, SA.csr_e, SA.pvpi, SA.n_out, SA.S, SA);
+                    FY_KERNEL_CHECK();
+                    R->st.score_launches++;
+                }
+                for (int32_t rb = 0; rb < (use_hot ? 0 : nrb); rb++) {
                     ScoreArgs SA{M.get(), ldm, Ic, a_rank.get() + pbase, rb_off.get(), P.csr_idx.get(), csr_e.get(), pvpi.get(),
                                  n_out.get(), lo, sbase, s0, nb, S.get(), ldS, n_slices, rb, nrb};
-#define FY_LAUNCH_SCORE(V_, P_) k_score<V_, P_><<<n_chunks * n_slices, 256, 0, st>>>(SA.M, SA.a_rank, SA.rb_off, SA.csr_idx, SA.csr_e, SA.pvpi, SA.n_out, SA.S, SA)
-                    if (pack24) FY_LAUNCH_SCORE(4, true);
-                    else if (VEC == 4) FY_LAUNCH_SCORE(4, false);
-                    else if (VEC == 2) FY_LAUNCH_SCORE(2, false);
-                    else FY_LAUNCH_SCORE(1, false);
+#define FY_LAUNCH_SCORE(V_, P_, B_) k_score<V_, P_, B_><<<n_chunks * n_slices, 256, 0, st>>>(SA.M, SA.a_rank, SA.rb_off, SA.csr_idx, SA.csr_e, SA.pvpi, SA.n_out, SA.S, SA)
+                    if (pack24 && tune.batch == 16) FY_LAUNCH_SCORE(4, true, 16);
+                    else if (pack24 && tune.batch == 12) FY_LAUNCH_SCORE(4, true, 12);
+                    else if (pack24) FY_LAUNCH_SCORE(4, true, 8);
+                    else if (VEC == 4) FY_LAUNCH_SCORE(4, false, 8);
+                    else if (VEC == 2) FY_LAUNCH_SCORE(2, false, 8);
+                    else FY_LAUNCH_SCORE(1, false, 8);
                     FY_KERNEL_CHECK();
                     R->st.score_launches++;
                 }
