@@ -57,12 +57,14 @@ __device__ __forceinline__ void cooc_accumulate_row(const CoocArgs& A, int row, 
     const int stride = A.nch + 1;
     const int32_t* __restrict__ csr_idx = A.csr_idx;
     const float* __restrict__ csr_w = A.csr_w;
-    // Rater (step s, slot q) of this wave = e0 + ((s * nwaves + wave) * 4 + q): consecutive groups of four raters go to
+    // Rater (step s, slot q) of this wave = e0 + ((s * nwaves + wave) * RS + q): consecutive groups of RS raters go to
     // consecutive waves, so a row with few raters still spreads over the whole workgroup (one step per wave), while
-    // lane l = 4 s + q of the wave prefetches the metadata of sixteen steps at once.
+    // lane l = RS s + q of the wave prefetches the metadata of 64 / RS steps at once.  (RS = 16 was slower: fewer
+    // waves busy on short rows.)
+    constexpr int RS = 4, STEPS = 64 / RS;
     for (int round = 0; e0 + round * nwaves * 64 < e1; round++) {
-        const int s_l = lane >> 2, q_l = lane & 3;
-        const int e = e0 + ((round * 16 + s_l) * nwaves + wave) * 4 + q_l;
+        const int s_l = lane / RS, q_l = lane % RS;
+        const int e = e0 + ((round * STEPS + s_l) * nwaves + wave) * RS + q_l;
         int f0 = 0, len = 0;
         float w = 0.0f;
         if (e < e1) {
@@ -73,33 +75,47 @@ __device__ __forceinline__ void cooc_accumulate_row(const CoocArgs& A, int row, 
             len = co[1] - f0;
         }
         const unsigned long long nonempty = __ballot(len > 0);
-        for (int s = 0; s < 16; s++) {   // wave-uniform
-            if (((nonempty >> (4 * s)) & 0xFull) == 0) {
-                if ((nonempty >> (4 * s)) == 0) break;
-                continue;
-            }
-            int F[4], L[4];
-            float W[4];
+        for (int s = 0; s < STEPS; s++) {   // wave-uniform
+            const unsigned long long rest = nonempty >> (RS * s);
+            if (rest == 0) break;
+            if ((rest & ((1ull << RS) - 1ull)) == 0) continue;
+            int F[RS], L[RS];
+            float W[RS];
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                F[q] = __builtin_amdgcn_readlane(f0, 4 * s + q);
-                L[q] = __builtin_amdgcn_readlane(len, 4 * s + q);
-                W[q] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(w), 4 * s + q));
+            for (int q = 0; q < RS; q++) {
+                F[q] = __builtin_amdgcn_readlane(f0, RS * s + q);
+                L[q] = __builtin_amdgcn_readlane(len, RS * s + q);
+                W[q] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(w), RS * s + q));
             }
-            int idx[4];
-            float x[4];
+            int idx[RS];
+            float x[RS];
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
+            for (int q = 0; q < RS; q++) {
                 idx[q] = 0; x[q] = 0.0f;
                 if (lane < L[q]) { idx[q] = csr_idx[F[q] + lane]; x[q] = csr_w[F[q] + lane]; }
             }
 #pragma unroll
-            for (int q = 0; q < 4; q++)
+            for (int q = 0; q < RS; q++)
                 if (lane < L[q]) atomicAdd(&fy_cooc_acc[idx[q] - c0], (double)W[q] * (double)x[q]);
+            // slices longer than one wave: heavy users, who are raters of very many rows -- half of all rater visits at
+            // ML-25M shape.  Eight 64-entry segments are loaded before the first atomic so eight round trips overlap
+            // (a plain one-segment loop here cost a full memory latency per 64 entries and dominated the kernel).
 #pragma unroll
-            for (int q = 0; q < 4; q++)   // slices longer than one wave (heavy users)
-                for (int f = 64 + lane; f < L[q]; f += 64)
-                    atomicAdd(&fy_cooc_acc[csr_idx[F[q] + f] - c0], (double)W[q] * (double)csr_w[F[q] + f]);
+            for (int q = 0; q < RS; q++) {
+                for (int fb = 64; fb < L[q]; fb += 512) {   // wave-uniform
+                    int ix[8];
+                    float xx[8];
+#pragma unroll
+                    for (int z = 0; z < 8; z++) {
+                        const int f = fb + 64 * z + lane;
+                        ix[z] = 0; xx[z] = 0.0f;
+                        if (f < L[q]) { ix[z] = csr_idx[F[q] + f]; xx[z] = csr_w[F[q] + f]; }
+                    }
+#pragma unroll
+                    for (int z = 0; z < 8; z++)
+                        if (fb + 64 * z + lane < L[q]) atomicAdd(&fy_cooc_acc[ix[z] - c0], (double)W[q] * (double)xx[z]);
+                }
+            }
         }
     }
 }
