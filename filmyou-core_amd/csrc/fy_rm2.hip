@@ -776,6 +776,8 @@ struct ScoreTune {
     int pack24 = 1;                    // M rows as 24-bit floats (3 bytes per element): -25 % of the dominant traffic
     int pack24_min_items = 4096;       // ... for clusters with at least this many items
     int batch = 8;                     // row-segment loads in flight per wave
+    int cooc_block = 0;                // test hook: force the row kernel's workgroup size
+    int cooc_max_ch = 16384;           // LDS accumulators of the row kernel (test hook: smaller forces column chunks)
     int hot_lds = 0;                   // k_score_hot: the 128 most popular rows of a chunk stay in LDS (slower: 16 waves/CU)
     int hot_min_items = 2048;
     int64_t tile_bytes = (int64_t)1 << 40;   // M[row block][chunk] tile; default: one row block (sweep r1)
@@ -787,6 +789,8 @@ static ScoreTune score_tune() {
     if (const char* e = getenv("FY_M24_MIN_ITEMS")) t.pack24_min_items = atoi(e);
     if (const char* e = getenv("FY_HOT_LDS")) t.hot_lds = atoi(e) != 0;
     if (const char* e = getenv("FY_SCORE_BATCH")) t.batch = atoi(e);
+    if (const char* e = getenv("FY_COOC_BLOCK")) { int v = atoi(e); if (v == 256 || v == 512 || v == 1024) t.cooc_block = v; }
+    if (const char* e = getenv("FY_COOC_MAX_CH")) { int v = atoi(e); if (v >= 64 && v <= 16384) t.cooc_max_ch = v; }
     if (const char* e = getenv("FY_HOT_MIN_ITEMS")) t.hot_min_items = atoi(e);
     if (const char* e = getenv("FY_TOPN_FORCE_SELECT")) t.force_select = atoi(e) != 0;
     if (const char* e = getenv("FY_SCORE_TILE_KB")) { long v = atol(e); if (v >= 16) t.tile_bytes = (int64_t)v << 10; }
@@ -937,7 +941,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
         const int64_t ldm_max = round_up(max_Ic, 256);
         DevBuf<float> M(ctx, (size_t)(max_Ic * ldm_max));
         const int64_t ws = prm.workspace_bytes > 0 ? prm.workspace_bytes : (int64_t)16 << 30;
-        const int max_ch_lds = 16384;   // fp64 accumulators: 128 KiB of the 160 KiB LDS
+        const int max_ch_lds = tune.cooc_max_ch;   // fp64 accumulators: 128 KiB of the 160 KiB LDS
         FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cooc_rm2), hipFuncAttributeMaxDynamicSharedMemorySize, max_ch_lds * 8));
         FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_score_hot<true>), hipFuncAttributeMaxDynamicSharedMemorySize, SCORE_HOT_ROWS * 1024));
         FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_score_hot<false>), hipFuncAttributeMaxDynamicSharedMemorySize, SCORE_HOT_ROWS * 1024));
@@ -963,7 +967,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                         csr_x.get(), pbase, sbase, Ic, CH, nch, 0, Ic};
             MEpilogue ME{M.get(), ldm, p_rank.get() + pbase, b_rank.get() + pbase, (1.0 - lambda) * (1.0 - lambda), lambda * (1.0 - lambda),
                          pack24 ? 1 : 0};
-            const int block = (CH * 8 > 48 * 1024) ? 1024 : 256;
+            const int block = tune.cooc_block ? tune.cooc_block : ((CH * 8 > 48 * 1024) ? 1024 : 256);
             const size_t sp = t_cooc.begin();
             k_cooc_rm2<<<Ic * nch, block, (size_t)CH * 8, st>>>(CA, ME);
             FY_KERNEL_CHECK();
