@@ -67,11 +67,16 @@ def main():
     P = importlib.import_module("filmyou-core_amd")
     S = importlib.import_module("filmyou-core_amd.synth")
     par = importlib.import_module("filmyou-core_amd.parallel")
-    rank, local_rank, world = par.init_distributed()
+    # FY_BENCH_REHEARSAL=1: several ranks share GPU 0 over gloo -- only to rehearse the multi-rank control flow on a
+    # one-GPU box (RCCL refuses two ranks on one device); never used for reported numbers
+    rehearsal = os.environ.get("FY_BENCH_REHEARSAL") == "1"
+    rank, local_rank, world = par.init_distributed(backend="gloo" if rehearsal else None)
     if world != a.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     top_n = a.top_n if a.top_n is not None else (100 if a.shape == "netflix" else 50)
@@ -109,6 +114,15 @@ def main():
         if world > 1:
             dist.barrier()
 
+    def reduce_(t, op):
+        if world > 1:
+            if rehearsal:      # gloo: reduce on the host
+                h = t.cpu()
+                dist.all_reduce(h, op=op)
+                t.copy_(h)
+            else:
+                dist.all_reduce(t, op=op)
+
     for _ in range(a.warmup):
         step()
     fence()
@@ -119,9 +133,8 @@ def main():
     tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     recs = torch.tensor([float(stats[-1]["recs"]), float(stats[-1]["log_terms"]), float(stats[-1]["users_scored"])],
                         dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dist.all_reduce(recs, op=dist.ReduceOp.SUM)
+    reduce_(tt, dist.ReduceOp.MAX)
+    reduce_(recs, dist.ReduceOp.SUM)
     elapsed = float(tt.item())
     total_recs, total_terms, total_users = (float(x) for x in recs.tolist())
     ms_per_step = 1e3 * elapsed / a.steps
@@ -177,7 +190,7 @@ def main():
             pp = torch.tensor([float(sst["unordered_pairs"]), dt], dtype=torch.float64, device=dev)
             if world > 1:
                 tmax = pp[1:2].clone()
-                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                reduce_(tmax, dist.ReduceOp.MAX)
                 dt = float(tmax.item())
             out["itemsim"] = {"metric": "item-sim pairs/sec (cosine, top-100)", "value": float(pp[0].item()) / dt,
                               "unit": "pairs/s", "seconds": dt, "ms_kernel_rank0": sst["ms_cooc"],

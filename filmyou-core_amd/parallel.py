@@ -36,8 +36,12 @@ def all_gather_stats(local):
     if world == 1:
         return local.clone()
     out = torch.empty(world * local.numel(), dtype=local.dtype, device=local.device)
-    if local.is_cuda:
-        dist.all_gather_into_tensor(out, local.contiguous())
+    if local.is_cuda and dist.get_backend() == "nccl":
+        dist.all_gather_into_tensor(out, local.contiguous())       # RCCL over xGMI
+    elif local.is_cuda:                                              # gloo rehearsal on a one-GPU box: stage through the host
+        host = torch.empty(world * local.numel(), dtype=local.dtype)
+        dist.all_gather(list(host.view(world, -1).unbind(0)), local.cpu().contiguous())
+        out.copy_(host)
     else:
         dist.all_gather(list(out.view(world, -1).unbind(0)), local.contiguous())
     return out
