@@ -100,8 +100,10 @@ __device__ __forceinline__ void cooc_accumulate_row(const CoocArgs& A, int row, 
             // slices longer than one wave: heavy users, who are raters of very many rows -- half of all rater visits at
             // ML-25M shape.  Eight 64-entry segments are loaded before the first atomic so eight round trips overlap
             // (a plain one-segment loop here cost a full memory latency per 64 entries and dominated the kernel: 84 ->
-            // 48 ms).  Queueing the remainders in LDS and walking them with the whole workgroup was tried too and was
-            // slower (104 ms: three barriers per 1024 raters).
+            // 48 ms).  Two re-balancing schemes were tried and were slower: queueing the remainders in LDS and walking them
+            // with the whole workgroup (104 ms: three barriers per 1024 raters), and giving segment s of rater r to wave
+            // (r + s) mod nwaves with every wave walking all raters' metadata (90 ms: 16x the uncoalesced chunk_off
+            // gathers).
 #pragma unroll
             for (int q = 0; q < RS; q++) {
                 for (int fb = 64; fb < L[q]; fb += 512) {   // wave-uniform
