@@ -21,8 +21,9 @@ struct CoocArgs {
     const int32_t* __restrict__ pair_start;
     const int32_t* __restrict__ csc_slot;
     const float* __restrict__ csc_w;
-    // CSR: chunk_off[(slot - slot_base) * (nch + 1) + ch] = first CSR entry of the slot's row with idx >= ch * CH
-    const int32_t* __restrict__ chunk_off;
+    // csc_slice[ch * nq + (e - q0)] = {first CSR entry, length} of the slice of rater e's CSR row that falls into column
+    // chunk ch: precomputed per CSC entry so the row kernel reads it coalesced instead of gathering per-user offsets
+    const int2* __restrict__ csc_slice;
     const int32_t* __restrict__ csr_idx;
     const float* __restrict__ csr_w;
     int32_t pbase;      // pcstart[c]
@@ -32,6 +33,8 @@ struct CoocArgs {
     int32_t nch;        // chunks per row
     int32_t row0;       // first row of this launch
     int32_t nrows;      // rows in this launch
+    int32_t q0;         // first CSC entry of the cluster
+    int32_t nq;         // CSC entries of the cluster
 };
 
 // Accumulates chunk `ch` of row `row` into the workgroup's dynamic LDS (fy_cooc_acc[0..CH), zeroed by the caller; all
@@ -54,7 +57,6 @@ __device__ __forceinline__ void cooc_accumulate_row(const CoocArgs& A, int row, 
     const int pair = A.rank_pair[A.pbase + row];
     const int e0 = A.pair_start[pair], e1 = A.pair_start[pair + 1];
     const int c0 = ch * A.CH;
-    const int stride = A.nch + 1;
     const int32_t* __restrict__ csr_idx = A.csr_idx;
     const float* __restrict__ csr_w = A.csr_w;
     // Rater (step s, slot q) of this wave = e0 + ((s * nwaves + wave) * RS + q): consecutive groups of RS raters go to
@@ -68,11 +70,10 @@ __device__ __forceinline__ void cooc_accumulate_row(const CoocArgs& A, int row, 
         int f0 = 0, len = 0;
         float w = 0.0f;
         if (e < e1) {
-            const int v = A.csc_slot[e] - A.slot_base;
             w = A.csc_w[e];
-            const int32_t* co = A.chunk_off + (int64_t)v * stride + ch;
-            f0 = co[0];
-            len = co[1] - f0;
+            const int2 sl = A.csc_slice[(int64_t)ch * A.nq + (e - A.q0)];
+            f0 = sl.x;
+            len = sl.y;
         }
         const unsigned long long nonempty = __ballot(len > 0);
         for (int s = 0; s < STEPS; s++) {   // wave-uniform
@@ -123,6 +124,10 @@ __device__ __forceinline__ void cooc_accumulate_row(const CoocArgs& A, int row, 
         }
     }
 }
+
+// csc_slice table of one cluster from its chunk_off table (one thread per (chunk, CSC entry))
+void build_csc_slices(Context* ctx, const int32_t* csc_slot, const int32_t* chunk_off, int32_t slot_base, int32_t q0, int32_t nq,
+                      int32_t nch, int2* csc_slice);
 
 // chunk_off table for one cluster: one thread per (slot, boundary)
 void build_chunk_offsets(Context* ctx, const int32_t* rowptr, const int32_t* csr_idx, int32_t slot_base, int32_t n_slots,

@@ -264,6 +264,10 @@ __global__ void k_slot_degrees(int32_t nU, const int32_t* __restrict__ slot2du, 
     }
 }
 
+__global__ void k_gather_i32(int32_t n, const int32_t* __restrict__ src, const int32_t* __restrict__ index, int32_t* __restrict__ dst) {
+    for (int32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) dst[t] = src[index[t]];
+}
+
 // ---------------------------------------------------------------- build
 void build_structure(Context* ctx, const fy_ratings* R, int32_t K, int64_t n_map, const int32_t* map_user,
                      const int32_t* map_cluster, const int32_t* cluster_count, bool keep_nonpositive, Prepared& P) {
@@ -295,6 +299,7 @@ void build_structure(Context* ctx, const fy_ratings* R, int32_t K, int64_t n_map
         P.csize.assign(K, 0);
         P.ucstart.assign(K + 1, 0);
         P.pcstart.assign(K + 1, 0);
+        P.cluster_q.assign(K + 1, 0);
         return;
     }
     k1a.release();
@@ -400,6 +405,14 @@ void build_structure(Context* ctx, const fy_ratings* R, int32_t K, int64_t n_map
     for (int c = 0; c < K; c++) P.pcstart[c + 1] = P.pcstart[c] + hpc[c];
     P.d_pcstart.alloc(ctx, (size_t)K + 1);
     h2d(ctx, P.d_pcstart.get(), P.pcstart.data(), (size_t)K + 1);
+    {   // first CSC entry of every cluster = pair_start at the cluster's first pair (pairs are cluster-major)
+        DevBuf<int32_t> dq(ctx, (size_t)K + 1);
+        k_gather_i32<<<grid_for(K + 1), 256, 0, st>>>(K + 1, P.pair_start.get(), P.d_pcstart.get(), dq.get());
+        FY_KERNEL_CHECK();
+        P.cluster_q.resize((size_t)K + 1);
+        d2h(ctx, P.cluster_q.data(), dq.get(), (size_t)K + 1);
+        sync(ctx);
+    }
 
     // ---- dense item index (ascending raw id)
     P.pair_di.alloc(ctx, nP);

@@ -28,6 +28,7 @@ struct Prepared {
     DevBuf<int32_t> iid;
     // cluster tables (host + device)
     std::vector<int32_t> csize, ucstart, pcstart;   // K, K+1, K+1
+    std::vector<int32_t> cluster_q;                  // K+1: first CSC entry of every cluster
     DevBuf<int32_t> d_ucstart, d_pcstart, d_csize;
     // pairs, (cluster, item) ascending
     DevBuf<int32_t> pair_cluster, pair_di, pair_start /* nP+1 */, pair_rank, rank_pair;

@@ -181,6 +181,23 @@ void build_chunk_offsets(Context* ctx, const int32_t* rowptr, const int32_t* csr
     FY_KERNEL_CHECK();
 }
 
+__global__ void k_csc_slices(const int32_t* __restrict__ csc_slot, const int32_t* __restrict__ chunk_off, int32_t slot_base,
+                             int32_t q0, int32_t nq, int32_t nch, int2* __restrict__ out) {
+    const int64_t total = (int64_t)nq * nch;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t ch = (int32_t)(t / nq), q = (int32_t)(t % nq);
+        const int32_t* co = chunk_off + (int64_t)(csc_slot[q0 + q] - slot_base) * (nch + 1) + ch;
+        out[t] = make_int2(co[0], co[1] - co[0]);
+    }
+}
+
+void build_csc_slices(Context* ctx, const int32_t* csc_slot, const int32_t* chunk_off, int32_t slot_base, int32_t q0, int32_t nq,
+                      int32_t nch, int2* csc_slice) {
+    if ((int64_t)nq * nch == 0) return;
+    k_csc_slices<<<grid_for((int64_t)nq * nch), 256, 0, ctx->stream>>>(csc_slot, chunk_off, slot_base, q0, nq, nch, csc_slice);
+    FY_KERNEL_CHECK();
+}
+
 // ================================================================ M build: co-rating row kernel + RM2 epilogue
 struct MEpilogue {
     float* __restrict__ M;
@@ -963,8 +980,11 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             pick_chunks(Ic, max_ch_lds, CH, nch);
             DevBuf<int32_t> chunk_off(ctx, (size_t)Uc * (nch + 1));
             build_chunk_offsets(ctx, P.rowptr.get(), P.csr_idx.get(), sbase, Uc, CH, nch, chunk_off.get());
-            CoocArgs CA{P.rank_pair.get(), P.pair_start.get(), P.csc_slot.get(), csc_x.get(), chunk_off.get(), P.csr_idx.get(),
-                        csr_x.get(), pbase, sbase, Ic, CH, nch, 0, Ic};
+            const int32_t q0 = P.cluster_q[c], nq = P.cluster_q[c + 1] - q0;
+            DevBuf<int2> csc_slice(ctx, (size_t)nq * nch);
+            build_csc_slices(ctx, P.csc_slot.get(), chunk_off.get(), sbase, q0, nq, nch, csc_slice.get());
+            CoocArgs CA{P.rank_pair.get(), P.pair_start.get(), P.csc_slot.get(), csc_x.get(), csc_slice.get(), P.csr_idx.get(),
+                        csr_x.get(), pbase, sbase, Ic, CH, nch, 0, Ic, q0, nq};
             MEpilogue ME{M.get(), ldm, p_rank.get() + pbase, b_rank.get() + pbase, (1.0 - lambda) * (1.0 - lambda), lambda * (1.0 - lambda),
                          pack24 ? 1 : 0};
             const int block = tune.cooc_block ? tune.cooc_block : ((CH * 8 > 48 * 1024) ? 1024 : 256);
