@@ -71,6 +71,7 @@ void fy_context_destroy(fy_context* c) {
         c->c.trim();
         for (auto& kv : c->c.capacity) (void)hipFree(kv.first);   // blocks still held by live objects: caller error, reclaimed anyway
         c->c.capacity.clear();
+        for (hipStream_t x : c->c.aux) { (void)hipStreamSynchronize(x); (void)hipStreamDestroy(x); }
         (void)hipStreamDestroy(c->c.stream);
     }
     delete c;

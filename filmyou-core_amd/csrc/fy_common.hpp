@@ -52,6 +52,7 @@ struct Context {
     int num_cus = 256;
     size_t lds_per_block = 160 * 1024;
     size_t total_mem = 0;
+    std::vector<hipStream_t> aux;               // extra streams ("lanes") a multi-cluster job overlaps its clusters on
     std::multimap<size_t, void*> free_blocks;   // capacity -> block
     std::map<void*, size_t> capacity;            // every block ever handed out
 
@@ -160,15 +161,16 @@ struct EventTimer {
     ~EventTimer() {
         for (auto& s : spans) { (void)hipEventDestroy(s.first); (void)hipEventDestroy(s.second); }
     }
-    size_t begin() {
+    // a span lives on ONE stream (default: the context's); spans of different lanes may overlap in time
+    size_t begin(hipStream_t st = nullptr) {
         hipEvent_t a, b;
         FY_HIP(hipEventCreate(&a));
         FY_HIP(hipEventCreate(&b));
-        FY_HIP(hipEventRecord(a, ctx->stream));
+        FY_HIP(hipEventRecord(a, st ? st : ctx->stream));
         spans.emplace_back(a, b);
         return spans.size() - 1;
     }
-    void end(size_t i) { FY_HIP(hipEventRecord(spans[i].second, ctx->stream)); }
+    void end(size_t i, hipStream_t st = nullptr) { FY_HIP(hipEventRecord(spans[i].second, st ? st : ctx->stream)); }
     // total milliseconds over all spans; the stream must have been synchronised
     double total_ms() {
         double t = 0;

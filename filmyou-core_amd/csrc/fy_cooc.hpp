@@ -127,11 +127,11 @@ __device__ __forceinline__ void cooc_accumulate_row(const CoocArgs& A, int row, 
 
 // csc_slice table of one cluster from its chunk_off table (one thread per (chunk, CSC entry))
 void build_csc_slices(Context* ctx, const int32_t* csc_slot, const int32_t* chunk_off, int32_t slot_base, int32_t q0, int32_t nq,
-                      int32_t nch, int2* csc_slice);
+                      int32_t nch, int2* csc_slice, hipStream_t st = nullptr);
 
 // chunk_off table for one cluster: one thread per (slot, boundary)
 void build_chunk_offsets(Context* ctx, const int32_t* rowptr, const int32_t* csr_idx, int32_t slot_base, int32_t n_slots,
-                         int32_t CH, int32_t nch, int32_t* chunk_off);
+                         int32_t CH, int32_t nch, int32_t* chunk_off, hipStream_t st = nullptr);
 
 // picks the chunk width for a cluster with Ic items: whole row when it fits the LDS budget
 inline void pick_chunks(int32_t Ic, int32_t max_ch, int32_t& CH, int32_t& nch) {

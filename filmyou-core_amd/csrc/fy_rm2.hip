@@ -174,10 +174,10 @@ __global__ void k_chunk_offsets(const int32_t* __restrict__ rowptr, const int32_
 }
 
 void build_chunk_offsets(Context* ctx, const int32_t* rowptr, const int32_t* csr_idx, int32_t slot_base, int32_t n_slots,
-                         int32_t CH, int32_t nch, int32_t* chunk_off) {
+                         int32_t CH, int32_t nch, int32_t* chunk_off, hipStream_t st) {
     const int64_t total = (int64_t)n_slots * (nch + 1);
     if (total == 0) return;
-    k_chunk_offsets<<<grid_for(total), 256, 0, ctx->stream>>>(rowptr, csr_idx, slot_base, n_slots, CH, nch, chunk_off);
+    k_chunk_offsets<<<grid_for(total), 256, 0, st ? st : ctx->stream>>>(rowptr, csr_idx, slot_base, n_slots, CH, nch, chunk_off);
     FY_KERNEL_CHECK();
 }
 
@@ -192,9 +192,9 @@ __global__ void k_csc_slices(const int32_t* __restrict__ csc_slot, const int32_t
 }
 
 void build_csc_slices(Context* ctx, const int32_t* csc_slot, const int32_t* chunk_off, int32_t slot_base, int32_t q0, int32_t nq,
-                      int32_t nch, int2* csc_slice) {
+                      int32_t nch, int2* csc_slice, hipStream_t st) {
     if ((int64_t)nq * nch == 0) return;
-    k_csc_slices<<<grid_for((int64_t)nq * nch), 256, 0, ctx->stream>>>(csc_slot, chunk_off, slot_base, q0, nq, nch, csc_slice);
+    k_csc_slices<<<grid_for((int64_t)nq * nch), 256, 0, st ? st : ctx->stream>>>(csc_slot, chunk_off, slot_base, q0, nq, nch, csc_slice);
     FY_KERNEL_CHECK();
 }
 
@@ -793,6 +793,7 @@ struct ScoreTune {
     int pack24 = 1;                    // M rows as 24-bit floats (3 bytes per element): -25 % of the dominant traffic
     int pack24_min_items = 4096;       // ... for clusters with at least this many items
     int batch = 8;                     // row-segment loads in flight per wave
+    int lanes = 4;                     // HIP streams the clusters of one job are spread over
     int cooc_block = 0;                // test hook: force the row kernel's workgroup size
     int cooc_max_ch = 16384;           // LDS accumulators of the row kernel (test hook: smaller forces column chunks)
     int hot_lds = 0;                   // k_score_hot: the 128 most popular rows of a chunk stay in LDS (slower: 16 waves/CU)
@@ -806,6 +807,7 @@ static ScoreTune score_tune() {
     if (const char* e = getenv("FY_M24_MIN_ITEMS")) t.pack24_min_items = atoi(e);
     if (const char* e = getenv("FY_HOT_LDS")) t.hot_lds = atoi(e) != 0;
     if (const char* e = getenv("FY_SCORE_BATCH")) t.batch = atoi(e);
+    if (const char* e = getenv("FY_LANES")) { int v = atoi(e); if (v >= 1 && v <= 8) t.lanes = v; }
     if (const char* e = getenv("FY_COOC_BLOCK")) { int v = atoi(e); if (v == 256 || v == 512 || v == 1024) t.cooc_block = v; }
     if (const char* e = getenv("FY_COOC_MAX_CH")) { int v = atoi(e); if (v >= 64 && v <= 16384) t.cooc_max_ch = v; }
     if (const char* e = getenv("FY_HOT_MIN_ITEMS")) t.hot_min_items = atoi(e);
@@ -955,81 +957,144 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
     if (eff_top > TOPN_MAX)
         FY_FAIL(FY_ERR_UNSUPPORTED, "min(numberOfRecommendations, items per cluster) = %d exceeds the top-N kernel limit %d", eff_top, TOPN_MAX);
     if (n_recs > 0 && max_Ic > 0) {
-        const int64_t ldm_max = round_up(max_Ic, 256);
-        DevBuf<float> M(ctx, (size_t)(max_Ic * ldm_max));
         const int64_t ws = prm.workspace_bytes > 0 ? prm.workspace_bytes : (int64_t)16 << 30;
         const int max_ch_lds = tune.cooc_max_ch;   // fp64 accumulators: 128 KiB of the 160 KiB LDS
         FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cooc_rm2), hipFuncAttributeMaxDynamicSharedMemorySize, max_ch_lds * 8));
         FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_score_hot<true>), hipFuncAttributeMaxDynamicSharedMemorySize, SCORE_HOT_ROWS * 1024));
         FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_score_hot<false>), hipFuncAttributeMaxDynamicSharedMemorySize, SCORE_HOT_ROWS * 1024));
 
+        // ---- per-cluster plan; the clusters are spread over up to four "lanes" (HIP streams with their own M / score
+        // scratch): the tail of one cluster's launches -- its heaviest user sits on a single wave for milliseconds, and
+        // most of its M rows have a handful of raters -- overlaps the next clusters' work instead of idling the chip.
+        struct Plan {
+            int c;
+            int32_t Uc, sbase, pbase, Ic, a, b, CH, nch, rb_rows, nrb, q0, nq;
+            int64_t ldm, B;
+            bool pack24, use_hot;
+        };
+        std::vector<Plan> plans;
+        const int VEC = tune.vec;
         for (int c = 0; c < K; c++) {
-            const int32_t Uc = P.csize[c];
-            if (Uc == 0) continue;
-            const int32_t sbase = P.ucstart[c], pbase = P.pcstart[c];
-            const int32_t Ic = P.pcstart[c + 1] - pbase;
-            const int32_t a = std::max(lo, sbase), b = std::min(hi, sbase + Uc);
-            if (a >= b || Ic == 0) continue;
-            const int64_t ldm = round_up(Ic, 256);
+            Plan p{};
+            p.c = c;
+            p.Uc = P.csize[c];
+            if (p.Uc == 0) continue;
+            p.sbase = P.ucstart[c];
+            p.pbase = P.pcstart[c];
+            p.Ic = P.pcstart[c + 1] - p.pbase;
+            p.a = std::max(lo, p.sbase);
+            p.b = std::min(hi, p.sbase + p.Uc);
+            if (p.a >= p.b || p.Ic == 0) continue;
+            p.ldm = round_up(p.Ic, 256);
             // 24-bit rows only where bandwidth matters: small clusters keep exact fp32 rows (their scores are small, and the
             // reference's own fixture is asserted with an ABSOLUTE 1e-4, T/util/HadoopIntegrationTest.java:53)
-            const bool pack24 = pack24_allowed && Ic >= tune.pack24_min_items;
+            p.pack24 = pack24_allowed && p.Ic >= tune.pack24_min_items;
+            pick_chunks(p.Ic, max_ch_lds, p.CH, p.nch);
+            p.q0 = P.cluster_q[c];
+            p.nq = P.cluster_q[c + 1] - p.q0;
+            // row blocks: tile = rb_rows x (256 * VEC) bytes <= tune.tile_bytes; one block when the cluster is small
+            p.rb_rows = (int32_t)std::max<int64_t>(64, tune.tile_bytes / (256 * VEC));
+            p.nrb = (int32_t)ceil_div(p.Ic, p.rb_rows);
+            if (p.nrb <= 1) { p.nrb = 1; p.rb_rows = p.Ic; }
+            p.use_hot = tune.hot_lds && VEC == 4 && p.nrb == 1 && p.Ic >= tune.hot_min_items;
+            plans.push_back(p);
+        }
+        const int NS = (int)std::min<size_t>(plans.size() > 1 ? (size_t)tune.lanes : 1, plans.size());
+        struct Lane {
+            hipStream_t st;
+            DevBuf<float> M, S;
+            DevBuf<int32_t> chunk_off, rb_off, hot_off, overflow, any_overflow;
+            DevBuf<int2> csc_slice;
+        };
+        std::vector<Lane> lanes((size_t)NS);
+        {
+            size_t m_el = 1, s_el = 1, co_el = 1, rb_el = 1, ho_el = 1, ov_el = 1, sl_el = 1;
+            for (auto& p : plans) {
+                p.B = std::min<int64_t>(std::max<int64_t>(1, (ws / NS) / (p.ldm * 4)), p.b - p.a);
+                m_el = std::max(m_el, (size_t)(p.Ic * p.ldm));
+                s_el = std::max(s_el, (size_t)(p.B * p.ldm));
+                co_el = std::max(co_el, (size_t)p.Uc * (p.nch + 1));
+                rb_el = std::max(rb_el, (size_t)p.Uc * (p.nrb + 1));
+                if (p.use_hot) ho_el = std::max(ho_el, (size_t)p.Uc * 3);
+                ov_el = std::max(ov_el, (size_t)p.B);
+                sl_el = std::max(sl_el, (size_t)p.nq * p.nch);
+            }
+            if (NS > 1 && ctx->aux.size() < (size_t)NS) {
+                while (ctx->aux.size() < (size_t)NS) {
+                    hipStream_t x;
+                    FY_HIP(hipStreamCreateWithFlags(&x, hipStreamNonBlocking));
+                    ctx->aux.push_back(x);
+                }
+            }
+            for (int l = 0; l < NS; l++) {
+                Lane& L = lanes[l];
+                L.st = NS > 1 ? ctx->aux[l] : st;
+                L.M.alloc(ctx, m_el);
+                L.S.alloc(ctx, s_el);
+                L.chunk_off.alloc(ctx, co_el);
+                L.rb_off.alloc(ctx, rb_el);
+                L.hot_off.alloc(ctx, ho_el);
+                L.overflow.alloc(ctx, ov_el);
+                L.any_overflow.alloc(ctx, 1);
+                L.csc_slice.alloc(ctx, sl_el);
+            }
+        }
+        hipEvent_t fork = nullptr;
+        if (NS > 1) {   // the lanes start after everything queued on the main stream so far
+            FY_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+            FY_HIP(hipEventRecord(fork, st));
+            for (int l = 0; l < NS; l++) FY_HIP(hipStreamWaitEvent(lanes[l].st, fork, 0));
+        }
+
+        for (size_t pi = 0; pi < plans.size(); pi++) {
+            const Plan& p = plans[pi];
+            Lane& L = lanes[pi % NS];
+            hipStream_t ls = L.st;
+            const int c = p.c;
+            const int32_t Uc = p.Uc, sbase = p.sbase, pbase = p.pbase, Ic = p.Ic, a = p.a, b = p.b, CH = p.CH, nch = p.nch;
+            const int64_t ldm = p.ldm;
+            const bool pack24 = p.pack24;
 
             // -- M build
-            int32_t CH, nch;
-            pick_chunks(Ic, max_ch_lds, CH, nch);
-            DevBuf<int32_t> chunk_off(ctx, (size_t)Uc * (nch + 1));
-            build_chunk_offsets(ctx, P.rowptr.get(), P.csr_idx.get(), sbase, Uc, CH, nch, chunk_off.get());
-            const int32_t q0 = P.cluster_q[c], nq = P.cluster_q[c + 1] - q0;
-            DevBuf<int2> csc_slice(ctx, (size_t)nq * nch);
-            build_csc_slices(ctx, P.csc_slot.get(), chunk_off.get(), sbase, q0, nq, nch, csc_slice.get());
-            CoocArgs CA{P.rank_pair.get(), P.pair_start.get(), P.csc_slot.get(), csc_x.get(), csc_slice.get(), P.csr_idx.get(),
-                        csr_x.get(), pbase, sbase, Ic, CH, nch, 0, Ic, q0, nq};
-            MEpilogue ME{M.get(), ldm, p_rank.get() + pbase, b_rank.get() + pbase, (1.0 - lambda) * (1.0 - lambda), lambda * (1.0 - lambda),
+            build_chunk_offsets(ctx, P.rowptr.get(), P.csr_idx.get(), sbase, Uc, CH, nch, L.chunk_off.get(), ls);
+            build_csc_slices(ctx, P.csc_slot.get(), L.chunk_off.get(), sbase, p.q0, p.nq, nch, L.csc_slice.get(), ls);
+            CoocArgs CA{P.rank_pair.get(), P.pair_start.get(), P.csc_slot.get(), csc_x.get(), L.csc_slice.get(), P.csr_idx.get(),
+                        csr_x.get(), pbase, sbase, Ic, CH, nch, 0, Ic, p.q0, p.nq};
+            MEpilogue ME{L.M.get(), ldm, p_rank.get() + pbase, b_rank.get() + pbase, (1.0 - lambda) * (1.0 - lambda), lambda * (1.0 - lambda),
                          pack24 ? 1 : 0};
             const int block = tune.cooc_block ? tune.cooc_block : ((CH * 8 > 48 * 1024) ? 1024 : 256);
-            const size_t sp = t_cooc.begin();
-            k_cooc_rm2<<<Ic * nch, block, (size_t)CH * 8, st>>>(CA, ME);
+            const size_t sp = t_cooc.begin(ls);
+            k_cooc_rm2<<<Ic * nch, block, (size_t)CH * 8, ls>>>(CA, ME);
             FY_KERNEL_CHECK();
-            t_cooc.end(sp);
+            t_cooc.end(sp, ls);
             R->st.cooc_launches++;
 
             // -- scoring + top-N in user batches that fit the score scratch
-            const int64_t ldS = ldm;
-            int64_t B = std::max<int64_t>(1, ws / (ldS * 4));
-            B = std::min<int64_t>(B, b - a);
-            DevBuf<float> S(ctx, (size_t)(B * ldS));
-            DevBuf<int32_t> overflow(ctx, (size_t)B), any_overflow(ctx, 1);
-            const int VEC = tune.vec;
+            const int64_t ldS = ldm, B = p.B;
             const int n_chunks = (int)ceil_div(Ic, 64 * VEC);
-            // row blocks: tile = rb_rows x (256 * VEC) bytes <= tune.tile_bytes; one block when the cluster is small
-            int32_t rb_rows = (int32_t)std::max<int64_t>(64, tune.tile_bytes / (256 * VEC));
-            int32_t nrb = (int32_t)ceil_div(Ic, rb_rows);
-            if (nrb <= 1) { nrb = 1; rb_rows = Ic; }
-            DevBuf<int32_t> rb_off(ctx, (size_t)Uc * (nrb + 1));
-            build_chunk_offsets(ctx, P.rowptr.get(), P.csr_idx.get(), sbase, Uc, rb_rows, nrb, rb_off.get());
-            const bool use_hot = tune.hot_lds && VEC == 4 && nrb == 1 && Ic >= tune.hot_min_items;
-            DevBuf<int32_t> hot_off(ctx, use_hot ? (size_t)Uc * 3 : 1);
-            if (use_hot) build_chunk_offsets(ctx, P.rowptr.get(), P.csr_idx.get(), sbase, Uc, SCORE_HOT_ROWS, 2, hot_off.get());
+            const int32_t nrb = p.nrb;
+            build_chunk_offsets(ctx, P.rowptr.get(), P.csr_idx.get(), sbase, Uc, p.rb_rows, nrb, L.rb_off.get(), ls);
+            const bool use_hot = p.use_hot;
+            if (use_hot) build_chunk_offsets(ctx, P.rowptr.get(), P.csr_idx.get(), sbase, Uc, SCORE_HOT_ROWS, 2, L.hot_off.get(), ls);
             for (int32_t s0 = a; s0 < b; s0 += (int32_t)B) {
                 const int32_t nb = (int32_t)std::min<int64_t>(B, b - s0);
                 int n_slices = (int)std::max<int64_t>(1, std::min<int64_t>(1024, ceil_div(nb, 4 * 16)));
-                const size_t ss = t_score.begin();
+                const size_t ss = t_score.begin(ls);
                 if (use_hot) {
                     // one 16-wave workgroup per CU (128 KiB of LDS); every wave gets >= 8 users to amortise the tile load
                     const int hs = (int)std::max<int64_t>(1, std::min<int64_t>(256, ceil_div(nb, 16 * 8)));
-                    ScoreArgs SA{M.get(), ldm, Ic, a_rank.get() + pbase, hot_off.get(), P.csr_idx.get(), csr_e.get(), pvpi.get(),
-                                 n_out.get(), lo, sbase, s0, nb, S.get(), ldS, hs, 0, 1};
+                    ScoreArgs SA{L.M.get(), ldm, Ic, a_rank.get() + pbase, L.hot_off.get(), P.csr_idx.get(), csr_e.get(), pvpi.get(),
+                                 n_out.get(), lo, sbase, s0, nb, L.S.get(), ldS, hs, 0, 1};
                     const size_t lds = (size_t)SCORE_HOT_ROWS * 1024;
-                    if (pack24) k_score_hot<true><<<(int)(ldm / 256) * hs, 1024, lds, st>>>(SA.M, SA.a_rank, SA.rb_off, SA.csr_idx, SA.csr_e, SA.pvpi, SA.n_out, SA.S, SA);
-                    else k_score_hot<false><<<(int)(ldm / 256) * hs, 1024, lds, st>>>(SA.M, SA.a_rank, SA.rb_off, SA.csr_idx, SA.csr_e, SA.pvpi, SA.n_out, SA.S, SA);
+                    if (pack24) k_score_hot<true><<<(int)(ldm / 256) * hs, 1024, lds, ls>>>(SA.M, SA.a_rank, SA.rb_off, SA.csr_idx, SA.csr_e, SA.pvpi, SA.n_out, SA.S, SA);
+                    else k_score_hot<false><<<(int)(ldm / 256) * hs, 1024, lds, ls>>>(SA.M, SA.a_rank, SA.rb_off, SA.csr_idx, SA.csr_e, SA.pvpi, SA.n_out, SA.S, SA);
                     FY_KERNEL_CHECK();
                     R->st.score_launches++;
                 }
                 for (int32_t rb = 0; rb < (use_hot ? 0 : nrb); rb++) {
-                    ScoreArgs SA{M.get(), ldm, Ic, a_rank.get() + pbase, rb_off.get(), P.csr_idx.get(), csr_e.get(), pvpi.get(),
-                                 n_out.get(), lo, sbase, s0, nb, S.get(), ldS, n_slices, rb, nrb};
-#define FY_LAUNCH_SCORE(V_, P_, B_) k_score<V_, P_, B_><<<n_chunks * n_slices, 256, 0, st>>>(SA.M, SA.a_rank, SA.rb_off, SA.csr_idx, SA.csr_e, SA.pvpi, SA.n_out, SA.S, SA)
+                    ScoreArgs SA{L.M.get(), ldm, Ic, a_rank.get() + pbase, L.rb_off.get(), P.csr_idx.get(), csr_e.get(), pvpi.get(),
+                                 n_out.get(), lo, sbase, s0, nb, L.S.get(), ldS, n_slices, rb, nrb};
+#define FY_LAUNCH_SCORE(V_, P_, B_) k_score<V_, P_, B_><<<n_chunks * n_slices, 256, 0, ls>>>(SA.M, SA.a_rank, SA.rb_off, SA.csr_idx, SA.csr_e, SA.pvpi, SA.n_out, SA.S, SA)
                     if (pack24 && tune.batch == 16) FY_LAUNCH_SCORE(4, true, 16);
                     else if (pack24 && tune.batch == 12) FY_LAUNCH_SCORE(4, true, 12);
                     else if (pack24) FY_LAUNCH_SCORE(4, true, 8);
@@ -1039,17 +1104,29 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                     FY_KERNEL_CHECK();
                     R->st.score_launches++;
                 }
-                t_score.end(ss);
-                TopNArgs TA{S.get(), ldS, Ic, n_out.get(), out_off.get(), P.rank_item_raw.get() + pbase, P.slot2du.get(), P.uid.get(),
+                t_score.end(ss, ls);
+                TopNArgs TA{L.S.get(), ldS, Ic, n_out.get(), out_off.get(), P.rank_item_raw.get() + pbase, P.slot2du.get(), P.uid.get(),
                             lo, s0, c, R->d_key0.get(), R->d_key1.get(), R->d_value.get(), R->d_aux.get()};
-                const size_t tt = t_topn.begin();
-                FY_HIP(hipMemsetAsync(any_overflow.get(), 0, sizeof(int32_t), st));
-                k_topn_fast<<<nb, 256, 0, st>>>(TA, overflow.get(), any_overflow.get(), tune.force_select);
+                const size_t tt = t_topn.begin(ls);
+                FY_HIP(hipMemsetAsync(L.any_overflow.get(), 0, sizeof(int32_t), ls));
+                k_topn_fast<<<nb, 256, 0, ls>>>(TA, L.overflow.get(), L.any_overflow.get(), tune.force_select);
                 FY_KERNEL_CHECK();
-                k_topn_select<<<nb, 256, 0, st>>>(TA, overflow.get(), any_overflow.get());
+                k_topn_select<<<nb, 256, 0, ls>>>(TA, L.overflow.get(), L.any_overflow.get());
                 FY_KERNEL_CHECK();
-                t_topn.end(tt);
+                t_topn.end(tt, ls);
             }
+        }
+        if (NS > 1) {   // join: the main stream continues after every lane has drained
+            for (int l = 0; l < NS; l++) {
+                hipEvent_t done;
+                FY_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+                FY_HIP(hipEventRecord(done, lanes[l].st));
+                FY_HIP(hipStreamWaitEvent(st, done, 0));
+                FY_HIP(hipEventDestroy(done));
+            }
+            FY_HIP(hipEventDestroy(fork));
+            // the lanes' buffers go back to the allocator only after the join point has been reached
+            FY_HIP(hipStreamSynchronize(st));
         }
     }
     // rm2/userSum and rm2/itemColl stay in HBM until somebody asks for them
