@@ -12,8 +12,8 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libfilmyou_hip.so")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include", "filmyou.h")
-SOURCES = ["fy_api.hip", "fy_prep.hip", "fy_rm2.hip", "fy_itemsim.hip"]
-HEADERS = ["fy_common.hpp", "fy_prep.hpp", "fy_cooc.hpp", "fy_rm2.hpp"]
+SOURCES = ["fy_api.hip", "fy_prep.hip", "fy_rm2.hip", "fy_itemsim.hip", "fy_itemcf.hip"]
+HEADERS = ["fy_common.hpp", "fy_prep.hpp", "fy_cooc.hpp", "fy_rm2.hpp"]  # fy_itemcf.hip uses fy_prep.hpp / fy_rm2.hpp
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics", "-Wall",
                "-Wno-unused-result"]
 
@@ -22,7 +22,7 @@ SYMBOLS = [
     "fy_abi_version", "fy_last_error", "fy_context_create", "fy_context_destroy", "fy_context_synchronize",
     "fy_context_stream", "fy_ratings_create", "fy_ratings_destroy", "fy_ratings_nnz", "fy_rm2_prepare",
     "fy_rm2_partial_stats", "fy_rm2_set_global_stats", "fy_rm2_score", "fy_rm2_job_destroy", "fy_rm2_run",
-    "fy_itemsim_build", "fy_itemsim_run", "fy_result_size", "fy_result_key0", "fy_result_key1", "fy_result_value",
+    "fy_itemsim_build", "fy_itemsim_run", "fy_itemcf_recommend", "fy_result_size", "fy_result_key0", "fy_result_key1", "fy_result_value",
     "fy_result_aux", "fy_result_n_users", "fy_result_user_id", "fy_result_user_sum", "fy_result_n_items",
     "fy_result_item_id", "fy_result_item_coll", "fy_result_total_sum", "fy_result_free", "fy_result_stats",
 ]
@@ -80,6 +80,11 @@ class ItemSimParams(C.Structure):
                 ("flags", C.c_uint32)]
 
 
+class ItemCFParams(C.Structure):
+    _fields_ = [("num_recommendations", C.c_int32), ("max_prefs_per_user", C.c_int32), ("boolean_data", C.c_int32),
+                ("rank", C.c_int32), ("world", C.c_int32), ("flags", C.c_uint32)]
+
+
 class Stats(C.Structure):
     _fields_ = [("nnz", C.c_int64), ("n_users", C.c_int64), ("n_items", C.c_int64),
                 ("n_clusters_nonempty", C.c_int64), ("users_scored", C.c_int64), ("recs", C.c_int64),
@@ -127,6 +132,7 @@ def load():
     L.fy_rm2_run.argtypes = [C.POINTER(RM2Params), i64, vp, vp, vp, i64, vp, vp, vp, pvp]
     L.fy_itemsim_build.argtypes = [vp, C.POINTER(ItemSimParams), vp, pvp]
     L.fy_itemsim_run.argtypes = [C.POINTER(ItemSimParams), i64, vp, vp, vp, pvp]
+    L.fy_itemcf_recommend.argtypes = [vp, C.POINTER(ItemCFParams), vp, vp, pvp]
     for name, rt in (("size", i64), ("key0", vp), ("key1", vp), ("value", vp), ("aux", vp), ("n_users", i64),
                      ("user_id", vp), ("user_sum", vp), ("n_items", i64), ("item_id", vp), ("item_coll", vp),
                      ("total_sum", C.c_double)):

@@ -214,6 +214,18 @@ int fy_itemsim_run(const fy_itemsim_params* p, int64_t nnz, const int32_t* user,
     return rc;
 }
 
+int fy_itemcf_recommend(fy_context* c, const fy_itemcf_params* p, const fy_ratings* r, fy_result* sims, fy_result** out) {
+    if (!out) { set_error("out is NULL"); return FY_ERR_INVALID_ARGUMENT; }
+    *out = nullptr;
+    if (!c || !r || !p || !sims) { set_error("NULL argument"); return FY_ERR_INVALID_ARGUMENT; }
+    if (r->ctx != &c->c || sims->ctx != &c->c) { set_error("ratings / similarities belong to another context"); return FY_ERR_INVALID_ARGUMENT; }
+    if (sims->kind != 1) { set_error("`similarities` is not the result of fy_itemsim_build"); return FY_ERR_INVALID_ARGUMENT; }
+    FY_TRY
+    FY_HIP(hipSetDevice(c->c.device));
+    *out = fy::itemcf_recommend(&c->c, p, r, sims);
+    FY_CATCH
+}
+
 // ---------------------------------------------------------------- results
 static void rows_to_host(fy_result* r) {
     if (r->rows_on_host) return;

@@ -770,6 +770,21 @@ __global__ __launch_bounds__(256) void k_topn_select(TopNArgs A, const int32_t* 
     }
 }
 
+void launch_topn_rows(Context* ctx, hipStream_t st, const float* S, int64_t ldS, int32_t n_cols, int32_t n_rows,
+                      const int32_t* n_out, const int32_t* out_off, const int32_t* rank_item_raw, const int32_t* slot2du,
+                      const int32_t* uid, int32_t slot0, int32_t aux_value, int32_t* out_user, int32_t* out_item,
+                      float* out_score, int32_t* out_aux, int32_t* overflow, int32_t* any_overflow) {
+    if (n_rows <= 0) return;
+    if (!st) st = ctx->stream;
+    // n_out / out_off are indexed by (slot - slot_lo): pass slot_lo = slot0 so that row u reads entry u
+    TopNArgs TA{S, ldS, n_cols, n_out, out_off, rank_item_raw, slot2du, uid, slot0, slot0, aux_value, out_user, out_item, out_score, out_aux};
+    FY_HIP(hipMemsetAsync(any_overflow, 0, sizeof(int32_t), st));
+    k_topn_fast<<<n_rows, 256, 0, st>>>(TA, overflow, any_overflow, 0);
+    FY_KERNEL_CHECK();
+    k_topn_select<<<n_rows, 256, 0, st>>>(TA, overflow, any_overflow);
+    FY_KERNEL_CHECK();
+}
+
 }  // namespace fy
 
 // ================================================================ job orchestration

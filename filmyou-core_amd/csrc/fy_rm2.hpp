@@ -30,4 +30,12 @@ void rm2_set_global_stats(fy_rm2_job*, const double* gathered, int32_t world);
 fy_result* rm2_score(fy_rm2_job*);
 void rm2_job_destroy(fy_rm2_job*);
 fy_result* itemsim_build(Context*, const fy_itemsim_params*, const fy_ratings*);
+fy_result* itemcf_recommend(Context*, const fy_itemcf_params*, const fy_ratings*, fy_result* similarities);
+
+// top-N over rows of a dense score matrix (NaN = not a candidate): k_topn_fast + k_topn_select of fy_rm2.hip.
+// n_out[u] rows are written at out_off[u] for u in [0, n_rows); item ids come from rank_item_raw[column].
+void launch_topn_rows(Context* ctx, hipStream_t st, const float* S, int64_t ldS, int32_t n_cols, int32_t n_rows,
+                      const int32_t* n_out, const int32_t* out_off, const int32_t* rank_item_raw, const int32_t* slot2du,
+                      const int32_t* uid, int32_t slot0, int32_t aux_value, int32_t* out_user, int32_t* out_item,
+                      float* out_score, int32_t* out_aux, int32_t* overflow, int32_t* any_overflow);
 }  // namespace fy

@@ -348,6 +348,61 @@ class PreparedRM2:
             pass
 
 
+class ItemRecommendations(_Result):
+    """Rows of the item-based recommender's output table: (user, item, score), grouped by user, best first."""
+
+    def __init__(self, handle, ctx=None):
+        super().__init__(handle, ctx)
+        self.stats = self._stats()
+        self.size = self._lib.fy_result_size(handle)
+        self._rows = None
+
+    def rows(self):
+        if self._rows is None:
+            L, h, n = self._lib, self._h, self.size
+            self._rows = {"user": _np(L.fy_result_key0(h), n, np.int32), "item": _np(L.fy_result_key1(h), n, np.int32),
+                          "score": _np(L.fy_result_value(h), n, np.float32)}
+        return self._rows
+
+
+class BaselineRecommenderJob:
+    """Item-based CF (M/baselinerecommender/BaselineRecommenderJob.java:179-328) from the similarity phase on: phase 2
+    (RowSimilarityJob), phase 3 (partialMultiply) and phase 4 (aggregateAndRecommend) on the GPU, with the job's
+    option names and defaults (:140-176)."""
+
+    JOB_NAME = "BaselineRecommenderJob"
+
+    def __init__(self, ctx=None):
+        self.ctx = ctx
+
+    def run(self, ratings, numRecommendations=100, maxPrefsPerUser=50, maxSimilaritiesPerItem=100,
+            similarityClassname=SIMILARITY_COSINE, threshold=None, booleanData=False, rank=0, world=1,
+            similarities=None):
+        """Returns (ItemRecommendations, ItemSimilarities).  `similarities` may be passed to skip phase 2
+        (Mahout's --startPhase)."""
+        lib = _native.load()
+        ctx = self.ctx or Context(0)
+        self.ctx = ctx
+        own_ratings = not isinstance(ratings, Ratings)
+        r = Ratings(ctx, *ratings) if own_ratings else ratings
+        try:
+            sims = similarities
+            if sims is None:
+                # every rank needs the whole matrix for phase 3: built with world = 1
+                sims = RowSimilarityJob(ctx).run(r, similarityClassname, maxSimilaritiesPerItem, True, threshold)
+            p = _native.ItemCFParams(int(numRecommendations), int(maxPrefsPerUser), 1 if booleanData else 0, int(rank),
+                                     int(world), 0)
+            res = C.c_void_p()
+            try:
+                _check(lib.fy_itemcf_recommend(ctx._h, C.byref(p), r._h, sims._h, C.byref(res)))
+            except FilmYouError as e:
+                raise RuntimeError("%s failed!: %s" % (self.JOB_NAME, e.message)) from e
+            return ItemRecommendations(res, ctx), sims
+        finally:
+            if own_ratings:
+                r.close()
+
+
 class RowSimilarityJob:
     """Item-item similarity build with the options the reference passes to Mahout's RowSimilarityJob
     (M/baselinerecommender/BaselineRecommenderJob.java:241-253)."""

@@ -123,6 +123,23 @@ int fy_itemsim_build(fy_context*, const fy_itemsim_params*, const fy_ratings*, f
 int fy_itemsim_run(const fy_itemsim_params*, int64_t nnz, const int32_t* user, const int32_t* item,
                    const float* score, fy_result** out);
 
+/* ------------------------------------------------------------------ item-based CF recommendation (phases 3-4)
+ * Replaces the partialMultiply and aggregateAndRecommend jobs of M/baselinerecommender/BaselineRecommenderJob.java:285-328,
+ * 340-393 (reducer M/baselinerecommender/BaselineAggregateAndRecommendReducer.java:97-161, 195-235): prediction(u, i) =
+ * sum_j sim(j, i) pref(u, j) / sum_j |sim(j, i)| over the user's maxPrefsPerUser strongest preferences j whose similarity
+ * row holds i, kept only where at least two preferences contribute; items of those preferences are excluded; the
+ * numRecommendations largest predictions per user.  `similarities` is the result of fy_itemsim_build with world == 1 on
+ * the same context (the whole matrix).  Users are sharded by (rank, world).  Output rows: (user, item, (float) prediction, 0). */
+typedef struct {
+    int32_t num_recommendations;   /* --numRecommendations (default 100, BaselineRecommenderJob.java:66) */
+    int32_t max_prefs_per_user;    /* --maxPrefsPerUser (default 50, :70) */
+    int32_t boolean_data;          /* --booleanData */
+    int32_t rank;
+    int32_t world;
+    uint32_t flags;
+} fy_itemcf_params;
+int fy_itemcf_recommend(fy_context*, const fy_itemcf_params*, const fy_ratings*, fy_result* similarities, fy_result** out);
+
 /* ------------------------------------------------------------------ results
  * Rows as the reference writes them: RM2 (user, item, (float) relevance, cluster) -- RM2HDFSReducer.java:48 /
  * RM2CassandraReducer.java:49-63 -- grouped by user, best first; item-sim (item, other item, similarity) grouped by

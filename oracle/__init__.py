@@ -16,7 +16,7 @@ _lib = None
 
 def build(force=False):
     """Compile liboracle.so with gcc (seconds).  Safe to call repeatedly."""
-    srcs = [os.path.join(_HERE, f) for f in ("rm2_oracle.c", "itemsim_oracle.c", "oracle.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("rm2_oracle.c", "itemsim_oracle.c", "itemcf_oracle.c", "oracle.h", "Makefile")]
     stale = force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
     if stale:
         subprocess.run(["make", "-C", _HERE, "-s"] + (["-B"] if force else []), check=True)
@@ -26,6 +26,10 @@ def build(force=False):
 class _RM2Params(C.Structure):
     _fields_ = [("lambda_", C.c_double), ("number_of_items", C.c_int32), ("number_of_recommendations", C.c_int32),
                 ("filter_users", C.c_int32), ("number_of_clusters", C.c_int32), ("n_threads", C.c_int32)]
+
+
+class _ICFParams(C.Structure):
+    _fields_ = [("num_recommendations", C.c_int32), ("max_prefs_per_user", C.c_int32), ("boolean_data", C.c_int32)]
 
 
 class _ISimParams(C.Structure):
@@ -57,6 +61,13 @@ def _load():
     L.isimo_free.argtypes = [vp]
     for name, rt in (("n", i64), ("item", vp), ("other", vp), ("sim", vp), ("pairs", i64), ("seconds", C.c_double)):
         f = getattr(L, "isimo_" + name)
+        f.argtypes = [vp]
+        f.restype = rt
+    L.icfo_run.argtypes = [C.POINTER(_ICFParams), i64, vp, vp, vp, i64, vp, vp, vp, C.POINTER(vp)]
+    L.icfo_run.restype = C.c_int
+    L.icfo_free.argtypes = [vp]
+    for name, rt in (("n", i64), ("user", vp), ("item", vp), ("score", vp)):
+        f = getattr(L, "icfo_" + name)
         f.argtypes = [vp]
         f.restype = rt
     _lib = L
@@ -132,3 +143,26 @@ def itemsim(user, item, score, *, similarity=COSINE, max_similarities_per_item=1
                 "sim": _arr(L.isimo_sim(h), n, np.float64), "pairs": L.isimo_pairs(h), "seconds": L.isimo_seconds(h)}
     finally:
         L.isimo_free(h)
+
+
+def itemcf(user, item, score, sim_item, sim_other, sim_value, *, num_recommendations=100, max_prefs_per_user=50,
+           boolean_data=False):
+    """Item-based CF recommendation phases on top of a similarity matrix (parity unpinned, see itemcf_oracle.c)."""
+    L = _load()
+    user, item = _i32(user), _i32(item)
+    score = np.ascontiguousarray(score, dtype=np.float32)
+    si, so = _i32(sim_item), _i32(sim_other)
+    sv = np.ascontiguousarray(sim_value, dtype=np.float64)
+    P = _ICFParams(int(num_recommendations), int(max_prefs_per_user), int(bool(boolean_data)))
+    out = C.c_void_p()
+    rc = L.icfo_run(C.byref(P), len(user), user.ctypes.data, item.ctypes.data, score.ctypes.data, len(si), si.ctypes.data,
+                    so.ctypes.data, sv.ctypes.data, C.byref(out))
+    if rc != 0:
+        raise RuntimeError("itemcf oracle failed (%d)" % rc)
+    h = out.value
+    try:
+        n = L.icfo_n(h)
+        return {"user": _arr(L.icfo_user(h), n, np.int32), "item": _arr(L.icfo_item(h), n, np.int32),
+                "score": _arr(L.icfo_score(h), n, np.float32)}
+    finally:
+        L.icfo_free(h)

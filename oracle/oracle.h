@@ -68,6 +68,22 @@ const double* isimo_sim(const isimo_result*);
 int64_t isimo_pairs(const isimo_result*);   /* sum_u n_u (n_u - 1) / 2 */
 double isimo_seconds(const isimo_result*);
 
+/* ---- item-based CF recommendation phases 3-4 (M/baselinerecommender/BaselineAggregateAndRecommendReducer.java) ---- */
+typedef struct {
+    int32_t num_recommendations;   /* --numRecommendations (default 100, BaselineRecommenderJob.java:66) */
+    int32_t max_prefs_per_user;    /* --maxPrefsPerUser: strongest preferences considered per user (default 50, :70) */
+    int32_t boolean_data;          /* --booleanData */
+} icfo_params;
+typedef struct icfo_result icfo_result;
+/* similarity rows (item, other, value) grouped by item, as produced by the similarity build */
+int icfo_run(const icfo_params* P, int64_t nnz, const int32_t* user, const int32_t* item, const float* score,
+             int64_t n_sim, const int32_t* sim_item, const int32_t* sim_other, const double* sim_value, icfo_result** out);
+void icfo_free(icfo_result*);
+int64_t icfo_n(const icfo_result*);          /* rows grouped by user id asc, best first (ties: ascending item id) */
+const int32_t* icfo_user(const icfo_result*);
+const int32_t* icfo_item(const icfo_result*);
+const float* icfo_score(const icfo_result*);
+
 #ifdef __cplusplus
 }
 #endif
