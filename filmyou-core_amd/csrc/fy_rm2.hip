@@ -277,6 +277,7 @@ struct ScoreArgs {
     int32_t n_slices;
     int32_t rb;                            // row block of this launch
     int32_t nrb;                           // row blocks per row
+    int32_t nt_rows;                       // rows with index >= nt_rows are loaded non-temporally (0 = never)
 };
 
 __device__ __forceinline__ float fy_log2(float x) { return __builtin_amdgcn_logf(x); }   // v_log_f32
@@ -292,6 +293,35 @@ template <> struct VecT<4> { using type = float4; };
 struct U3 {
     uint32_t a, b, c;
 };
+typedef uint32_t fy_u32x3 __attribute__((ext_vector_type(3)));
+typedef float fy_f32x4 __attribute__((ext_vector_type(4)));
+typedef float fy_f32x2 __attribute__((ext_vector_type(2)));
+
+// Row segments of unpopular items are read by few users within an L2 lifetime: loading them with the non-temporal hint
+// keeps them from evicting the popular rows every wave of the XCD re-reads.
+template <class G>
+__device__ __forceinline__ G fy_load_nt(const char* p);
+template <>
+__device__ __forceinline__ U3 fy_load_nt<U3>(const char* p) {
+    const fy_u32x3 v = __builtin_nontemporal_load(reinterpret_cast<const fy_u32x3*>(p));
+    U3 r;
+    r.a = v.x; r.b = v.y; r.c = v.z;
+    return r;
+}
+template <>
+__device__ __forceinline__ float4 fy_load_nt<float4>(const char* p) {
+    const fy_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const fy_f32x4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+template <>
+__device__ __forceinline__ float2 fy_load_nt<float2>(const char* p) {
+    const fy_f32x2 v = __builtin_nontemporal_load(reinterpret_cast<const fy_f32x2*>(p));
+    return make_float2(v.x, v.y);
+}
+template <>
+__device__ __forceinline__ float fy_load_nt<float>(const char* p) {
+    return __builtin_nontemporal_load(reinterpret_cast<const float*>(p));
+}
 // four packed 24-bit values (12 bytes; exponent + 16 mantissa bits, no sign) -> four floats: v_perm_b32 + shift each
 __device__ __forceinline__ void fy_unpack24(const U3& d, float* f) {
     f[0] = __uint_as_float(__builtin_amdgcn_perm(0u, d.a, 0x0201000cu) >> 1);
@@ -349,7 +379,9 @@ __global__ __launch_bounds__(256) void k_score(const float* __restrict__ M_, con
                 const int kk = min(k + q, end - 1);
                 jj[q] = csr_idx_[kk];
                 e[q] = csr_e_[kk];
-                g[q] = *reinterpret_cast<const G*>(Mcol + (int64_t)jj[q] * pitch);
+                const char* src = Mcol + (int64_t)jj[q] * pitch;
+                if (A.nt_rows > 0 && jj[q] >= A.nt_rows) g[q] = fy_load_nt<G>(src);   // wave-uniform
+                else g[q] = *reinterpret_cast<const G*>(src);
             }
             float p[VEC];
 #pragma unroll
@@ -808,6 +840,7 @@ struct ScoreTune {
     int pack24 = 1;                    // M rows as 24-bit floats (3 bytes per element): -25 % of the dominant traffic
     int pack24_min_items = 4096;       // ... for clusters with at least this many items
     int batch = 8;                     // row-segment loads in flight per wave
+    int nt_rows = 0;                   // rows >= this index are loaded with the non-temporal hint (0 = off)
     int lanes = 4;                     // HIP streams the clusters of one job are spread over
     int cooc_block = 0;                // test hook: force the row kernel's workgroup size
     int cooc_max_ch = 16384;           // LDS accumulators of the row kernel (test hook: smaller forces column chunks)
@@ -822,6 +855,7 @@ static ScoreTune score_tune() {
     if (const char* e = getenv("FY_M24_MIN_ITEMS")) t.pack24_min_items = atoi(e);
     if (const char* e = getenv("FY_HOT_LDS")) t.hot_lds = atoi(e) != 0;
     if (const char* e = getenv("FY_SCORE_BATCH")) t.batch = atoi(e);
+    if (const char* e = getenv("FY_SCORE_NT_ROWS")) t.nt_rows = atoi(e);
     if (const char* e = getenv("FY_LANES")) { int v = atoi(e); if (v >= 1 && v <= 8) t.lanes = v; }
     if (const char* e = getenv("FY_COOC_BLOCK")) { int v = atoi(e); if (v == 256 || v == 512 || v == 1024) t.cooc_block = v; }
     if (const char* e = getenv("FY_COOC_MAX_CH")) { int v = atoi(e); if (v >= 64 && v <= 16384) t.cooc_max_ch = v; }
@@ -1099,7 +1133,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                     // one 16-wave workgroup per CU (128 KiB of LDS); every wave gets >= 8 users to amortise the tile load
                     const int hs = (int)std::max<int64_t>(1, std::min<int64_t>(256, ceil_div(nb, 16 * 8)));
                     ScoreArgs SA{L.M.get(), ldm, Ic, a_rank.get() + pbase, L.hot_off.get(), P.csr_idx.get(), csr_e.get(), pvpi.get(),
-                                 n_out.get(), lo, sbase, s0, nb, L.S.get(), ldS, hs, 0, 1};
+                                 n_out.get(), lo, sbase, s0, nb, L.S.get(), ldS, hs, 0, 1, 0};
                     const size_t lds = (size_t)SCORE_HOT_ROWS * 1024;
                     if (pack24) k_score_hot<true><<<(int)(ldm / 256) * hs, 1024, lds, ls>>>(SA.M, SA.a_rank, SA.rb_off, SA.csr_idx, SA.csr_e, SA.pvpi, SA.n_out, SA.S, SA);
                     else k_score_hot<false><<<(int)(ldm / 256) * hs, 1024, lds, ls>>>(SA.M, SA.a_rank, SA.rb_off, SA.csr_idx, SA.csr_e, SA.pvpi, SA.n_out, SA.S, SA);
@@ -1108,7 +1142,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 }
                 for (int32_t rb = 0; rb < (use_hot ? 0 : nrb); rb++) {
                     ScoreArgs SA{L.M.get(), ldm, Ic, a_rank.get() + pbase, L.rb_off.get(), P.csr_idx.get(), csr_e.get(), pvpi.get(),
-                                 n_out.get(), lo, sbase, s0, nb, L.S.get(), ldS, n_slices, rb, nrb};
+                                 n_out.get(), lo, sbase, s0, nb, L.S.get(), ldS, n_slices, rb, nrb, tune.nt_rows};
 #define FY_LAUNCH_SCORE(V_, P_, B_) k_score<V_, P_, B_><<<n_chunks * n_slices, 256, 0, ls>>>(SA.M, SA.a_rank, SA.rb_off, SA.csr_idx, SA.csr_e, SA.pvpi, SA.n_out, SA.S, SA)
                     if (pack24 && tune.batch == 16) FY_LAUNCH_SCORE(4, true, 16);
                     else if (pack24 && tune.batch == 12) FY_LAUNCH_SCORE(4, true, 12);

@@ -1,0 +1,66 @@
+"""Randomised small cases, GPU vs oracle: ragged users, empty / tiny / unbalanced clusters, items seen by one user,
+ties (integer ratings make exact ties common), top-N cut-offs, filterUsers, non-contiguous raw ids."""
+import numpy as np
+import pytest
+
+import oracle
+from util import assert_topn_matches, pkg
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = pkg().Context(0)
+    yield c
+    c.close()
+
+
+def random_case(rng):
+    U = int(rng.integers(2, 60))
+    I = int(rng.integers(2, 90))
+    K = int(rng.integers(1, 7))
+    density = rng.choice([0.05, 0.2, 0.6])
+    mask = rng.random((U, I)) < density
+    mask[np.arange(U), rng.integers(0, I, U)] = True            # every user rates something
+    u_idx, i_idx = np.nonzero(mask)
+    half = rng.random() < 0.5
+    s = (rng.integers(1, 11, len(u_idx)) / 2.0) if half else rng.integers(1, 6, len(u_idx)).astype(float)
+    s = s.astype(np.float32)
+    s[rng.random(len(s)) < 0.03] = 0.0                           # records the score > 0 filter drops
+    uid = np.sort(rng.choice(10_000, U, replace=False)).astype(np.int32) + 1
+    iid = np.sort(rng.choice(5_000, I, replace=False)).astype(np.int32) + 1
+    user, item = uid[u_idx], iid[i_idx]
+    perm = rng.permutation(len(user))
+    clusters = rng.integers(0, K, U).astype(np.int32)
+    if rng.random() < 0.3:
+        clusters[:] = clusters[0]                                # everyone in one cluster, others empty
+    drop = rng.random(U) < 0.1                                   # unmapped users fall into cluster 0
+    lam = float(rng.choice([0.0, 0.1, 0.5, 0.9, 1.0]))
+    top_n = int(rng.choice([1, 3, 10, 1000]))
+    filt = int(rng.choice([0, 0, uid[U // 2]]))
+    return dict(user=user[perm], item=item[perm], score=s[perm], mu=uid[~drop], mc=clusters[~drop], K=K, lam=lam,
+                top_n=top_n, filt=filt, n_items=int(iid.max()))
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_case(ctx, seed):
+    P = pkg()
+    c = random_case(np.random.default_rng(1000 + seed))
+    conf = P.Configuration()
+    conf.set("lambda", repr(c["lam"]))
+    conf.setInt("numberOfItems", c["n_items"])
+    conf.setInt("numberOfClusters", c["K"])
+    conf.setInt("numberOfRecommendations", c["top_n"])
+    conf.setInt("filterUsers", c["filt"])
+    rec = P.RM2Job(conf, ctx).run((c["user"], c["item"], c["score"]), clustering=(c["mu"], c["mc"]))
+    ref = oracle.rm2(c["user"], c["item"], c["score"], lam=c["lam"], number_of_items=c["n_items"],
+                     number_of_recommendations=1 << 30, number_of_clusters=c["K"], map_user=c["mu"], map_cluster=c["mc"],
+                     filter_users=c["filt"])
+    if len(ref["rec_user"]) == 0:
+        assert rec.size == 0
+        return
+    assert_topn_matches(rec.rows(), ref, c["top_n"])
+    sums = rec.sums()
+    np.testing.assert_array_equal(sums["user_sum"], ref["user_sum"])
+    assert sums["total_sum"] == ref["total_sum"]
