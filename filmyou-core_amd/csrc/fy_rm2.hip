@@ -278,6 +278,8 @@ struct ScoreArgs {
     int32_t rb;                            // row block of this launch
     int32_t nrb;                           // row blocks per row
     int32_t nt_rows;                       // rows with index >= nt_rows are loaded non-temporally (0 = never)
+    int32_t xcd_map;                       // 1: workgroup b works on chunk 8 * (b / 8 / n_slices) + b % 8 (one chunk per XCD at a time)
+    int32_t n_chunks;
 };
 
 __device__ __forceinline__ float fy_log2(float x) { return __builtin_amdgcn_logf(x); }   // v_log_f32
@@ -341,8 +343,14 @@ __global__ __launch_bounds__(256) void k_score(const float* __restrict__ M_, con
     constexpr int CW = 64 * VEC;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int chunk = blockIdx.x / A.n_slices;
-    const int slice = blockIdx.x - chunk * A.n_slices;
+    int chunk = blockIdx.x / A.n_slices;
+    int slice = blockIdx.x - chunk * A.n_slices;
+    if (A.xcd_map) {   // blocks b and b + 8 share an XCD (round-robin dispatch): give every XCD its own chunk
+        const int t = blockIdx.x >> 3;
+        chunk = (t / A.n_slices) * 8 + (blockIdx.x & 7);
+        slice = t % A.n_slices;
+        if (chunk >= A.n_chunks) return;
+    }
     const int col0 = chunk * CW;
     const int col = col0 + lane * VEC;
     float a[VEC];
@@ -841,6 +849,9 @@ struct ScoreTune {
     int pack24_min_items = 4096;       // ... for clusters with at least this many items
     int batch = 8;                     // row-segment loads in flight per wave
     int nt_rows = 0;                   // rows >= this index are loaded with the non-temporal hint (0 = off)
+    int xcd_map = 0;                   // one column chunk per XCD at a time
+    int max_slices = 65536;            // user slices (workgroups) per column chunk
+    int users_per_wave = 16;           // users a wave of the scoring kernel walks for one column chunk
     int lanes = 4;                     // HIP streams the clusters of one job are spread over
     int cooc_block = 0;                // test hook: force the row kernel's workgroup size
     int cooc_max_ch = 16384;           // LDS accumulators of the row kernel (test hook: smaller forces column chunks)
@@ -856,6 +867,9 @@ static ScoreTune score_tune() {
     if (const char* e = getenv("FY_HOT_LDS")) t.hot_lds = atoi(e) != 0;
     if (const char* e = getenv("FY_SCORE_BATCH")) t.batch = atoi(e);
     if (const char* e = getenv("FY_SCORE_NT_ROWS")) t.nt_rows = atoi(e);
+    if (const char* e = getenv("FY_SCORE_XCD")) t.xcd_map = atoi(e) != 0;
+    if (const char* e = getenv("FY_SCORE_SLICES")) t.max_slices = atoi(e);
+    if (const char* e = getenv("FY_SCORE_UPW")) { int v = atoi(e); if (v >= 1) t.users_per_wave = v; }
     if (const char* e = getenv("FY_LANES")) { int v = atoi(e); if (v >= 1 && v <= 8) t.lanes = v; }
     if (const char* e = getenv("FY_COOC_BLOCK")) { int v = atoi(e); if (v == 256 || v == 512 || v == 1024) t.cooc_block = v; }
     if (const char* e = getenv("FY_COOC_MAX_CH")) { int v = atoi(e); if (v >= 64 && v <= 16384) t.cooc_max_ch = v; }
@@ -1127,13 +1141,13 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             if (use_hot) build_chunk_offsets(ctx, P.rowptr.get(), P.csr_idx.get(), sbase, Uc, SCORE_HOT_ROWS, 2, L.hot_off.get(), ls);
             for (int32_t s0 = a; s0 < b; s0 += (int32_t)B) {
                 const int32_t nb = (int32_t)std::min<int64_t>(B, b - s0);
-                int n_slices = (int)std::max<int64_t>(1, std::min<int64_t>(1024, ceil_div(nb, 4 * 16)));
+                int n_slices = (int)std::max<int64_t>(1, std::min<int64_t>(tune.max_slices, ceil_div(nb, 4 * tune.users_per_wave)));
                 const size_t ss = t_score.begin(ls);
                 if (use_hot) {
                     // one 16-wave workgroup per CU (128 KiB of LDS); every wave gets >= 8 users to amortise the tile load
                     const int hs = (int)std::max<int64_t>(1, std::min<int64_t>(256, ceil_div(nb, 16 * 8)));
                     ScoreArgs SA{L.M.get(), ldm, Ic, a_rank.get() + pbase, L.hot_off.get(), P.csr_idx.get(), csr_e.get(), pvpi.get(),
-                                 n_out.get(), lo, sbase, s0, nb, L.S.get(), ldS, hs, 0, 1, 0};
+                                 n_out.get(), lo, sbase, s0, nb, L.S.get(), ldS, hs, 0, 1, 0, 0, 0};
                     const size_t lds = (size_t)SCORE_HOT_ROWS * 1024;
                     if (pack24) k_score_hot<true><<<(int)(ldm / 256) * hs, 1024, lds, ls>>>(SA.M, SA.a_rank, SA.rb_off, SA.csr_idx, SA.csr_e, SA.pvpi, SA.n_out, SA.S, SA);
                     else k_score_hot<false><<<(int)(ldm / 256) * hs, 1024, lds, ls>>>(SA.M, SA.a_rank, SA.rb_off, SA.csr_idx, SA.csr_e, SA.pvpi, SA.n_out, SA.S, SA);
@@ -1142,8 +1156,8 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 }
                 for (int32_t rb = 0; rb < (use_hot ? 0 : nrb); rb++) {
                     ScoreArgs SA{L.M.get(), ldm, Ic, a_rank.get() + pbase, L.rb_off.get(), P.csr_idx.get(), csr_e.get(), pvpi.get(),
-                                 n_out.get(), lo, sbase, s0, nb, L.S.get(), ldS, n_slices, rb, nrb, tune.nt_rows};
-#define FY_LAUNCH_SCORE(V_, P_, B_) k_score<V_, P_, B_><<<n_chunks * n_slices, 256, 0, ls>>>(SA.M, SA.a_rank, SA.rb_off, SA.csr_idx, SA.csr_e, SA.pvpi, SA.n_out, SA.S, SA)
+                                 n_out.get(), lo, sbase, s0, nb, L.S.get(), ldS, n_slices, rb, nrb, tune.nt_rows, tune.xcd_map, n_chunks};
+#define FY_LAUNCH_SCORE(V_, P_, B_) k_score<V_, P_, B_><<<(tune.xcd_map ? (int)round_up(n_chunks, 8) : n_chunks) * n_slices, 256, 0, ls>>>(SA.M, SA.a_rank, SA.rb_off, SA.csr_idx, SA.csr_e, SA.pvpi, SA.n_out, SA.S, SA)
                     if (pack24 && tune.batch == 16) FY_LAUNCH_SCORE(4, true, 16);
                     else if (pack24 && tune.batch == 12) FY_LAUNCH_SCORE(4, true, 12);
                     else if (pack24) FY_LAUNCH_SCORE(4, true, 8);
