@@ -41,12 +41,21 @@ void inclusive_scan_u32(Context* c, const uint32_t* in, uint32_t* out, size_t n)
     DevBuf<char> t(c, tmp);
     FY_HIP(rocprim::inclusive_scan(t.get(), tmp, in, out, n, rocprim::plus<uint32_t>(), c->stream));
 }
-void exclusive_scan_i32(Context* c, const int32_t* in, int32_t* out, size_t n) {
+void exclusive_scan_i32(Context* c, const int32_t* in, int32_t* out, size_t n, hipStream_t st) {
     if (n == 0) return;
+    if (!st) st = c->stream;
     size_t tmp = 0;
-    FY_HIP(rocprim::exclusive_scan(nullptr, tmp, in, out, int32_t(0), n, rocprim::plus<int32_t>(), c->stream));
-    DevBuf<char> t(c, tmp);
-    FY_HIP(rocprim::exclusive_scan(t.get(), tmp, in, out, int32_t(0), n, rocprim::plus<int32_t>(), c->stream));
+    FY_HIP(rocprim::exclusive_scan(nullptr, tmp, in, out, int32_t(0), n, rocprim::plus<int32_t>(), st));
+    if (st == c->stream) {
+        DevBuf<char> t(c, tmp);
+        FY_HIP(rocprim::exclusive_scan(t.get(), tmp, in, out, int32_t(0), n, rocprim::plus<int32_t>(), st));
+    } else {
+        // on a lane the temporary must not go back to the (single-stream) allocator while the lane still uses it
+        void* t = nullptr;
+        FY_HIP(hipMallocAsync(&t, tmp ? tmp : 1, st));
+        FY_HIP(rocprim::exclusive_scan(t, tmp, in, out, int32_t(0), n, rocprim::plus<int32_t>(), st));
+        FY_HIP(hipFreeAsync(t, st));
+    }
 }
 void inclusive_scan_i64(Context* c, const int64_t* in, int64_t* out, size_t n) {
     if (n == 0) return;

@@ -207,6 +207,8 @@ struct MEpilogue {
     double w2;    // (1-l)^2
     double w1;    // l (1-l)
     int pack24;   // 3 bytes per element: 8 exponent + 16 mantissa bits of the (non-negative) fp32, rounded to nearest
+    float* __restrict__ Bmax;   // optional [row][ldb]: maximum of the (rounded) row over every 64-column block
+    int64_t ldb;
 };
 
 __global__ void k_cooc_rm2(CoocArgs A, MEpilogue E) {
@@ -236,6 +238,18 @@ __global__ void k_cooc_rm2(CoocArgs A, MEpilogue E) {
             out3[3 * c4 + 0] = v[0] | (v[1] << 24);
             out3[3 * c4 + 1] = (v[1] >> 8) | (v[2] << 16);
             out3[3 * c4 + 2] = (v[2] >> 16) | (v[3] << 8);
+            if (E.Bmax) {
+                // maximum of the values exactly as the scoring kernel will unpack them; 16 consecutive threads = one
+                // 64-column block (c0, c1 and the thread index are multiples of 16 groups of 4 columns)
+                float m = 0.0f;
+#pragma unroll
+                for (int q = 0; q < 4; q++) m = fmaxf(m, __uint_as_float((v[q] << 8) >> 1));
+                m = fmaxf(m, __shfl_xor(m, 1, 64));
+                m = fmaxf(m, __shfl_xor(m, 2, 64));
+                m = fmaxf(m, __shfl_xor(m, 4, 64));
+                m = fmaxf(m, __shfl_xor(m, 8, 64));
+                if ((threadIdx.x & 15) == 0) E.Bmax[(int64_t)row * E.ldb + (c4 >> 4)] = m;
+            }
         }
         return;
     }
@@ -280,6 +294,7 @@ struct ScoreArgs {
     int32_t nt_rows;                       // rows with index >= nt_rows are loaded non-temporally (0 = never)
     int32_t xcd_map;                       // 1: workgroup b works on chunk 8 * (b / 8 / n_slices) + b % 8 (one chunk per XCD at a time)
     int32_t n_chunks;
+    int32_t no_mask;                       // 1: the columns are not items (bound pass over block maxima): no "already rated" mask
 };
 
 __device__ __forceinline__ float fy_log2(float x) { return __builtin_amdgcn_logf(x); }   // v_log_f32
@@ -407,7 +422,7 @@ __global__ __launch_bounds__(256) void k_score(const float* __restrict__ M_, con
 #pragma unroll
                     for (int v = 0; v < VEC; v++) p[v] += fy_log2(fmaf(a[v], e[q], gv[v]));
                     const unsigned d = (unsigned)(jj[q] - col0);
-                    if (d < (unsigned)CW && (int)(d / VEC) == lane) mask |= 1u << (d % VEC);
+                    if (!A.no_mask && d < (unsigned)CW && (int)(d / VEC) == lane) mask |= 1u << (d % VEC);
                 }
             }
 #pragma unroll
@@ -810,6 +825,157 @@ __global__ __launch_bounds__(256) void k_topn_select(TopNArgs A, const int32_t* 
     }
 }
 
+// ================================================================ exact pruning of candidate blocks (branch and bound)
+// For a block B of 64 candidate columns,
+//     UB(u, B) = pvpi + sum_{j in rated(u)} ln( max_{i in B} M[j][i] + (max_{i in B} a_i) * e_uj )  >=  score(u, i)  for all i in B,
+// because every term is monotone in M[j][i] and a_i.  Evaluating UB is the scoring kernel itself run on the reduced
+// matrix Bmax[j][B] (1/64 of the columns).  With tau_u = the N-th best EXACT score among the first `seed` (most
+// popular) columns, a block whose UB is below tau_u cannot contribute to the user's top N and is skipped; the exact
+// kernel then runs only on the surviving (user, block) pairs.  RM2 scores fall steeply with candidate popularity, so on
+// MovieLens-shaped data well under 1 % of the tail blocks survive -- the lists are bit-for-bit those of the full pass.
+constexpr int PRUNE_BLOCK = 64;
+
+// block maxima of a = lambda * p
+__global__ void k_block_amax(int32_t Ic, int32_t ldb, const float* __restrict__ a_rank, float* __restrict__ amax) {
+    for (int32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < ldb; b += gridDim.x * blockDim.x) {
+        float m = 0.0f;
+        for (int i = b * PRUNE_BLOCK; i < min(Ic, (b + 1) * PRUNE_BLOCK); i++) m = fmaxf(m, a_rank[i]);
+        amax[b] = m;
+    }
+}
+
+// tau_u = K-th best exact score among the seed columns (K = rows the user will emit), -inf when fewer are valid
+__global__ __launch_bounds__(256) void k_seed_tau(const float* __restrict__ S, int64_t ldS, int32_t n_seed_cols,
+                                                   const int32_t* __restrict__ n_out, float* __restrict__ tau) {
+    __shared__ uint64_t keys[TOPN_SAMPLE];
+    __shared__ uint32_t sh_nvalid;
+    const int u = blockIdx.x;
+    const int K = n_out[u];
+    if (K == 0) {
+        if (threadIdx.x == 0) tau[u] = INFINITY;   // nothing to emit: every block may be skipped
+        return;
+    }
+    if (threadIdx.x == 0) sh_nvalid = 0;
+    __syncthreads();
+    int myvalid = 0;
+    for (int i = threadIdx.x; i < TOPN_SAMPLE; i += blockDim.x) {
+        uint64_t c = 0ull;
+        if (i < n_seed_cols) {
+            const float f = S[(int64_t)u * ldS + i];
+            if (f == f) { c = (uint64_t)fy_order_key(f); myvalid++; }
+        }
+        keys[i] = c;
+    }
+    if (myvalid) atomicAdd(&sh_nvalid, (uint32_t)myvalid);
+    __syncthreads();
+    fy_bitonic_desc(keys, TOPN_SAMPLE);
+    if (threadIdx.x == 0) tau[u] = ((int)sh_nvalid >= K) ? fy_order_unkey((uint32_t)keys[K - 1]) : -INFINITY;
+}
+
+// one wave per user: compact list of the blocks that may still hold a top-N candidate
+__global__ void k_survivors(int32_t n_users, int32_t nblk, int32_t seed_blocks, int64_t ldb, const float* __restrict__ UB,
+                            const float* __restrict__ tau, uint16_t* __restrict__ surv, int32_t* __restrict__ n_quads,
+                            unsigned long long* __restrict__ counters) {
+    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    for (int32_t u = blockIdx.x * wpb + (threadIdx.x >> 6); u < n_users; u += gridDim.x * wpb) {
+        const float t = tau[u];
+        int count = 0;
+        for (int base = seed_blocks; base < nblk && t != INFINITY; base += 64) {
+            const int b = base + lane;
+            bool keep = false;
+            if (b < nblk) {
+                const float ub = UB[(int64_t)u * ldb + b];
+                // safety margin over the rounding of both sums (each is accurate to ~1e-7 relative)
+                keep = ub + (1e-5f * fabsf(ub) + 1e-4f) >= t;
+            }
+            const unsigned long long bal = __ballot(keep);
+            if (keep) surv[(int64_t)u * ldb + count + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)b;
+            count += __popcll(bal);
+        }
+        if (lane == 0) {
+            n_quads[u] = (count + 3) >> 2;
+            // the last quad is padded with its first block
+            if (count) atomicAdd(&counters[0], (unsigned long long)count);
+        }
+        const int padded = ((count + 3) >> 2) << 2;
+        if (count && lane < padded - count) surv[(int64_t)u * ldb + count + lane] = 0xFFFFu;
+    }
+}
+
+// exact scores of the surviving blocks: one wave = one user x four 64-column blocks (16 lanes x 4 columns each)
+template <int SB>
+__global__ __launch_bounds__(256) void k_score_quads(const float* __restrict__ M_, const float* __restrict__ a_rank_,
+                                                     const int32_t* __restrict__ rowptr_, const int32_t* __restrict__ csr_idx_,
+                                                     const float* __restrict__ csr_e_, const double* __restrict__ pvpi_,
+                                                     const int32_t* __restrict__ quad_prefix_, const uint16_t* __restrict__ surv_,
+                                                     float* __restrict__ S_, ScoreArgs A, int64_t ldb, unsigned long long* counters) {
+    const int lane = threadIdx.x & 63;
+    const int wave_in_grid = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    const int n_waves = gridDim.x * (blockDim.x >> 6);
+    const int total = quad_prefix_[A.n_users];
+    const int64_t pitch = A.ldm * 3;
+    const double LN2 = 0.69314718055994530942;
+    const float qnan = __builtin_nanf("");
+    unsigned long long my_terms = 0;
+    for (int w = wave_in_grid; w < total; w += n_waves) {
+        int lo = 0, hi = A.n_users;                 // last user with quad_prefix <= w
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (quad_prefix_[mid] <= w) lo = mid; else hi = mid;
+        }
+        const int u = lo;
+        const int q = w - quad_prefix_[u];
+        const int slot = A.slot0 + u;
+        const unsigned blk = surv_[(int64_t)u * ldb + 4 * q + (lane >> 4)];
+        const bool live = blk != 0xFFFFu;
+        const int col = (live ? (int)blk : (int)surv_[(int64_t)u * ldb + 4 * q]) * PRUNE_BLOCK + (lane & 15) * 4;
+        float a[4];
+#pragma unroll
+        for (int v = 0; v < 4; v++) a[v] = col + v < A.Ic ? a_rank_[col + v] : 0.0f;
+        const char* __restrict__ Mcol = reinterpret_cast<const char*>(M_) + (int64_t)col * 3;
+        const int beg = rowptr_[slot], end = rowptr_[slot + 1];
+        double t[4] = {0.0, 0.0, 0.0, 0.0};
+        unsigned mask = 0;
+        for (int k = beg; k < end; k += SB) {
+            U3 g[SB];
+            float e[SB];
+            int jj[SB];
+#pragma unroll
+            for (int x = 0; x < SB; x++) {
+                const int kk = min(k + x, end - 1);
+                jj[x] = csr_idx_[kk];
+                e[x] = csr_e_[kk];
+                g[x] = *reinterpret_cast<const U3*>(Mcol + (int64_t)jj[x] * pitch);
+            }
+            float p[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int x = 0; x < SB; x++) {
+                if (k + x < end) {
+                    float gv[4];
+                    fy_unpack24(g[x], gv);
+#pragma unroll
+                    for (int v = 0; v < 4; v++) p[v] += fy_log2(fmaf(a[v], e[x], gv[v]));
+                    const unsigned d = (unsigned)(jj[x] - col);
+                    if (d < 4u) mask |= 1u << d;
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < 4; v++) t[v] += (double)p[v];
+        }
+        if (live) {
+            const double base = pvpi_[slot - A.slot_lo];
+            float4 o;
+            o.x = ((mask & 1u) || col + 0 >= A.Ic) ? qnan : (float)(base + LN2 * t[0]);
+            o.y = ((mask & 2u) || col + 1 >= A.Ic) ? qnan : (float)(base + LN2 * t[1]);
+            o.z = ((mask & 4u) || col + 2 >= A.Ic) ? qnan : (float)(base + LN2 * t[2]);
+            o.w = ((mask & 8u) || col + 3 >= A.Ic) ? qnan : (float)(base + LN2 * t[3]);
+            *reinterpret_cast<float4*>(S_ + (int64_t)u * A.ldS + col) = o;
+        }
+        my_terms += (unsigned long long)(end - beg) * 256ull;
+    }
+    if (lane == 0 && my_terms) atomicAdd(&counters[1], my_terms);
+}
+
 void launch_topn_rows(Context* ctx, hipStream_t st, const float* S, int64_t ldS, int32_t n_cols, int32_t n_rows,
                       const int32_t* n_out, const int32_t* out_off, const int32_t* rank_item_raw, const int32_t* slot2du,
                       const int32_t* uid, int32_t slot0, int32_t aux_value, int32_t* out_user, int32_t* out_item,
@@ -853,6 +1019,9 @@ struct ScoreTune {
     int max_slices = 65536;            // user slices (workgroups) per column chunk
     int users_per_wave = 16;           // users a wave of the scoring kernel walks for one column chunk
     int lanes = 4;                     // HIP streams the clusters of one job are spread over
+    int prune = 1;                     // branch and bound over 64-column candidate blocks
+    int prune_min_items = 8192;
+    int seed_chunks = 4;               // 256-column chunks scored exactly before the bound pass (the most popular candidates)
     int cooc_block = 0;                // test hook: force the row kernel's workgroup size
     int cooc_max_ch = 16384;           // LDS accumulators of the row kernel (test hook: smaller forces column chunks)
     int hot_lds = 0;                   // k_score_hot: the 128 most popular rows of a chunk stay in LDS (slower: 16 waves/CU)
@@ -870,6 +1039,9 @@ static ScoreTune score_tune() {
     if (const char* e = getenv("FY_SCORE_XCD")) t.xcd_map = atoi(e) != 0;
     if (const char* e = getenv("FY_SCORE_SLICES")) t.max_slices = atoi(e);
     if (const char* e = getenv("FY_SCORE_UPW")) { int v = atoi(e); if (v >= 1) t.users_per_wave = v; }
+    if (const char* e = getenv("FY_PRUNE")) t.prune = atoi(e) != 0;
+    if (const char* e = getenv("FY_PRUNE_MIN_ITEMS")) t.prune_min_items = atoi(e);
+    if (const char* e = getenv("FY_SEED_CHUNKS")) { int v = atoi(e); if (v >= 1 && v <= 4) t.seed_chunks = v; }
     if (const char* e = getenv("FY_LANES")) { int v = atoi(e); if (v >= 1 && v <= 8) t.lanes = v; }
     if (const char* e = getenv("FY_COOC_BLOCK")) { int v = atoi(e); if (v == 256 || v == 512 || v == 1024) t.cooc_block = v; }
     if (const char* e = getenv("FY_COOC_MAX_CH")) { int v = atoi(e); if (v >= 64 && v <= 16384) t.cooc_max_ch = v; }
@@ -1033,7 +1205,9 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             int c;
             int32_t Uc, sbase, pbase, Ic, a, b, CH, nch, rb_rows, nrb, q0, nq;
             int64_t ldm, B;
-            bool pack24, use_hot;
+            bool pack24, use_hot, prune;
+            int32_t nblk;
+            int64_t ldb;
         };
         std::vector<Plan> plans;
         const int VEC = tune.vec;
@@ -1060,6 +1234,10 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             p.nrb = (int32_t)ceil_div(p.Ic, p.rb_rows);
             if (p.nrb <= 1) { p.nrb = 1; p.rb_rows = p.Ic; }
             p.use_hot = tune.hot_lds && VEC == 4 && p.nrb == 1 && p.Ic >= tune.hot_min_items;
+            // branch-and-bound over 64-column blocks: only where the matrix is big enough for the bound pass to pay
+            p.nblk = (int32_t)ceil_div(p.Ic, PRUNE_BLOCK);
+            p.ldb = round_up(p.nblk, 256);
+            p.prune = tune.prune && p.pack24 && p.nrb == 1 && !p.use_hot && p.Ic >= tune.prune_min_items && p.nblk < 0xFFFF;
             plans.push_back(p);
         }
         const int NS = (int)std::min<size_t>(plans.size() > 1 ? (size_t)tune.lanes : 1, plans.size());
@@ -1068,10 +1246,14 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             DevBuf<float> M, S;
             DevBuf<int32_t> chunk_off, rb_off, hot_off, overflow, any_overflow;
             DevBuf<int2> csc_slice;
+            // branch and bound
+            DevBuf<float> Bmax, amax, UB, tau;
+            DevBuf<uint16_t> surv;
+            DevBuf<int32_t> n_quads, quad_prefix;
         };
         std::vector<Lane> lanes((size_t)NS);
         {
-            size_t m_el = 1, s_el = 1, co_el = 1, rb_el = 1, ho_el = 1, ov_el = 1, sl_el = 1;
+            size_t m_el = 1, s_el = 1, co_el = 1, rb_el = 1, ho_el = 1, ov_el = 1, sl_el = 1, bm_el = 1, ub_el = 1, am_el = 1;
             for (auto& p : plans) {
                 p.B = std::min<int64_t>(std::max<int64_t>(1, (ws / NS) / (p.ldm * 4)), p.b - p.a);
                 m_el = std::max(m_el, (size_t)(p.Ic * p.ldm));
@@ -1081,6 +1263,11 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 if (p.use_hot) ho_el = std::max(ho_el, (size_t)p.Uc * 3);
                 ov_el = std::max(ov_el, (size_t)p.B);
                 sl_el = std::max(sl_el, (size_t)p.nq * p.nch);
+                if (p.prune) {
+                    bm_el = std::max(bm_el, (size_t)(p.Ic * p.ldb));
+                    ub_el = std::max(ub_el, (size_t)(p.B * p.ldb));
+                    am_el = std::max(am_el, (size_t)p.ldb);
+                }
             }
             if (NS > 1 && ctx->aux.size() < (size_t)NS) {
                 while (ctx->aux.size() < (size_t)NS) {
@@ -1100,8 +1287,18 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 L.overflow.alloc(ctx, ov_el);
                 L.any_overflow.alloc(ctx, 1);
                 L.csc_slice.alloc(ctx, sl_el);
+                L.Bmax.alloc(ctx, bm_el);
+                L.amax.alloc(ctx, am_el);
+                L.UB.alloc(ctx, ub_el);
+                L.tau.alloc(ctx, ov_el);
+                L.surv.alloc(ctx, ub_el);
+                L.n_quads.alloc(ctx, ov_el + 1);
+                L.quad_prefix.alloc(ctx, ov_el + 1);
             }
         }
+        DevBuf<unsigned long long> prune_counters(ctx, 2);   // [0] surviving blocks, [1] log terms of the survivor pass
+        prune_counters.zero();
+        int64_t prune_blocks_total = 0, prune_seed_terms_cols = 0;
         hipEvent_t fork = nullptr;
         if (NS > 1) {   // the lanes start after everything queued on the main stream so far
             FY_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
@@ -1124,7 +1321,12 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             CoocArgs CA{P.rank_pair.get(), P.pair_start.get(), P.csc_slot.get(), csc_x.get(), L.csc_slice.get(), P.csr_idx.get(),
                         csr_x.get(), pbase, sbase, Ic, CH, nch, 0, Ic, p.q0, p.nq};
             MEpilogue ME{L.M.get(), ldm, p_rank.get() + pbase, b_rank.get() + pbase, (1.0 - lambda) * (1.0 - lambda), lambda * (1.0 - lambda),
-                         pack24 ? 1 : 0};
+                         pack24 ? 1 : 0, p.prune ? L.Bmax.get() : nullptr, p.ldb};
+            if (p.prune) {
+                FY_HIP(hipMemsetAsync(L.Bmax.get(), 0, (size_t)Ic * p.ldb * sizeof(float), ls));
+                k_block_amax<<<grid_for(p.ldb), 256, 0, ls>>>(Ic, (int32_t)p.ldb, a_rank.get() + pbase, L.amax.get());
+                FY_KERNEL_CHECK();
+            }
             const int block = tune.cooc_block ? tune.cooc_block : ((CH * 8 > 48 * 1024) ? 1024 : 256);
             const size_t sp = t_cooc.begin(ls);
             k_cooc_rm2<<<Ic * nch, block, (size_t)CH * 8, ls>>>(CA, ME);
@@ -1147,16 +1349,51 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                     // one 16-wave workgroup per CU (128 KiB of LDS); every wave gets >= 8 users to amortise the tile load
                     const int hs = (int)std::max<int64_t>(1, std::min<int64_t>(256, ceil_div(nb, 16 * 8)));
                     ScoreArgs SA{L.M.get(), ldm, Ic, a_rank.get() + pbase, L.hot_off.get(), P.csr_idx.get(), csr_e.get(), pvpi.get(),
-                                 n_out.get(), lo, sbase, s0, nb, L.S.get(), ldS, hs, 0, 1, 0, 0, 0};
+                                 n_out.get(), lo, sbase, s0, nb, L.S.get(), ldS, hs, 0, 1, 0, 0, 0, 0};
                     const size_t lds = (size_t)SCORE_HOT_ROWS * 1024;
                     if (pack24) k_score_hot<true><<<(int)(ldm / 256) * hs, 1024, lds, ls>>>(SA.M, SA.a_rank, SA.rb_off, SA.csr_idx, SA.csr_e, SA.pvpi, SA.n_out, SA.S, SA);
                     else k_score_hot<false><<<(int)(ldm / 256) * hs, 1024, lds, ls>>>(SA.M, SA.a_rank, SA.rb_off, SA.csr_idx, SA.csr_e, SA.pvpi, SA.n_out, SA.S, SA);
                     FY_KERNEL_CHECK();
                     R->st.score_launches++;
                 }
-                for (int32_t rb = 0; rb < (use_hot ? 0 : nrb); rb++) {
+                if (p.prune) {
+                    const int seed_chunks = std::min(n_chunks, tune.seed_chunks);
+                    const int seed_blocks = seed_chunks * 4;
+                    // every column outside the seed and the surviving blocks stays "not a candidate"
+                    FY_HIP(hipMemsetAsync(L.S.get(), 0xFF, (size_t)nb * ldS * sizeof(float), ls));
+                    // (1) exact scores of the seed columns (the most popular candidates)
                     ScoreArgs SA{L.M.get(), ldm, Ic, a_rank.get() + pbase, L.rb_off.get(), P.csr_idx.get(), csr_e.get(), pvpi.get(),
-                                 n_out.get(), lo, sbase, s0, nb, L.S.get(), ldS, n_slices, rb, nrb, tune.nt_rows, tune.xcd_map, n_chunks};
+                                 n_out.get(), lo, sbase, s0, nb, L.S.get(), ldS, n_slices, 0, 1, 0, 0, seed_chunks, 0};
+                    k_score<4, true, 8><<<seed_chunks * n_slices, 256, 0, ls>>>(SA.M, SA.a_rank, SA.rb_off, SA.csr_idx, SA.csr_e, SA.pvpi, SA.n_out, SA.S, SA);
+                    FY_KERNEL_CHECK();
+                    // (2) tau_u = N-th best seed score
+                    k_seed_tau<<<nb, 256, 0, ls>>>(L.S.get(), ldS, std::min<int32_t>(Ic, seed_chunks * 256), n_out.get() + (s0 - lo), L.tau.get());
+                    FY_KERNEL_CHECK();
+                    // (3) upper bounds of all 64-column blocks: the scoring kernel on the block-maximum matrix
+                    const int bchunks = (int)(p.ldb / 256);
+                    ScoreArgs SB_{L.Bmax.get(), p.ldb, p.nblk, L.amax.get(), L.rb_off.get(), P.csr_idx.get(), csr_e.get(), pvpi.get(),
+                                  n_out.get(), lo, sbase, s0, nb, L.UB.get(), p.ldb, n_slices, 0, 1, 0, 0, bchunks, 1};
+                    k_score<4, false, 8><<<bchunks * n_slices, 256, 0, ls>>>(SB_.M, SB_.a_rank, SB_.rb_off, SB_.csr_idx, SB_.csr_e, SB_.pvpi, SB_.n_out, SB_.S, SB_);
+                    FY_KERNEL_CHECK();
+                    // (4) surviving blocks, four per wave
+                    FY_HIP(hipMemsetAsync(L.n_quads.get() + nb, 0, sizeof(int32_t), ls));
+                    k_survivors<<<grid_for((int64_t)nb * 64, 256), 256, 0, ls>>>(nb, p.nblk, seed_blocks, p.ldb, L.UB.get(), L.tau.get(), L.surv.get(),
+                                                                                 L.n_quads.get(), prune_counters.get());
+                    FY_KERNEL_CHECK();
+                    exclusive_scan_i32(ctx, L.n_quads.get(), L.quad_prefix.get(), (size_t)nb + 1, ls);
+                    // (5) exact scores of the survivors
+                    ScoreArgs SQ{L.M.get(), ldm, Ic, a_rank.get() + pbase, L.rb_off.get(), P.csr_idx.get(), csr_e.get(), pvpi.get(),
+                                 n_out.get(), lo, sbase, s0, nb, L.S.get(), ldS, n_slices, 0, 1, 0, 0, n_chunks, 0};
+                    k_score_quads<8><<<ctx->num_cus * 8, 256, 0, ls>>>(SQ.M, SQ.a_rank, P.rowptr.get(), SQ.csr_idx, SQ.csr_e, SQ.pvpi,
+                                                                       L.quad_prefix.get(), L.surv.get(), SQ.S, SQ, p.ldb, prune_counters.get());
+                    FY_KERNEL_CHECK();
+                    R->st.score_launches += 3;
+                    prune_blocks_total += (int64_t)nb * std::max(0, p.nblk - seed_blocks);
+                    prune_seed_terms_cols += (int64_t)(seed_chunks * 256 + p.ldb);
+                }
+                for (int32_t rb = 0; rb < ((use_hot || p.prune) ? 0 : nrb); rb++) {
+                    ScoreArgs SA{L.M.get(), ldm, Ic, a_rank.get() + pbase, L.rb_off.get(), P.csr_idx.get(), csr_e.get(), pvpi.get(),
+                                 n_out.get(), lo, sbase, s0, nb, L.S.get(), ldS, n_slices, rb, nrb, tune.nt_rows, tune.xcd_map, n_chunks, 0};
 #define FY_LAUNCH_SCORE(V_, P_, B_) k_score<V_, P_, B_><<<(tune.xcd_map ? (int)round_up(n_chunks, 8) : n_chunks) * n_slices, 256, 0, ls>>>(SA.M, SA.a_rank, SA.rb_off, SA.csr_idx, SA.csr_e, SA.pvpi, SA.n_out, SA.S, SA)
                     if (pack24 && tune.batch == 16) FY_LAUNCH_SCORE(4, true, 16);
                     else if (pack24 && tune.batch == 12) FY_LAUNCH_SCORE(4, true, 12);
@@ -1190,6 +1427,15 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             FY_HIP(hipEventDestroy(fork));
             // the lanes' buffers go back to the allocator only after the join point has been reached
             FY_HIP(hipStreamSynchronize(st));
+        }
+        {
+            unsigned long long hc[2];
+            d2h(ctx, hc, prune_counters.get(), 2);
+            sync(ctx);
+            R->st.blocks_survived = (int64_t)hc[0];
+            R->st.blocks_total = prune_blocks_total;
+            R->st.log_terms_survivors = (int64_t)hc[1];
+            (void)prune_seed_terms_cols;
         }
     }
     // rm2/userSum and rm2/itemColl stay in HBM until somebody asks for them

@@ -172,8 +172,11 @@ typedef struct {
     double ms_score;           /* RM2 scoring kernel, summed over launches */
     double ms_topn;
     double ms_total;
-    int64_t score_launches;    /* launches of the dominant kernel and bytes of its algorithmic traffic model */
+    int64_t score_launches;    /* launches of the scoring kernels */
     int64_t cooc_launches;
+    int64_t blocks_total;        /* RM2 branch and bound: (user, 64-column block) pairs behind the seed columns ... */
+    int64_t blocks_survived;     /* ... and how many of them had to be scored exactly */
+    int64_t log_terms_survivors; /* log terms evaluated by the survivor pass */
 } fy_stats;
 int fy_result_stats(fy_result*, fy_stats* out);
 
