@@ -582,6 +582,15 @@ struct TopNArgs {
     int32_t* __restrict__ out_item;
     float* __restrict__ out_score;
     int32_t* __restrict__ out_cluster;
+    // branch and bound (fy_rm2.hip, "exact pruning"): only the seed columns and the surviving 64-column blocks of a score row
+    // are ever written.  mode 0: the whole row is live.  mode 1 (seed phase): sort the seed columns, publish tau_u and the
+    // list the user gets if no block survives.  mode 2 (merge phase): users with surviving blocks only, seed + survivors.
+    int32_t mode;
+    int32_t seed_cols;
+    const uint16_t* __restrict__ surv;    // [u * ldb + k]: surviving block ids, quads padded with 0xFFFF
+    const int32_t* __restrict__ n_quads;  // [u]
+    int64_t ldb;
+    float* __restrict__ tau;              // [u]
 };
 
 __device__ __forceinline__ uint32_t fy_order_key(float f) {
@@ -629,14 +638,18 @@ __global__ __launch_bounds__(256) void k_topn_fast(TopNArgs A, int32_t* __restri
     const int slot = A.slot0 + u;
     const int K = A.n_out[slot - A.slot_lo];
     if (threadIdx.x == 0) overflow[u] = 0;
-    if (K == 0) return;
-    if (force_select) {   // test hook (FY_TOPN_FORCE_SELECT=1): exercise the radix-select path for every user
+    if (A.mode == 2 && A.n_quads[u] == 0) return;         // the seed phase already wrote this user's final list
+    if (K == 0) {
+        if (A.mode == 1 && threadIdx.x == 0) A.tau[u] = INFINITY;   // nothing to emit: every block may be skipped
+        return;
+    }
+    if (force_select && A.mode != 1) {   // test hook (FY_TOPN_FORCE_SELECT=1): exercise the radix-select path for every user
         if (threadIdx.x == 0) { overflow[u] = 1; atomicAdd(any_overflow, 1); }
         return;
     }
     const float* __restrict__ row = A.S + (int64_t)u * A.ldS;
     const int tid = threadIdx.x;
-    const int Ls = min(A.Ic, TOPN_SAMPLE);
+    const int Ls = min(A.Ic, A.mode ? min(A.seed_cols, TOPN_SAMPLE) : TOPN_SAMPLE);
     if (tid == 0) sh_nvalid = 0;
     __syncthreads();
     int myvalid = 0;
@@ -654,12 +667,33 @@ __global__ __launch_bounds__(256) void k_topn_fast(TopNArgs A, int32_t* __restri
     const int nvalid = (int)sh_nvalid;
     const uint32_t tau = nvalid >= K ? (uint32_t)(cand[K - 1] >> 32) : 0u;   // valid keys are > 0
     const int keep = min(K, nvalid);
+    if (A.mode == 1) {
+        // seed phase: tau for the bound pass, and the list that stands unless a block survives (almost always)
+        if (tid == 0) A.tau[u] = nvalid >= K ? fy_order_unkey(tau) : -INFINITY;
+        const int off1 = A.out_off[slot - A.slot_lo];
+        const int user1 = A.uid[A.slot2du[slot]];
+        for (int i = tid; i < keep; i += blockDim.x) {
+            const uint64_t c = cand[i];
+            A.out_user[off1 + i] = user1;
+            A.out_item[off1 + i] = 0x7FFFFFFF - (int32_t)(uint32_t)c;
+            A.out_score[off1 + i] = fy_order_unkey((uint32_t)(c >> 32));
+            A.out_cluster[off1 + i] = A.cluster;
+        }
+        return;
+    }
     __syncthreads();
     if (tid == 0) sh_count = (uint32_t)keep;
     __syncthreads();
-    // stream the rest of the row
-    const int i4_end = (A.Ic + 3) >> 2;
-    for (int i4 = (TOPN_SAMPLE >> 2) + tid; i4 < i4_end; i4 += blockDim.x) {
+    // stream the rest of the row (mode 2: only the surviving blocks, 16 float4 each)
+    const int i4_begin = A.mode == 2 ? 0 : (TOPN_SAMPLE >> 2);
+    const int i4_end = A.mode == 2 ? A.n_quads[u] * 4 * 16 : (A.Ic + 3) >> 2;
+    for (int x = i4_begin + tid; x < i4_end; x += blockDim.x) {
+        int i4 = x;
+        if (A.mode == 2) {
+            const unsigned blk = A.surv[(int64_t)u * A.ldb + (x >> 4)];
+            if (blk == 0xFFFFu) continue;
+            i4 = (int)blk * 16 + (x & 15);
+        }
         const float4 f4 = *reinterpret_cast<const float4*>(row + 4 * i4);
         const float fv[4] = {f4.x, f4.y, f4.z, f4.w};
 #pragma unroll
@@ -712,6 +746,18 @@ __global__ __launch_bounds__(256) void k_topn_select(TopNArgs A, const int32_t* 
     if (K == 0) return;
     const float* __restrict__ row = A.S + (int64_t)u * A.ldS;
     const int tid = threadIdx.x;
+    // pruned rows: only the seed columns and the surviving 64-column blocks were ever written
+    __shared__ uint32_t live[2048];
+    if (A.mode) {
+        for (int w = tid; w < 2048; w += blockDim.x) live[w] = 0;
+        __syncthreads();
+        for (int k = tid; k < A.n_quads[u] * 4; k += blockDim.x) {
+            const unsigned blk = A.surv[(int64_t)u * A.ldb + k];
+            if (blk != 0xFFFFu) atomicOr(&live[blk >> 5], 1u << (blk & 31u));
+        }
+        __syncthreads();
+    }
+#define FY_ROWVAL(i) ((A.mode == 0 || (i) < A.seed_cols || ((live[(i) >> 11] >> (((i) >> 6) & 31)) & 1u)) ? row[(i)] : __builtin_nanf(""))
 
     // ---- radix select: 12 + 10 + 10 bits, most significant first
     uint32_t prefix = 0, prefix_mask = 0, need = (uint32_t)K;
@@ -722,7 +768,7 @@ __global__ __launch_bounds__(256) void k_topn_select(TopNArgs A, const int32_t* 
         for (int b = tid; b < nb; b += blockDim.x) hist[b] = 0;
         __syncthreads();
         for (int i = tid; i < A.Ic; i += blockDim.x) {
-            const float f = row[i];
+            const float f = FY_ROWVAL(i);
             if (f != f) continue;
             const uint32_t key = fy_order_key(f);
             if ((key & prefix_mask) == prefix) atomicAdd(&hist[(key >> shifts[pass]) & (nb - 1)], 1u);
@@ -754,7 +800,7 @@ __global__ __launch_bounds__(256) void k_topn_select(TopNArgs A, const int32_t* 
     if (tid == 0) { sh_count = 0; sh_eq_taken = 0; }
     __syncthreads();
     for (int i = tid; i < A.Ic; i += blockDim.x) {
-        const float f = row[i];
+        const float f = FY_ROWVAL(i);
         if (f != f) continue;
         const uint32_t key = fy_order_key(f);
         if (key > T || (take_all_eq && key == T)) {
@@ -772,7 +818,7 @@ __global__ __launch_bounds__(256) void k_topn_select(TopNArgs A, const int32_t* 
             const int i = base + tid;
             bool eq = false;
             if (i < A.Ic) {
-                const float f = row[i];
+                const float f = FY_ROWVAL(i);
                 eq = (f == f) && fy_order_key(f) == T;
             }
             const unsigned long long bal = __ballot(eq);
@@ -844,38 +890,11 @@ __global__ void k_block_amax(int32_t Ic, int32_t ldb, const float* __restrict__ 
     }
 }
 
-// tau_u = K-th best exact score among the seed columns (K = rows the user will emit), -inf when fewer are valid
-__global__ __launch_bounds__(256) void k_seed_tau(const float* __restrict__ S, int64_t ldS, int32_t n_seed_cols,
-                                                   const int32_t* __restrict__ n_out, float* __restrict__ tau) {
-    __shared__ uint64_t keys[TOPN_SAMPLE];
-    __shared__ uint32_t sh_nvalid;
-    const int u = blockIdx.x;
-    const int K = n_out[u];
-    if (K == 0) {
-        if (threadIdx.x == 0) tau[u] = INFINITY;   // nothing to emit: every block may be skipped
-        return;
-    }
-    if (threadIdx.x == 0) sh_nvalid = 0;
-    __syncthreads();
-    int myvalid = 0;
-    for (int i = threadIdx.x; i < TOPN_SAMPLE; i += blockDim.x) {
-        uint64_t c = 0ull;
-        if (i < n_seed_cols) {
-            const float f = S[(int64_t)u * ldS + i];
-            if (f == f) { c = (uint64_t)fy_order_key(f); myvalid++; }
-        }
-        keys[i] = c;
-    }
-    if (myvalid) atomicAdd(&sh_nvalid, (uint32_t)myvalid);
-    __syncthreads();
-    fy_bitonic_desc(keys, TOPN_SAMPLE);
-    if (threadIdx.x == 0) tau[u] = ((int)sh_nvalid >= K) ? fy_order_unkey((uint32_t)keys[K - 1]) : -INFINITY;
-}
-
 // one wave per user: compact list of the blocks that may still hold a top-N candidate
 __global__ void k_survivors(int32_t n_users, int32_t nblk, int32_t seed_blocks, int64_t ldb, const float* __restrict__ UB,
                             const float* __restrict__ tau, uint16_t* __restrict__ surv, int32_t* __restrict__ n_quads,
-                            unsigned long long* __restrict__ counters) {
+                            unsigned long long* __restrict__ counters, const int32_t* __restrict__ rowptr, int32_t slot0,
+                            int32_t cols_seed_and_bound) {
     const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
     for (int32_t u = blockIdx.x * wpb + (threadIdx.x >> 6); u < n_users; u += gridDim.x * wpb) {
         const float t = tau[u];
@@ -894,8 +913,10 @@ __global__ void k_survivors(int32_t n_users, int32_t nblk, int32_t seed_blocks, 
         }
         if (lane == 0) {
             n_quads[u] = (count + 3) >> 2;
-            // the last quad is padded with its first block
             if (count) atomicAdd(&counters[0], (unsigned long long)count);
+            // log terms the seed pass and the bound pass evaluated for this user (statistics only)
+            if (t != INFINITY)
+                atomicAdd(&counters[1], (unsigned long long)(rowptr[slot0 + u + 1] - rowptr[slot0 + u]) * (unsigned long long)cols_seed_and_bound);
         }
         const int padded = ((count + 3) >> 2) << 2;
         if (count && lane < padded - count) surv[(int64_t)u * ldb + count + lane] = 0xFFFFu;
@@ -983,7 +1004,8 @@ void launch_topn_rows(Context* ctx, hipStream_t st, const float* S, int64_t ldS,
     if (n_rows <= 0) return;
     if (!st) st = ctx->stream;
     // n_out / out_off are indexed by (slot - slot_lo): pass slot_lo = slot0 so that row u reads entry u
-    TopNArgs TA{S, ldS, n_cols, n_out, out_off, rank_item_raw, slot2du, uid, slot0, slot0, aux_value, out_user, out_item, out_score, out_aux};
+    TopNArgs TA{S, ldS, n_cols, n_out, out_off, rank_item_raw, slot2du, uid, slot0, slot0, aux_value, out_user, out_item, out_score, out_aux,
+                0, 0, nullptr, nullptr, 0, nullptr};
     FY_HIP(hipMemsetAsync(any_overflow, 0, sizeof(int32_t), st));
     k_topn_fast<<<n_rows, 256, 0, st>>>(TA, overflow, any_overflow, 0);
     FY_KERNEL_CHECK();
@@ -1296,7 +1318,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 L.quad_prefix.alloc(ctx, ov_el + 1);
             }
         }
-        DevBuf<unsigned long long> prune_counters(ctx, 2);   // [0] surviving blocks, [1] log terms of the survivor pass
+        DevBuf<unsigned long long> prune_counters(ctx, 2);   // [0] surviving blocks, [1] log terms evaluated by the three pruned passes
         prune_counters.zero();
         int64_t prune_blocks_total = 0, prune_seed_terms_cols = 0;
         hipEvent_t fork = nullptr;
@@ -1359,15 +1381,17 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 if (p.prune) {
                     const int seed_chunks = std::min(n_chunks, tune.seed_chunks);
                     const int seed_blocks = seed_chunks * 4;
-                    // every column outside the seed and the surviving blocks stays "not a candidate"
-                    FY_HIP(hipMemsetAsync(L.S.get(), 0xFF, (size_t)nb * ldS * sizeof(float), ls));
+                    // only the seed columns and the surviving blocks of a score row are ever written or read
                     // (1) exact scores of the seed columns (the most popular candidates)
                     ScoreArgs SA{L.M.get(), ldm, Ic, a_rank.get() + pbase, L.rb_off.get(), P.csr_idx.get(), csr_e.get(), pvpi.get(),
                                  n_out.get(), lo, sbase, s0, nb, L.S.get(), ldS, n_slices, 0, 1, 0, 0, seed_chunks, 0};
                     k_score<4, true, 8><<<seed_chunks * n_slices, 256, 0, ls>>>(SA.M, SA.a_rank, SA.rb_off, SA.csr_idx, SA.csr_e, SA.pvpi, SA.n_out, SA.S, SA);
                     FY_KERNEL_CHECK();
-                    // (2) tau_u = N-th best seed score
-                    k_seed_tau<<<nb, 256, 0, ls>>>(L.S.get(), ldS, std::min<int32_t>(Ic, seed_chunks * 256), n_out.get() + (s0 - lo), L.tau.get());
+                    // (2) tau_u = N-th best seed score; the sorted seed head is also the user's list unless a block survives
+                    TopNArgs T1{L.S.get(), ldS, Ic, n_out.get(), out_off.get(), P.rank_item_raw.get() + pbase, P.slot2du.get(), P.uid.get(),
+                                lo, s0, c, R->d_key0.get(), R->d_key1.get(), R->d_value.get(), R->d_aux.get(),
+                                1, seed_chunks * 256, L.surv.get(), L.n_quads.get(), p.ldb, L.tau.get()};
+                    k_topn_fast<<<nb, 256, 0, ls>>>(T1, L.overflow.get(), L.any_overflow.get(), 0);
                     FY_KERNEL_CHECK();
                     // (3) upper bounds of all 64-column blocks: the scoring kernel on the block-maximum matrix
                     const int bchunks = (int)(p.ldb / 256);
@@ -1378,7 +1402,8 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                     // (4) surviving blocks, four per wave
                     FY_HIP(hipMemsetAsync(L.n_quads.get() + nb, 0, sizeof(int32_t), ls));
                     k_survivors<<<grid_for((int64_t)nb * 64, 256), 256, 0, ls>>>(nb, p.nblk, seed_blocks, p.ldb, L.UB.get(), L.tau.get(), L.surv.get(),
-                                                                                 L.n_quads.get(), prune_counters.get());
+                                                                                 L.n_quads.get(), prune_counters.get(), P.rowptr.get(), s0,
+                                                                                 seed_chunks * 256 + (int32_t)p.ldb);
                     FY_KERNEL_CHECK();
                     exclusive_scan_i32(ctx, L.n_quads.get(), L.quad_prefix.get(), (size_t)nb + 1, ls);
                     // (5) exact scores of the survivors
@@ -1406,7 +1431,9 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 }
                 t_score.end(ss, ls);
                 TopNArgs TA{L.S.get(), ldS, Ic, n_out.get(), out_off.get(), P.rank_item_raw.get() + pbase, P.slot2du.get(), P.uid.get(),
-                            lo, s0, c, R->d_key0.get(), R->d_key1.get(), R->d_value.get(), R->d_aux.get()};
+                            lo, s0, c, R->d_key0.get(), R->d_key1.get(), R->d_value.get(), R->d_aux.get(),
+                            p.prune ? 2 : 0, p.prune ? std::min(n_chunks, tune.seed_chunks) * 256 : 0, L.surv.get(), L.n_quads.get(), p.ldb,
+                            L.tau.get()};
                 const size_t tt = t_topn.begin(ls);
                 FY_HIP(hipMemsetAsync(L.any_overflow.get(), 0, sizeof(int32_t), ls));
                 k_topn_fast<<<nb, 256, 0, ls>>>(TA, L.overflow.get(), L.any_overflow.get(), tune.force_select);
@@ -1434,7 +1461,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             sync(ctx);
             R->st.blocks_survived = (int64_t)hc[0];
             R->st.blocks_total = prune_blocks_total;
-            R->st.log_terms_survivors = (int64_t)hc[1];
+            R->st.log_terms_evaluated = (int64_t)hc[1];
             (void)prune_seed_terms_cols;
         }
     }

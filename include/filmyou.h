@@ -176,7 +176,7 @@ typedef struct {
     int64_t cooc_launches;
     int64_t blocks_total;        /* RM2 branch and bound: (user, 64-column block) pairs behind the seed columns ... */
     int64_t blocks_survived;     /* ... and how many of them had to be scored exactly */
-    int64_t log_terms_survivors; /* log terms evaluated by the survivor pass */
+    int64_t log_terms_evaluated; /* log terms actually evaluated (seed + bound + survivor passes); 0 = no pruning: log_terms */
 } fy_stats;
 int fy_result_stats(fy_result*, fy_stats* out);
 
