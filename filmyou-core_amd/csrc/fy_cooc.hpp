@@ -19,11 +19,12 @@ struct CoocArgs {
     // CSC of the cluster: pair_start indexed by pair id; rank_pair maps (pbase + row) -> pair id
     const int32_t* __restrict__ rank_pair;
     const int32_t* __restrict__ pair_start;
-    const int32_t* __restrict__ csc_slot;
-    const float* __restrict__ csc_w;
-    // csc_slice[ch * nq + (e - q0)] = {first CSR entry, length} of the slice of rater e's CSR row that falls into column
-    // chunk ch: precomputed per CSC entry so the row kernel reads it coalesced instead of gathering per-user offsets
-    const int2* __restrict__ csc_slice;
+    // Segment table: the slice of every rater's CSR row that falls into column chunk ch is cut into segments of at most 64
+    // entries.  seg_ptr[ch * (nq + 1) + (e - q0)] = first segment of CSC entry e in chunk ch (exclusive prefix, the
+    // segments of one item row are contiguous); seg[k] = {first CSR entry, length}, seg_w[k] = the rater's weight.
+    const int32_t* __restrict__ seg_ptr;
+    const int2* __restrict__ seg;
+    const float* __restrict__ seg_w;
     const int32_t* __restrict__ csr_idx;
     const float* __restrict__ csr_w;
     int32_t pbase;      // pcstart[c]
@@ -35,99 +36,80 @@ struct CoocArgs {
     int32_t nrows;      // rows in this launch
     int32_t q0;         // first CSC entry of the cluster
     int32_t nq;         // CSC entries of the cluster
+    int32_t debug;      // timing experiments only (wrong results): 1 = no LDS atomics
 };
 
 // Accumulates chunk `ch` of row `row` into the workgroup's dynamic LDS (fy_cooc_acc[0..CH), zeroed by the caller; all
 // threads call this).
 //
-// A wave fetches the metadata of 64 of its raters at a time: lane l loads one rater's slot, weight and the [f0, f0+len)
-// slice of that user's CSR row inside the chunk with two vector loads -- one dependent chain per 64 raters instead of
-// one scalar chain per rater (the first version spent 88 % of its wave cycles waiting, rocprof r1a).  The wave then walks
-// its raters four at a time (v_readlane broadcasts), issuing the four coalesced slice loads before the first LDS atomic
-// so four memory round trips overlap.  The accumulators are addressed through the LDS symbol itself, so the
-// compiler emits ds_add_f64 and knows they cannot alias the global arrays.
-// (A fully load-balanced expansion with a per-lane binary search over the prefix sums was tried and ran 3x slower:
-// six dependent ds_bpermute per step on a 16-wave workgroup.)
+// Unit of work = one SEGMENT (<= 64 entries of one rater's row slice, one entry per lane).  The segments of an item row
+// are contiguous in the segment table, so a wave simply takes 64 of them at a time (wave w: segments 64 w, 64 (w + nwaves),
+// ...), broadcasts their descriptors with v_readlane, eight at a time: eight coalesced loads, then eight LDS atomics.
+// Heavy users -- raters of very many rows with slices of thousands of entries, half of all rater visits at ML-25M shape --
+// are spread over all waves of the workgroup by construction; there is no per-rater loop left.
+// History (rocprof, ML-25M shape, ms per M build): one scalar chain per rater 110; per-lane binary-search expansion 362;
+// 4 raters per wave-step 84; + pipelined long-slice loop 48 (of which 28 were waves idling behind the wave that held a
+// long slice); LDS queue for the remainders 104; segment s of rater r -> wave (r + s) mod 16 with every wave reading all
+// metadata 90; persistent workgroups 47; this version (segments precomputed per CSC entry): DESIGN.md section 7.
 extern __shared__ double fy_cooc_acc[];
 
 __device__ __forceinline__ void cooc_accumulate_row(const CoocArgs& A, int row, int ch) {
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = blockDim.x >> 6;
     const int pair = A.rank_pair[A.pbase + row];
     const int e0 = A.pair_start[pair], e1 = A.pair_start[pair + 1];
+    const int32_t* __restrict__ sp = A.seg_ptr + (int64_t)ch * (A.nq + 1) - A.q0;
+    const int s_begin = sp[e0], s_end = sp[e1];
     const int c0 = ch * A.CH;
     const int32_t* __restrict__ csr_idx = A.csr_idx;
     const float* __restrict__ csr_w = A.csr_w;
-    // Rater (step s, slot q) of this wave = e0 + ((s * nwaves + wave) * RS + q): consecutive groups of RS raters go to
-    // consecutive waves, so a row with few raters still spreads over the whole workgroup (one step per wave), while
-    // lane l = RS s + q of the wave prefetches the metadata of 64 / RS steps at once.  (RS = 16 was slower: fewer
-    // waves busy on short rows.)
-    constexpr int RS = 4, STEPS = 64 / RS;
-    for (int round = 0; e0 + round * nwaves * 64 < e1; round++) {
-        const int s_l = lane / RS, q_l = lane % RS;
-        const int e = e0 + ((round * STEPS + s_l) * nwaves + wave) * RS + q_l;
-        int f0 = 0, len = 0;
+    constexpr int NB = 8;
+    // a wave fetches 64 segment descriptors with one vector load (one round trip per 64 segments) and then works through
+    // them eight at a time: eight coalesced slice loads in flight, then eight LDS atomics
+    for (int sb = s_begin + wave * 64; sb < s_end; sb += nwaves * 64) {   // wave-uniform
+        int2 d = make_int2(0, 0);
         float w = 0.0f;
-        if (e < e1) {
-            w = A.csc_w[e];
-            const int2 sl = A.csc_slice[(int64_t)ch * A.nq + (e - A.q0)];
-            f0 = sl.x;
-            len = sl.y;
-        }
-        const unsigned long long nonempty = __ballot(len > 0);
-        for (int s = 0; s < STEPS; s++) {   // wave-uniform
-            const unsigned long long rest = nonempty >> (RS * s);
-            if (rest == 0) break;
-            if ((rest & ((1ull << RS) - 1ull)) == 0) continue;
-            int F[RS], L[RS];
-            float W[RS];
+        if (sb + lane < s_end) { d = A.seg[sb + lane]; w = A.seg_w[sb + lane]; }
+        const int nloc = min(64, s_end - sb);
+        for (int g = 0; g < nloc; g += NB) {
+            int F[NB], L[NB];
+            float W[NB];
 #pragma unroll
-            for (int q = 0; q < RS; q++) {
-                F[q] = __builtin_amdgcn_readlane(f0, RS * s + q);
-                L[q] = __builtin_amdgcn_readlane(len, RS * s + q);
-                W[q] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(w), RS * s + q));
+            for (int q = 0; q < NB; q++) {
+                F[q] = __builtin_amdgcn_readlane(d.x, g + q);
+                L[q] = __builtin_amdgcn_readlane(d.y, g + q);
+                W[q] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(w), g + q));
             }
-            int idx[RS];
-            float x[RS];
+            int idx[NB];
+            float x[NB];
 #pragma unroll
-            for (int q = 0; q < RS; q++) {
-                idx[q] = 0; x[q] = 0.0f;
+            for (int q = 0; q < NB; q++) {
+                idx[q] = c0; x[q] = 0.0f;
                 if (lane < L[q]) { idx[q] = csr_idx[F[q] + lane]; x[q] = csr_w[F[q] + lane]; }
             }
+            if (A.debug == 1) {
+                float sink = 0.f;
 #pragma unroll
-            for (int q = 0; q < RS; q++)
-                if (lane < L[q]) atomicAdd(&fy_cooc_acc[idx[q] - c0], (double)W[q] * (double)x[q]);
-            // slices longer than one wave: heavy users, who are raters of very many rows -- half of all rater visits at
-            // ML-25M shape.  Eight 64-entry segments are loaded before the first atomic so eight round trips overlap
-            // (a plain one-segment loop here cost a full memory latency per 64 entries and dominated the kernel: 84 ->
-            // 48 ms).  Two re-balancing schemes were tried and were slower: queueing the remainders in LDS and walking them
-            // with the whole workgroup (104 ms: three barriers per 1024 raters), and giving segment s of rater r to wave
-            // (r + s) mod nwaves with every wave walking all raters' metadata (90 ms: 16x the uncoalesced chunk_off
-            // gathers).
+                for (int q = 0; q < NB; q++) sink += x[q] + (float)idx[q];
+                if (sink == -12345.f) fy_cooc_acc[0] = sink;
+            } else {
 #pragma unroll
-            for (int q = 0; q < RS; q++) {
-                for (int fb = 64; fb < L[q]; fb += 512) {   // wave-uniform
-                    int ix[8];
-                    float xx[8];
-#pragma unroll
-                    for (int z = 0; z < 8; z++) {
-                        const int f = fb + 64 * z + lane;
-                        ix[z] = 0; xx[z] = 0.0f;
-                        if (f < L[q]) { ix[z] = csr_idx[F[q] + f]; xx[z] = csr_w[F[q] + f]; }
-                    }
-#pragma unroll
-                    for (int z = 0; z < 8; z++)
-                        if (fb + 64 * z + lane < L[q]) atomicAdd(&fy_cooc_acc[ix[z] - c0], (double)W[q] * (double)xx[z]);
-                }
+                for (int q = 0; q < NB; q++)
+                    if (lane < L[q]) atomicAdd(&fy_cooc_acc[idx[q] - c0], (double)W[q] * (double)x[q]);   // ds_add_f64
             }
         }
     }
 }
 
-// csc_slice table of one cluster from its chunk_off table (one thread per (chunk, CSC entry))
-void build_csc_slices(Context* ctx, const int32_t* csc_slot, const int32_t* chunk_off, int32_t slot_base, int32_t q0, int32_t nq,
-                      int32_t nch, int2* csc_slice, hipStream_t st = nullptr);
+// segment table of one cluster from its chunk_off table; returns the number of segments (synchronises once)
+struct SegTable {
+    DevBuf<int32_t> ptr;   // nch * (nq + 1)
+    DevBuf<int2> seg;
+    DevBuf<float> w;
+};
+void build_segments(Context* ctx, const int32_t* csc_slot, const float* csc_w, const int32_t* chunk_off, int32_t slot_base,
+                    int32_t q0, int32_t nq, int32_t nch, SegTable& out, hipStream_t st = nullptr);
 
 // chunk_off table for one cluster: one thread per (slot, boundary)
 void build_chunk_offsets(Context* ctx, const int32_t* rowptr, const int32_t* csr_idx, int32_t slot_base, int32_t n_slots,

@@ -218,10 +218,10 @@ fy_result* itemsim_build(Context* ctx, const fy_itemsim_params* prm, const fy_ra
     DevBuf<float> sim(ctx, (size_t)rows_mine * K);
     cnt.zero();
     if (rows_mine > 0) {
-        DevBuf<int2> csc_slice(ctx, (size_t)P.nnz * nch);
-        build_csc_slices(ctx, P.csc_slot.get(), chunk_off.get(), 0, 0, (int32_t)P.nnz, nch, csc_slice.get());
-        CoocArgs CA{P.rank_pair.get(), P.pair_start.get(), P.csc_slot.get(), csc_w.get(), csc_slice.get(), P.csr_idx.get(),
-                    csr_w.get(), 0, 0, Ic, CH, nch, 0, Ic, 0, (int32_t)P.nnz};
+        SegTable segs;
+        build_segments(ctx, P.csc_slot.get(), csc_w.get(), chunk_off.get(), 0, 0, (int32_t)P.nnz, nch, segs);
+        CoocArgs CA{P.rank_pair.get(), P.pair_start.get(), segs.ptr.get(), segs.seg.get(), segs.w.get(), P.csr_idx.get(),
+                    csr_w.get(), 0, 0, Ic, CH, nch, 0, Ic, 0, (int32_t)P.nnz, 0};
         ISimEpilogue IE{P.rank_item_raw.get(), K, prm->exclude_self, prm->has_threshold, (float)prm->threshold, prm->rank,
                         prm->world, cnt.get(), other.get(), sim.get()};
         const size_t lds = (size_t)CH * 8 + (size_t)ISIM_CAP * 8;

@@ -181,21 +181,57 @@ void build_chunk_offsets(Context* ctx, const int32_t* rowptr, const int32_t* csr
     FY_KERNEL_CHECK();
 }
 
-__global__ void k_csc_slices(const int32_t* __restrict__ csc_slot, const int32_t* __restrict__ chunk_off, int32_t slot_base,
-                             int32_t q0, int32_t nq, int32_t nch, int2* __restrict__ out) {
-    const int64_t total = (int64_t)nq * nch;
+// ---- segment table (fy_cooc.hpp): counts, exclusive prefix, fill
+__global__ void k_seg_counts(const int32_t* __restrict__ csc_slot, const int32_t* __restrict__ chunk_off, int32_t slot_base,
+                             int32_t q0, int32_t nq, int32_t nch, int32_t* __restrict__ cnt) {
+    const int64_t total = (int64_t)nch * (nq + 1);
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-        const int32_t ch = (int32_t)(t / nq), q = (int32_t)(t % nq);
-        const int32_t* co = chunk_off + (int64_t)(csc_slot[q0 + q] - slot_base) * (nch + 1) + ch;
-        out[t] = make_int2(co[0], co[1] - co[0]);
+        const int32_t ch = (int32_t)(t / (nq + 1)), q = (int32_t)(t % (nq + 1));
+        int32_t n = 0;
+        if (q < nq) {
+            const int32_t* co = chunk_off + (int64_t)(csc_slot[q0 + q] - slot_base) * (nch + 1) + ch;
+            n = (co[1] - co[0] + 63) >> 6;
+        }
+        cnt[t] = n;
     }
 }
 
-void build_csc_slices(Context* ctx, const int32_t* csc_slot, const int32_t* chunk_off, int32_t slot_base, int32_t q0, int32_t nq,
-                      int32_t nch, int2* csc_slice, hipStream_t st) {
-    if ((int64_t)nq * nch == 0) return;
-    k_csc_slices<<<grid_for((int64_t)nq * nch), 256, 0, st ? st : ctx->stream>>>(csc_slot, chunk_off, slot_base, q0, nq, nch, csc_slice);
+__global__ void k_seg_fill(const int32_t* __restrict__ csc_slot, const float* __restrict__ csc_w, const int32_t* __restrict__ chunk_off,
+                           int32_t slot_base, int32_t q0, int32_t nq, int32_t nch, const int32_t* __restrict__ ptr,
+                           int2* __restrict__ seg, float* __restrict__ seg_w) {
+    const int64_t total = (int64_t)nch * nq;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t ch = (int32_t)(t / nq), q = (int32_t)(t % nq);
+        const int32_t* co = chunk_off + (int64_t)(csc_slot[q0 + q] - slot_base) * (nch + 1) + ch;
+        const int32_t f0 = co[0], len = co[1] - f0;
+        const float w = csc_w[q0 + q];
+        int32_t k = ptr[(int64_t)ch * (nq + 1) + q];
+        for (int32_t off = 0; off < len; off += 64, k++) {
+            seg[k] = make_int2(f0 + off, min(64, len - off));
+            seg_w[k] = w;
+        }
+    }
+}
+
+void build_segments(Context* ctx, const int32_t* csc_slot, const float* csc_w, const int32_t* chunk_off, int32_t slot_base,
+                    int32_t q0, int32_t nq, int32_t nch, SegTable& out, hipStream_t st) {
+    if (!st) st = ctx->stream;
+    const size_t np = (size_t)nch * ((size_t)nq + 1);
+    out.ptr.alloc(ctx, np);
+    DevBuf<int32_t> cnt(ctx, np);
+    k_seg_counts<<<grid_for((int64_t)np), 256, 0, st>>>(csc_slot, chunk_off, slot_base, q0, nq, nch, cnt.get());
     FY_KERNEL_CHECK();
+    exclusive_scan_i32(ctx, cnt.get(), out.ptr.get(), np, st);
+    int32_t total = 0;   // the last count is 0 by construction: the last prefix is the total
+    FY_HIP(hipMemcpyAsync(&total, out.ptr.get() + (np - 1), sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    FY_HIP(hipStreamSynchronize(st));
+    out.seg.alloc(ctx, (size_t)total);
+    out.w.alloc(ctx, (size_t)total);
+    if ((int64_t)nch * nq > 0) {
+        k_seg_fill<<<grid_for((int64_t)nch * nq), 256, 0, st>>>(csc_slot, csc_w, chunk_off, slot_base, q0, nq, nch, out.ptr.get(),
+                                                                 out.seg.get(), out.w.get());
+        FY_KERNEL_CHECK();
+    }
 }
 
 // ================================================================ M build: co-rating row kernel + RM2 epilogue
@@ -211,53 +247,72 @@ struct MEpilogue {
     int64_t ldb;
 };
 
-__global__ void k_cooc_rm2(CoocArgs A, MEpilogue E) {
+// Persistent workgroups pull (row, chunk) items from a global counter (rows are in popularity order: heavy items first);
+// the epilogue re-zeroes the accumulators it reads, so an item costs one accumulate phase, one barrier, one epilogue and
+// one barrier -- no dispatch, no separate clearing pass.
+__global__ void k_cooc_rm2(CoocArgs A, MEpilogue E, int n_items, int* __restrict__ next_item) {
     double* acc = fy_cooc_acc;
-    const int row = A.row0 + blockIdx.x / A.nch;
-    const int ch = blockIdx.x % A.nch;
+    __shared__ int sh_item;
     for (int t = threadIdx.x; t < A.CH; t += blockDim.x) acc[t] = 0.0;
-    __syncthreads();
-    cooc_accumulate_row(A, row, ch);
-    __syncthreads();
-    const int c0 = ch * A.CH;
-    // the last chunk also writes the padding columns [Ic, ldm) so the scoring kernel may load whole 256-wide chunks
-    const int c1 = (ch == A.nch - 1) ? (int)E.ldm : min(c0 + A.CH, (int)E.ldm);
-    const double pj = E.p_rank[row];
-    if (E.pack24) {
-        // four columns -> three dwords (c0 and c1 are multiples of 64)
-        uint32_t* __restrict__ out3 = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(E.M) + (int64_t)row * E.ldm * 3);
-        for (int c4 = (c0 >> 2) + threadIdx.x; 4 * c4 < c1; c4 += blockDim.x) {
-            uint32_t v[4];
+    // items are handed out by a global counter: the chunks of a row differ a lot in weight (chunk 0 holds the popular
+    // columns), a static stride would leave three quarters of the workgroups idle behind the chunk-0 owners
+    for (;;) {
+        if (threadIdx.x == 0) sh_item = atomicAdd(next_item, 1);
+        __syncthreads();
+        const int item = sh_item;
+        if (item >= n_items) break;
+        const int row = A.row0 + item / A.nch;
+        const int ch = item % A.nch;
+        if (A.debug != 3) cooc_accumulate_row(A, row, ch);
+        __syncthreads();
+        if (A.debug == 4) continue;   // timing experiment: no epilogue (block-uniform)
+        const int c0 = ch * A.CH;
+        // the last chunk also writes the padding columns [Ic, ldm) so the scoring kernel may load whole 256-wide chunks
+        const int c1 = (ch == A.nch - 1) ? (int)E.ldm : min(c0 + A.CH, (int)E.ldm);
+        const double pj = E.p_rank[row];
+        if (E.pack24) {
+            // four columns -> three dwords (c0 and c1 are multiples of 64)
+            uint32_t* __restrict__ out3 = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(E.M) + (int64_t)row * E.ldm * 3);
+            for (int c4 = (c0 >> 2) + threadIdx.x; 4 * c4 < c1; c4 += blockDim.x) {
+                uint32_t v[4];
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int col = 4 * c4 + q;
-                float f = 0.0f;
-                if (col < A.Ic) f = (float)(E.w2 * acc[col - c0] + E.w1 * pj * E.b_rank[col]);
-                v[q] = ((__float_as_uint(f) << 1) + 0x80u) >> 8;   // M >= 0: drop the sign, keep 8 exponent + 16 mantissa bits, round to nearest
+                for (int q = 0; q < 4; q++) {
+                    const int col = 4 * c4 + q;
+                    float f = 0.0f;
+                    if (col < A.Ic) {
+                        f = (float)(E.w2 * acc[col - c0] + E.w1 * pj * E.b_rank[col]);
+                        acc[col - c0] = 0.0;
+                    }
+                    v[q] = ((__float_as_uint(f) << 1) + 0x80u) >> 8;   // M >= 0: drop the sign, keep 8 exponent + 16 mantissa bits, round to nearest
+                }
+                out3[3 * c4 + 0] = v[0] | (v[1] << 24);
+                out3[3 * c4 + 1] = (v[1] >> 8) | (v[2] << 16);
+                out3[3 * c4 + 2] = (v[2] >> 16) | (v[3] << 8);
+                if (E.Bmax) {
+                    // maximum of the values exactly as the scoring kernel will unpack them; 16 consecutive threads = one
+                    // 64-column block (c0, c1 and the thread index are multiples of 16 groups of 4 columns)
+                    float m = 0.0f;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) m = fmaxf(m, __uint_as_float((v[q] << 8) >> 1));
+                    m = fmaxf(m, __shfl_xor(m, 1, 64));
+                    m = fmaxf(m, __shfl_xor(m, 2, 64));
+                    m = fmaxf(m, __shfl_xor(m, 4, 64));
+                    m = fmaxf(m, __shfl_xor(m, 8, 64));
+                    if ((threadIdx.x & 15) == 0) E.Bmax[(int64_t)row * E.ldb + (c4 >> 4)] = m;
+                }
             }
-            out3[3 * c4 + 0] = v[0] | (v[1] << 24);
-            out3[3 * c4 + 1] = (v[1] >> 8) | (v[2] << 16);
-            out3[3 * c4 + 2] = (v[2] >> 16) | (v[3] << 8);
-            if (E.Bmax) {
-                // maximum of the values exactly as the scoring kernel will unpack them; 16 consecutive threads = one
-                // 64-column block (c0, c1 and the thread index are multiples of 16 groups of 4 columns)
-                float m = 0.0f;
-#pragma unroll
-                for (int q = 0; q < 4; q++) m = fmaxf(m, __uint_as_float((v[q] << 8) >> 1));
-                m = fmaxf(m, __shfl_xor(m, 1, 64));
-                m = fmaxf(m, __shfl_xor(m, 2, 64));
-                m = fmaxf(m, __shfl_xor(m, 4, 64));
-                m = fmaxf(m, __shfl_xor(m, 8, 64));
-                if ((threadIdx.x & 15) == 0) E.Bmax[(int64_t)row * E.ldb + (c4 >> 4)] = m;
+        } else {
+            float* __restrict__ out = E.M + (int64_t)row * E.ldm;
+            for (int col = c0 + threadIdx.x; col < c1; col += blockDim.x) {
+                float v = 0.0f;
+                if (col < A.Ic) {
+                    v = (float)(E.w2 * acc[col - c0] + E.w1 * pj * E.b_rank[col]);
+                    acc[col - c0] = 0.0;
+                }
+                out[col] = v;
             }
         }
-        return;
-    }
-    float* __restrict__ out = E.M + (int64_t)row * E.ldm;
-    for (int col = c0 + threadIdx.x; col < c1; col += blockDim.x) {
-        float v = 0.0f;
-        if (col < A.Ic) v = (float)(E.w2 * acc[col - c0] + E.w1 * pj * E.b_rank[col]);
-        out[col] = v;
+        __syncthreads();   // the accumulators are clean again before the next item's atomics
     }
 }
 
@@ -1044,6 +1099,7 @@ struct ScoreTune {
     int prune = 1;                     // branch and bound over 64-column candidate blocks
     int prune_min_items = 8192;
     int seed_chunks = 4;               // 256-column chunks scored exactly before the bound pass (the most popular candidates)
+    int cooc_debug = 0;                // timing experiments only
     int cooc_block = 0;                // test hook: force the row kernel's workgroup size
     int cooc_max_ch = 16384;           // LDS accumulators of the row kernel (test hook: smaller forces column chunks)
     int hot_lds = 0;                   // k_score_hot: the 128 most popular rows of a chunk stay in LDS (slower: 16 waves/CU)
@@ -1065,6 +1121,7 @@ static ScoreTune score_tune() {
     if (const char* e = getenv("FY_PRUNE_MIN_ITEMS")) t.prune_min_items = atoi(e);
     if (const char* e = getenv("FY_SEED_CHUNKS")) { int v = atoi(e); if (v >= 1 && v <= 4) t.seed_chunks = v; }
     if (const char* e = getenv("FY_LANES")) { int v = atoi(e); if (v >= 1 && v <= 8) t.lanes = v; }
+    if (const char* e = getenv("FY_COOC_DEBUG")) t.cooc_debug = atoi(e);
     if (const char* e = getenv("FY_COOC_BLOCK")) { int v = atoi(e); if (v == 256 || v == 512 || v == 1024) t.cooc_block = v; }
     if (const char* e = getenv("FY_COOC_MAX_CH")) { int v = atoi(e); if (v >= 64 && v <= 16384) t.cooc_max_ch = v; }
     if (const char* e = getenv("FY_HOT_MIN_ITEMS")) t.hot_min_items = atoi(e);
@@ -1267,7 +1324,6 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             hipStream_t st;
             DevBuf<float> M, S;
             DevBuf<int32_t> chunk_off, rb_off, hot_off, overflow, any_overflow;
-            DevBuf<int2> csc_slice;
             // branch and bound
             DevBuf<float> Bmax, amax, UB, tau;
             DevBuf<uint16_t> surv;
@@ -1308,7 +1364,6 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 L.hot_off.alloc(ctx, ho_el);
                 L.overflow.alloc(ctx, ov_el);
                 L.any_overflow.alloc(ctx, 1);
-                L.csc_slice.alloc(ctx, sl_el);
                 L.Bmax.alloc(ctx, bm_el);
                 L.amax.alloc(ctx, am_el);
                 L.UB.alloc(ctx, ub_el);
@@ -1321,6 +1376,18 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
         DevBuf<unsigned long long> prune_counters(ctx, 2);   // [0] surviving blocks, [1] log terms evaluated by the three pruned passes
         prune_counters.zero();
         int64_t prune_blocks_total = 0, prune_seed_terms_cols = 0;
+        // segment tables of the row kernel, one per cluster, built on the main stream before the lanes fork
+        std::vector<SegTable> segs(plans.size());
+        {
+            size_t co_all = 1;
+            for (auto& p : plans) co_all = std::max(co_all, (size_t)p.Uc * (p.nch + 1));
+            DevBuf<int32_t> co_tmp(ctx, co_all);
+            for (size_t pi = 0; pi < plans.size(); pi++) {
+                const Plan& p = plans[pi];
+                build_chunk_offsets(ctx, P.rowptr.get(), P.csr_idx.get(), p.sbase, p.Uc, p.CH, p.nch, co_tmp.get());
+                build_segments(ctx, P.csc_slot.get(), csc_x.get(), co_tmp.get(), p.sbase, p.q0, p.nq, p.nch, segs[pi]);
+            }
+        }
         hipEvent_t fork = nullptr;
         if (NS > 1) {   // the lanes start after everything queued on the main stream so far
             FY_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
@@ -1338,10 +1405,8 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             const bool pack24 = p.pack24;
 
             // -- M build
-            build_chunk_offsets(ctx, P.rowptr.get(), P.csr_idx.get(), sbase, Uc, CH, nch, L.chunk_off.get(), ls);
-            build_csc_slices(ctx, P.csc_slot.get(), L.chunk_off.get(), sbase, p.q0, p.nq, nch, L.csc_slice.get(), ls);
-            CoocArgs CA{P.rank_pair.get(), P.pair_start.get(), P.csc_slot.get(), csc_x.get(), L.csc_slice.get(), P.csr_idx.get(),
-                        csr_x.get(), pbase, sbase, Ic, CH, nch, 0, Ic, p.q0, p.nq};
+            CoocArgs CA{P.rank_pair.get(), P.pair_start.get(), segs[pi].ptr.get(), segs[pi].seg.get(), segs[pi].w.get(), P.csr_idx.get(),
+                        csr_x.get(), pbase, sbase, Ic, CH, nch, 0, Ic, p.q0, p.nq, tune.cooc_debug};
             MEpilogue ME{L.M.get(), ldm, p_rank.get() + pbase, b_rank.get() + pbase, (1.0 - lambda) * (1.0 - lambda), lambda * (1.0 - lambda),
                          pack24 ? 1 : 0, p.prune ? L.Bmax.get() : nullptr, p.ldb};
             if (p.prune) {
@@ -1351,7 +1416,13 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             }
             const int block = tune.cooc_block ? tune.cooc_block : ((CH * 8 > 48 * 1024) ? 1024 : 256);
             const size_t sp = t_cooc.begin(ls);
-            k_cooc_rm2<<<Ic * nch, block, (size_t)CH * 8, ls>>>(CA, ME);
+            {
+                const int n_items = Ic * nch;
+                const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2048 / block, (160 * 1024) / ((size_t)CH * 8 + 1024)));
+                const int grid = std::min(n_items, ctx->num_cus * per_cu);
+                FY_HIP(hipMemsetAsync(L.any_overflow.get(), 0, sizeof(int32_t), ls));   // reused as the item counter
+                k_cooc_rm2<<<grid, block, (size_t)CH * 8, ls>>>(CA, ME, n_items, L.any_overflow.get());
+            }
             FY_KERNEL_CHECK();
             t_cooc.end(sp, ls);
             R->st.cooc_launches++;
