@@ -115,14 +115,17 @@ void build_segments(Context* ctx, const int32_t* csc_slot, const float* csc_w, c
 void build_chunk_offsets(Context* ctx, const int32_t* rowptr, const int32_t* csr_idx, int32_t slot_base, int32_t n_slots,
                          int32_t CH, int32_t nch, int32_t* chunk_off, hipStream_t st = nullptr);
 
-// picks the chunk width for a cluster with Ic items: whole row when it fits the LDS budget
+// picks the chunk width for a cluster with Ic items: whole row when it fits the LDS budget.  Chunks are multiples of 256
+// columns whenever there are several (a wave of the epilogue then owns exactly one 256-column block, fy_rm2.hip).
 inline void pick_chunks(int32_t Ic, int32_t max_ch, int32_t& CH, int32_t& nch) {
     if (Ic <= max_ch) {
         CH = (int32_t)round_up(Ic > 0 ? Ic : 1, 64);
         nch = 1;
     } else {
-        nch = (int32_t)ceil_div(Ic, max_ch);
-        CH = (int32_t)round_up(ceil_div(Ic, nch), 64);
+        const int32_t cap = max_ch >= 256 ? (max_ch / 256) * 256 : max_ch;
+        const int32_t gran = max_ch >= 256 ? 256 : 64;
+        nch = (int32_t)ceil_div(Ic, cap);
+        CH = (int32_t)std::min<int64_t>(cap, round_up(ceil_div(Ic, nch), gran));
         nch = (int32_t)ceil_div(Ic, CH);
     }
 }

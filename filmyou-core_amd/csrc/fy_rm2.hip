@@ -289,16 +289,14 @@ __global__ void k_cooc_rm2(CoocArgs A, MEpilogue E, int n_items, int* __restrict
                 out3[3 * c4 + 1] = (v[1] >> 8) | (v[2] << 16);
                 out3[3 * c4 + 2] = (v[2] >> 16) | (v[3] << 8);
                 if (E.Bmax) {
-                    // maximum of the values exactly as the scoring kernel will unpack them; 16 consecutive threads = one
-                    // 64-column block (c0, c1 and the thread index are multiples of 16 groups of 4 columns)
+                    // maximum of the values exactly as the scoring kernel will unpack them; one wave = one 256-column
+                    // block (c0 and c1 are multiples of 256 when the bound matrix is requested, see pick_chunks)
                     float m = 0.0f;
 #pragma unroll
                     for (int q = 0; q < 4; q++) m = fmaxf(m, __uint_as_float((v[q] << 8) >> 1));
-                    m = fmaxf(m, __shfl_xor(m, 1, 64));
-                    m = fmaxf(m, __shfl_xor(m, 2, 64));
-                    m = fmaxf(m, __shfl_xor(m, 4, 64));
-                    m = fmaxf(m, __shfl_xor(m, 8, 64));
-                    if ((threadIdx.x & 15) == 0) E.Bmax[(int64_t)row * E.ldb + (c4 >> 4)] = m;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+                    if ((threadIdx.x & 63) == 0) E.Bmax[(int64_t)row * E.ldb + (c4 >> 6)] = m;
                 }
             }
         } else {
@@ -642,8 +640,8 @@ struct TopNArgs {
     // list the user gets if no block survives.  mode 2 (merge phase): users with surviving blocks only, seed + survivors.
     int32_t mode;
     int32_t seed_cols;
-    const uint16_t* __restrict__ surv;    // [u * ldb + k]: surviving block ids, quads padded with 0xFFFF
-    const int32_t* __restrict__ n_quads;  // [u]
+    const uint16_t* __restrict__ surv;    // [u * ldb + k]: surviving block ids
+    const int32_t* __restrict__ n_quads;  // [u]: surviving blocks of the user
     int64_t ldb;
     float* __restrict__ tau;              // [u]
 };
@@ -660,6 +658,7 @@ __device__ __forceinline__ float fy_order_unkey(uint32_t k) {
 constexpr int TOPN_MAX = 2048;
 constexpr int TOPN_BINS = 4096;
 constexpr int TOPN_SAMPLE = 1024;
+constexpr int PRUNE_BLOCK_COLS = 256;   // candidate block of the branch and bound = one column chunk
 
 // descending bitonic sort of P2 (power of two) 64-bit keys in LDS; every thread of the block calls it
 __device__ __forceinline__ void fy_bitonic_desc(uint64_t* v, int P2) {
@@ -741,13 +740,12 @@ __global__ __launch_bounds__(256) void k_topn_fast(TopNArgs A, int32_t* __restri
     __syncthreads();
     // stream the rest of the row (mode 2: only the surviving blocks, 16 float4 each)
     const int i4_begin = A.mode == 2 ? 0 : (TOPN_SAMPLE >> 2);
-    const int i4_end = A.mode == 2 ? A.n_quads[u] * 4 * 16 : (A.Ic + 3) >> 2;
+    const int i4_end = A.mode == 2 ? A.n_quads[u] * (PRUNE_BLOCK_COLS / 4) : (A.Ic + 3) >> 2;
     for (int x = i4_begin + tid; x < i4_end; x += blockDim.x) {
         int i4 = x;
         if (A.mode == 2) {
-            const unsigned blk = A.surv[(int64_t)u * A.ldb + (x >> 4)];
-            if (blk == 0xFFFFu) continue;
-            i4 = (int)blk * 16 + (x & 15);
+            const unsigned blk = A.surv[(int64_t)u * A.ldb + (x >> 6)];
+            i4 = (int)blk * (PRUNE_BLOCK_COLS / 4) + (x & 63);
         }
         const float4 f4 = *reinterpret_cast<const float4*>(row + 4 * i4);
         const float fv[4] = {f4.x, f4.y, f4.z, f4.w};
@@ -806,13 +804,13 @@ __global__ __launch_bounds__(256) void k_topn_select(TopNArgs A, const int32_t* 
     if (A.mode) {
         for (int w = tid; w < 2048; w += blockDim.x) live[w] = 0;
         __syncthreads();
-        for (int k = tid; k < A.n_quads[u] * 4; k += blockDim.x) {
+        for (int k = tid; k < A.n_quads[u]; k += blockDim.x) {
             const unsigned blk = A.surv[(int64_t)u * A.ldb + k];
-            if (blk != 0xFFFFu) atomicOr(&live[blk >> 5], 1u << (blk & 31u));
+            atomicOr(&live[blk >> 5], 1u << (blk & 31u));
         }
         __syncthreads();
     }
-#define FY_ROWVAL(i) ((A.mode == 0 || (i) < A.seed_cols || ((live[(i) >> 11] >> (((i) >> 6) & 31)) & 1u)) ? row[(i)] : __builtin_nanf(""))
+#define FY_ROWVAL(i) ((A.mode == 0 || (i) < A.seed_cols || ((live[(i) >> 13] >> (((i) >> 8) & 31)) & 1u)) ? row[(i)] : __builtin_nanf(""))
 
     // ---- radix select: 12 + 10 + 10 bits, most significant first
     uint32_t prefix = 0, prefix_mask = 0, need = (uint32_t)K;
@@ -934,7 +932,7 @@ __global__ __launch_bounds__(256) void k_topn_select(TopNArgs A, const int32_t* 
 // popular) columns, a block whose UB is below tau_u cannot contribute to the user's top N and is skipped; the exact
 // kernel then runs only on the surviving (user, block) pairs.  RM2 scores fall steeply with candidate popularity, so on
 // MovieLens-shaped data well under 1 % of the tail blocks survive -- the lists are bit-for-bit those of the full pass.
-constexpr int PRUNE_BLOCK = 64;
+constexpr int PRUNE_BLOCK = 256;   // = the column chunk of the scoring kernel: a surviving block is one (user, chunk) work item
 
 // block maxima of a = lambda * p
 __global__ void k_block_amax(int32_t Ic, int32_t ldb, const float* __restrict__ a_rank, float* __restrict__ amax) {
@@ -947,7 +945,7 @@ __global__ void k_block_amax(int32_t Ic, int32_t ldb, const float* __restrict__ 
 
 // one wave per user: compact list of the blocks that may still hold a top-N candidate
 __global__ void k_survivors(int32_t n_users, int32_t nblk, int32_t seed_blocks, int64_t ldb, const float* __restrict__ UB,
-                            const float* __restrict__ tau, uint16_t* __restrict__ surv, int32_t* __restrict__ n_quads,
+                            const float* __restrict__ tau, uint16_t* __restrict__ surv, int32_t* __restrict__ n_surv,
                             unsigned long long* __restrict__ counters, const int32_t* __restrict__ rowptr, int32_t slot0,
                             int32_t cols_seed_and_bound) {
     const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
@@ -967,44 +965,39 @@ __global__ void k_survivors(int32_t n_users, int32_t nblk, int32_t seed_blocks, 
             count += __popcll(bal);
         }
         if (lane == 0) {
-            n_quads[u] = (count + 3) >> 2;
+            n_surv[u] = count;
+            const unsigned long long n_u = (unsigned long long)(rowptr[slot0 + u + 1] - rowptr[slot0 + u]);
             if (count) atomicAdd(&counters[0], (unsigned long long)count);
-            // log terms the seed pass and the bound pass evaluated for this user (statistics only)
-            if (t != INFINITY)
-                atomicAdd(&counters[1], (unsigned long long)(rowptr[slot0 + u + 1] - rowptr[slot0 + u]) * (unsigned long long)cols_seed_and_bound);
+            // log terms the three passes evaluate for this user (statistics only)
+            if (t != INFINITY) atomicAdd(&counters[1], n_u * (unsigned long long)(cols_seed_and_bound + count * PRUNE_BLOCK));
         }
-        const int padded = ((count + 3) >> 2) << 2;
-        if (count && lane < padded - count) surv[(int64_t)u * ldb + count + lane] = 0xFFFFu;
     }
 }
 
-// exact scores of the surviving blocks: one wave = one user x four 64-column blocks (16 lanes x 4 columns each)
+// exact scores of the surviving blocks: one wave = one (user, surviving 256-column block), the scoring kernel's work item
 template <int SB>
-__global__ __launch_bounds__(256) void k_score_quads(const float* __restrict__ M_, const float* __restrict__ a_rank_,
-                                                     const int32_t* __restrict__ rowptr_, const int32_t* __restrict__ csr_idx_,
-                                                     const float* __restrict__ csr_e_, const double* __restrict__ pvpi_,
-                                                     const int32_t* __restrict__ quad_prefix_, const uint16_t* __restrict__ surv_,
-                                                     float* __restrict__ S_, ScoreArgs A, int64_t ldb, unsigned long long* counters) {
+__global__ __launch_bounds__(256) void k_score_blocks(const float* __restrict__ M_, const float* __restrict__ a_rank_,
+                                                      const int32_t* __restrict__ rowptr_, const int32_t* __restrict__ csr_idx_,
+                                                      const float* __restrict__ csr_e_, const double* __restrict__ pvpi_,
+                                                      const int32_t* __restrict__ surv_prefix_, const uint16_t* __restrict__ surv_,
+                                                      float* __restrict__ S_, ScoreArgs A, int64_t ldb) {
     const int lane = threadIdx.x & 63;
     const int wave_in_grid = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
     const int n_waves = gridDim.x * (blockDim.x >> 6);
-    const int total = quad_prefix_[A.n_users];
+    const int total = surv_prefix_[A.n_users];
     const int64_t pitch = A.ldm * 3;
     const double LN2 = 0.69314718055994530942;
     const float qnan = __builtin_nanf("");
-    unsigned long long my_terms = 0;
     for (int w = wave_in_grid; w < total; w += n_waves) {
-        int lo = 0, hi = A.n_users;                 // last user with quad_prefix <= w
+        int lo = 0, hi = A.n_users;                 // last user with surv_prefix <= w
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
-            if (quad_prefix_[mid] <= w) lo = mid; else hi = mid;
+            if (surv_prefix_[mid] <= w) lo = mid; else hi = mid;
         }
         const int u = lo;
-        const int q = w - quad_prefix_[u];
         const int slot = A.slot0 + u;
-        const unsigned blk = surv_[(int64_t)u * ldb + 4 * q + (lane >> 4)];
-        const bool live = blk != 0xFFFFu;
-        const int col = (live ? (int)blk : (int)surv_[(int64_t)u * ldb + 4 * q]) * PRUNE_BLOCK + (lane & 15) * 4;
+        const int col0 = (int)surv_[(int64_t)u * ldb + (w - surv_prefix_[u])] * PRUNE_BLOCK;
+        const int col = col0 + lane * 4;
         float a[4];
 #pragma unroll
         for (int v = 0; v < 4; v++) a[v] = col + v < A.Ic ? a_rank_[col + v] : 0.0f;
@@ -1038,18 +1031,14 @@ __global__ __launch_bounds__(256) void k_score_quads(const float* __restrict__ M
 #pragma unroll
             for (int v = 0; v < 4; v++) t[v] += (double)p[v];
         }
-        if (live) {
-            const double base = pvpi_[slot - A.slot_lo];
-            float4 o;
-            o.x = ((mask & 1u) || col + 0 >= A.Ic) ? qnan : (float)(base + LN2 * t[0]);
-            o.y = ((mask & 2u) || col + 1 >= A.Ic) ? qnan : (float)(base + LN2 * t[1]);
-            o.z = ((mask & 4u) || col + 2 >= A.Ic) ? qnan : (float)(base + LN2 * t[2]);
-            o.w = ((mask & 8u) || col + 3 >= A.Ic) ? qnan : (float)(base + LN2 * t[3]);
-            *reinterpret_cast<float4*>(S_ + (int64_t)u * A.ldS + col) = o;
-        }
-        my_terms += (unsigned long long)(end - beg) * 256ull;
+        const double base = pvpi_[slot - A.slot_lo];
+        float4 o;
+        o.x = ((mask & 1u) || col + 0 >= A.Ic) ? qnan : (float)(base + LN2 * t[0]);
+        o.y = ((mask & 2u) || col + 1 >= A.Ic) ? qnan : (float)(base + LN2 * t[1]);
+        o.z = ((mask & 4u) || col + 2 >= A.Ic) ? qnan : (float)(base + LN2 * t[2]);
+        o.w = ((mask & 8u) || col + 3 >= A.Ic) ? qnan : (float)(base + LN2 * t[3]);
+        *reinterpret_cast<float4*>(S_ + (int64_t)u * A.ldS + col) = o;
     }
-    if (lane == 0 && my_terms) atomicAdd(&counters[1], my_terms);
 }
 
 void launch_topn_rows(Context* ctx, hipStream_t st, const float* S, int64_t ldS, int32_t n_cols, int32_t n_rows,
@@ -1095,10 +1084,11 @@ struct ScoreTune {
     int xcd_map = 0;                   // one column chunk per XCD at a time
     int max_slices = 65536;            // user slices (workgroups) per column chunk
     int users_per_wave = 16;           // users a wave of the scoring kernel walks for one column chunk
+    int64_t workspace_default = (int64_t)16 << 30;   // score scratch per batch of users
     int lanes = 4;                     // HIP streams the clusters of one job are spread over
     int prune = 1;                     // branch and bound over 64-column candidate blocks
     int prune_min_items = 8192;
-    int seed_chunks = 4;               // 256-column chunks scored exactly before the bound pass (the most popular candidates)
+    int seed_chunks = 1;               // 256-column chunks scored exactly before the bound pass (the most popular candidates)
     int cooc_debug = 0;                // timing experiments only
     int cooc_block = 0;                // test hook: force the row kernel's workgroup size
     int cooc_max_ch = 16384;           // LDS accumulators of the row kernel (test hook: smaller forces column chunks)
@@ -1120,6 +1110,7 @@ static ScoreTune score_tune() {
     if (const char* e = getenv("FY_PRUNE")) t.prune = atoi(e) != 0;
     if (const char* e = getenv("FY_PRUNE_MIN_ITEMS")) t.prune_min_items = atoi(e);
     if (const char* e = getenv("FY_SEED_CHUNKS")) { int v = atoi(e); if (v >= 1 && v <= 4) t.seed_chunks = v; }
+    if (const char* e = getenv("FY_WORKSPACE_GB")) { long v = atol(e); if (v >= 1) t.workspace_default = (int64_t)v << 30; }
     if (const char* e = getenv("FY_LANES")) { int v = atoi(e); if (v >= 1 && v <= 8) t.lanes = v; }
     if (const char* e = getenv("FY_COOC_DEBUG")) t.cooc_debug = atoi(e);
     if (const char* e = getenv("FY_COOC_BLOCK")) { int v = atoi(e); if (v == 256 || v == 512 || v == 1024) t.cooc_block = v; }
@@ -1271,7 +1262,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
     if (eff_top > TOPN_MAX)
         FY_FAIL(FY_ERR_UNSUPPORTED, "min(numberOfRecommendations, items per cluster) = %d exceeds the top-N kernel limit %d", eff_top, TOPN_MAX);
     if (n_recs > 0 && max_Ic > 0) {
-        const int64_t ws = prm.workspace_bytes > 0 ? prm.workspace_bytes : (int64_t)16 << 30;
+        const int64_t ws = prm.workspace_bytes > 0 ? prm.workspace_bytes : tune.workspace_default;
         const int max_ch_lds = tune.cooc_max_ch;   // fp64 accumulators: 128 KiB of the 160 KiB LDS
         FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cooc_rm2), hipFuncAttributeMaxDynamicSharedMemorySize, max_ch_lds * 8));
         FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_score_hot<true>), hipFuncAttributeMaxDynamicSharedMemorySize, SCORE_HOT_ROWS * 1024));
@@ -1313,7 +1304,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             p.nrb = (int32_t)ceil_div(p.Ic, p.rb_rows);
             if (p.nrb <= 1) { p.nrb = 1; p.rb_rows = p.Ic; }
             p.use_hot = tune.hot_lds && VEC == 4 && p.nrb == 1 && p.Ic >= tune.hot_min_items;
-            // branch-and-bound over 64-column blocks: only where the matrix is big enough for the bound pass to pay
+            // branch-and-bound over 256-column blocks: only where the matrix is big enough for the bound pass to pay
             p.nblk = (int32_t)ceil_div(p.Ic, PRUNE_BLOCK);
             p.ldb = round_up(p.nblk, 256);
             p.prune = tune.prune && p.pack24 && p.nrb == 1 && !p.use_hot && p.Ic >= tune.prune_min_items && p.nblk < 0xFFFF;
@@ -1451,7 +1442,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 }
                 if (p.prune) {
                     const int seed_chunks = std::min(n_chunks, tune.seed_chunks);
-                    const int seed_blocks = seed_chunks * 4;
+                    const int seed_blocks = seed_chunks;
                     // only the seed columns and the surviving blocks of a score row are ever written or read
                     // (1) exact scores of the seed columns (the most popular candidates)
                     ScoreArgs SA{L.M.get(), ldm, Ic, a_rank.get() + pbase, L.rb_off.get(), P.csr_idx.get(), csr_e.get(), pvpi.get(),
@@ -1470,7 +1461,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                                   n_out.get(), lo, sbase, s0, nb, L.UB.get(), p.ldb, n_slices, 0, 1, 0, 0, bchunks, 1};
                     k_score<4, false, 8><<<bchunks * n_slices, 256, 0, ls>>>(SB_.M, SB_.a_rank, SB_.rb_off, SB_.csr_idx, SB_.csr_e, SB_.pvpi, SB_.n_out, SB_.S, SB_);
                     FY_KERNEL_CHECK();
-                    // (4) surviving blocks, four per wave
+                    // (4) surviving blocks
                     FY_HIP(hipMemsetAsync(L.n_quads.get() + nb, 0, sizeof(int32_t), ls));
                     k_survivors<<<grid_for((int64_t)nb * 64, 256), 256, 0, ls>>>(nb, p.nblk, seed_blocks, p.ldb, L.UB.get(), L.tau.get(), L.surv.get(),
                                                                                  L.n_quads.get(), prune_counters.get(), P.rowptr.get(), s0,
@@ -1480,8 +1471,8 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                     // (5) exact scores of the survivors
                     ScoreArgs SQ{L.M.get(), ldm, Ic, a_rank.get() + pbase, L.rb_off.get(), P.csr_idx.get(), csr_e.get(), pvpi.get(),
                                  n_out.get(), lo, sbase, s0, nb, L.S.get(), ldS, n_slices, 0, 1, 0, 0, n_chunks, 0};
-                    k_score_quads<8><<<ctx->num_cus * 8, 256, 0, ls>>>(SQ.M, SQ.a_rank, P.rowptr.get(), SQ.csr_idx, SQ.csr_e, SQ.pvpi,
-                                                                       L.quad_prefix.get(), L.surv.get(), SQ.S, SQ, p.ldb, prune_counters.get());
+                    k_score_blocks<8><<<ctx->num_cus * 8, 256, 0, ls>>>(SQ.M, SQ.a_rank, P.rowptr.get(), SQ.csr_idx, SQ.csr_e, SQ.pvpi,
+                                                                        L.quad_prefix.get(), L.surv.get(), SQ.S, SQ, p.ldb);
                     FY_KERNEL_CHECK();
                     R->st.score_launches += 3;
                     prune_blocks_total += (int64_t)nb * std::max(0, p.nblk - seed_blocks);
