@@ -161,7 +161,15 @@ __global__ void k_slot_keys(int32_t nU, const int32_t* __restrict__ ucluster, co
     for (int32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < nU; u += gridDim.x * blockDim.x) {
         keys[u] = ((uint64_t)(uint32_t)ucluster[u] << 32) | (0xFFFFFFFFu - (uint32_t)udeg[u]);
         vals[u] = (uint32_t)u;
-        atomicAdd(&csize[ucluster[u]], 1);
+        // one atomic per wave when the whole wave sits in one cluster (always, with a single cluster)
+        const int c = ucluster[u];
+        const int c0 = __shfl(c, __ffsll((long long)__ballot(1)) - 1, 64);
+        const unsigned long long same = __ballot(c == c0);
+        if (same == __ballot(1)) {
+            if ((threadIdx.x & 63) == __ffsll((long long)same) - 1) atomicAdd(&csize[c0], (int)__popcll(same));
+        } else {
+            atomicAdd(&csize[c], 1);
+        }
     }
 }
 

@@ -29,13 +29,20 @@ static inline int grid_for(int64_t n, int block = 256, int cap = 256 * 16) {
 }
 
 // ================================================================ statistics (jobs RM2-1 / RM2-2)
-// this rank's partial per-item sums: sum of (double) score over the ratings of the users in [lo, hi)
-__global__ void k_partial_item_sums(int64_t nnz, const int32_t* __restrict__ csc_slot, const int32_t* __restrict__ csc_pair,
+// this rank's partial per-item sums: sum of (double) score over the ratings of the users in [lo, hi).  One wave per
+// (cluster, item) column of the CSC, one atomic per column (a per-rating atomic version spent 4 ms on the popular items).
+__global__ void k_partial_item_sums(int32_t nP, const int32_t* __restrict__ pair_start, const int32_t* __restrict__ csc_slot,
                                     const float* __restrict__ csc_r, const int32_t* __restrict__ pair_di, int32_t lo,
                                     int32_t hi, double* __restrict__ partial) {
-    for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < nnz; q += (int64_t)gridDim.x * blockDim.x) {
-        const int32_t s = csc_slot[q];
-        if (s >= lo && s < hi) atomicAdd(&partial[pair_di[csc_pair[q]]], (double)csc_r[q]);
+    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    for (int32_t p = blockIdx.x * wpb + (threadIdx.x >> 6); p < nP; p += gridDim.x * wpb) {
+        double s = 0.0;
+        for (int32_t q = pair_start[p] + lane; q < pair_start[p + 1]; q += 64) {
+            const int32_t slot = csc_slot[q];
+            if (slot >= lo && slot < hi) s += (double)csc_r[q];
+        }
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+        if (lane == 0 && s != 0.0) atomicAdd(&partial[pair_di[p]], s);
     }
 }
 
@@ -348,6 +355,11 @@ struct ScoreArgs {
     int32_t xcd_map;                       // 1: workgroup b works on chunk 8 * (b / 8 / n_slices) + b % 8 (one chunk per XCD at a time)
     int32_t n_chunks;
     int32_t no_mask;                       // 1: the columns are not items (bound pass over block maxima): no "already rated" mask
+    // bound pass only: blocks whose upper bound reaches tau_u are appended to the user's survivor list instead of being stored
+    const float* __restrict__ tau;         // [u]
+    uint16_t* __restrict__ surv;           // [u * ldS + k]
+    int32_t* __restrict__ n_surv;          // [u], zeroed before the launch
+    int32_t seed_blocks;
 };
 
 __device__ __forceinline__ float fy_log2(float x) { return __builtin_amdgcn_logf(x); }   // v_log_f32
@@ -495,6 +507,31 @@ __global__ __launch_bounds__(256) void k_score(const float* __restrict__ M_, con
 #pragma unroll
         for (int v = 0; v < VEC; v++)
             if ((mask >> v) & 1u || col + v >= A.Ic) ov[v] = qnan;
+        if (A.no_mask) {
+            // bound pass: column = candidate block.  Keep the blocks behind the seed whose bound (plus a margin over the
+            // rounding of both sums, each accurate to ~1e-7 relative) reaches tau_u.
+            const float t = A.tau[u];
+            int base = 0;
+            int mine[VEC];
+            unsigned long long bal[VEC];
+#pragma unroll
+            for (int v = 0; v < VEC; v++) {
+                const bool keep = (ov[v] == ov[v]) && (col + v >= A.seed_blocks) && t != INFINITY &&
+                                  (ov[v] + (1e-5f * fabsf(ov[v]) + 1e-4f) >= t);
+                bal[v] = __ballot(keep);
+                mine[v] = keep ? base + __popcll(bal[v] & ((1ull << lane) - 1ull)) : -1;
+                base += __popcll(bal[v]);
+            }
+            if (base > 0) {   // wave-uniform
+                int at = 0;
+                if (lane == 0) at = atomicAdd(&A.n_surv[u], base);
+                at = __builtin_amdgcn_readfirstlane(at);
+#pragma unroll
+                for (int v = 0; v < VEC; v++)
+                    if (mine[v] >= 0) A.surv[(int64_t)u * A.ldS + at + mine[v]] = (uint16_t)(col + v);
+            }
+            continue;
+        }
         *reinterpret_cast<V*>(dst) = o;
     }
 }
@@ -707,7 +744,9 @@ __global__ __launch_bounds__(256) void k_topn_fast(TopNArgs A, int32_t* __restri
     if (tid == 0) sh_nvalid = 0;
     __syncthreads();
     int myvalid = 0;
-    for (int i = tid; i < TOPN_SAMPLE; i += blockDim.x) {
+    int LP2 = 64;                      // sort only as much as the sample needs
+    while (LP2 < Ls) LP2 <<= 1;
+    for (int i = tid; i < LP2; i += blockDim.x) {
         uint64_t c = 0ull;
         if (i < Ls) {
             const float f = row[i];
@@ -717,7 +756,7 @@ __global__ __launch_bounds__(256) void k_topn_fast(TopNArgs A, int32_t* __restri
     }
     if (myvalid) atomicAdd(&sh_nvalid, (uint32_t)myvalid);
     __syncthreads();
-    fy_bitonic_desc(cand, TOPN_SAMPLE);
+    fy_bitonic_desc(cand, LP2);
     const int nvalid = (int)sh_nvalid;
     const uint32_t tau = nvalid >= K ? (uint32_t)(cand[K - 1] >> 32) : 0u;   // valid keys are > 0
     const int keep = min(K, nvalid);
@@ -943,44 +982,14 @@ __global__ void k_block_amax(int32_t Ic, int32_t ldb, const float* __restrict__ 
     }
 }
 
-// one wave per user: compact list of the blocks that may still hold a top-N candidate
-__global__ void k_survivors(int32_t n_users, int32_t nblk, int32_t seed_blocks, int64_t ldb, const float* __restrict__ UB,
-                            const float* __restrict__ tau, uint16_t* __restrict__ surv, int32_t* __restrict__ n_surv,
-                            unsigned long long* __restrict__ counters, const int32_t* __restrict__ rowptr, int32_t slot0,
-                            int32_t cols_seed_and_bound) {
-    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
-    for (int32_t u = blockIdx.x * wpb + (threadIdx.x >> 6); u < n_users; u += gridDim.x * wpb) {
-        const float t = tau[u];
-        int count = 0;
-        for (int base = seed_blocks; base < nblk && t != INFINITY; base += 64) {
-            const int b = base + lane;
-            bool keep = false;
-            if (b < nblk) {
-                const float ub = UB[(int64_t)u * ldb + b];
-                // safety margin over the rounding of both sums (each is accurate to ~1e-7 relative)
-                keep = ub + (1e-5f * fabsf(ub) + 1e-4f) >= t;
-            }
-            const unsigned long long bal = __ballot(keep);
-            if (keep) surv[(int64_t)u * ldb + count + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)b;
-            count += __popcll(bal);
-        }
-        if (lane == 0) {
-            n_surv[u] = count;
-            const unsigned long long n_u = (unsigned long long)(rowptr[slot0 + u + 1] - rowptr[slot0 + u]);
-            if (count) atomicAdd(&counters[0], (unsigned long long)count);
-            // log terms the three passes evaluate for this user (statistics only)
-            if (t != INFINITY) atomicAdd(&counters[1], n_u * (unsigned long long)(cols_seed_and_bound + count * PRUNE_BLOCK));
-        }
-    }
-}
-
 // exact scores of the surviving blocks: one wave = one (user, surviving 256-column block), the scoring kernel's work item
 template <int SB>
 __global__ __launch_bounds__(256) void k_score_blocks(const float* __restrict__ M_, const float* __restrict__ a_rank_,
                                                       const int32_t* __restrict__ rowptr_, const int32_t* __restrict__ csr_idx_,
                                                       const float* __restrict__ csr_e_, const double* __restrict__ pvpi_,
                                                       const int32_t* __restrict__ surv_prefix_, const uint16_t* __restrict__ surv_,
-                                                      float* __restrict__ S_, ScoreArgs A, int64_t ldb) {
+                                                      float* __restrict__ S_, ScoreArgs A, int64_t ldb,
+                                                      unsigned long long* __restrict__ counters) {
     const int lane = threadIdx.x & 63;
     const int wave_in_grid = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
     const int n_waves = gridDim.x * (blockDim.x >> 6);
@@ -988,6 +997,8 @@ __global__ __launch_bounds__(256) void k_score_blocks(const float* __restrict__ 
     const int64_t pitch = A.ldm * 3;
     const double LN2 = 0.69314718055994530942;
     const float qnan = __builtin_nanf("");
+    unsigned long long my_terms = 0;
+    if (wave_in_grid == 0 && lane == 0 && total) atomicAdd(&counters[0], (unsigned long long)total);
     for (int w = wave_in_grid; w < total; w += n_waves) {
         int lo = 0, hi = A.n_users;                 // last user with surv_prefix <= w
         while (hi - lo > 1) {
@@ -1038,7 +1049,9 @@ __global__ __launch_bounds__(256) void k_score_blocks(const float* __restrict__ 
         o.z = ((mask & 4u) || col + 2 >= A.Ic) ? qnan : (float)(base + LN2 * t[2]);
         o.w = ((mask & 8u) || col + 3 >= A.Ic) ? qnan : (float)(base + LN2 * t[3]);
         *reinterpret_cast<float4*>(S_ + (int64_t)u * A.ldS + col) = o;
+        my_terms += (unsigned long long)(end - beg) * 256ull;
     }
+    if (lane == 0 && my_terms) atomicAdd(&counters[1], my_terms);
 }
 
 void launch_topn_rows(Context* ctx, hipStream_t st, const float* S, int64_t ldS, int32_t n_cols, int32_t n_rows,
@@ -1088,7 +1101,7 @@ struct ScoreTune {
     int lanes = 4;                     // HIP streams the clusters of one job are spread over
     int prune = 1;                     // branch and bound over 64-column candidate blocks
     int prune_min_items = 8192;
-    int seed_chunks = 1;               // 256-column chunks scored exactly before the bound pass (the most popular candidates)
+    int seed_chunks = 2;               // 256-column chunks scored exactly before the bound pass (the most popular candidates)
     int cooc_debug = 0;                // timing experiments only
     int cooc_block = 0;                // test hook: force the row kernel's workgroup size
     int cooc_max_ch = 16384;           // LDS accumulators of the row kernel (test hook: smaller forces column chunks)
@@ -1147,8 +1160,8 @@ fy_rm2_job* fy::rm2_prepare(Context* ctx, const fy_rm2_params* prm, const fy_rat
     if (P.nnz > 0) {
         DevBuf<unsigned long long> counter(ctx, 1);
         counter.zero();
-        k_partial_item_sums<<<grid_for(P.nnz), 256, 0, ctx->stream>>>(P.nnz, P.csc_slot.get(), P.csc_pair.get(), P.csc_r.get(),
-                                                                      P.pair_di.get(), J->slot_lo, J->slot_hi, J->partial.get());
+        k_partial_item_sums<<<grid_for((int64_t)P.nP * 64, 256), 256, 0, ctx->stream>>>(P.nP, P.pair_start.get(), P.csc_slot.get(), P.csc_r.get(),
+                                                                                        P.pair_di.get(), J->slot_lo, J->slot_hi, J->partial.get());
         FY_KERNEL_CHECK();
         if (J->slot_hi > J->slot_lo) {
             k_partial_total<<<grid_for(J->slot_hi - J->slot_lo), 256, 0, ctx->stream>>>(J->slot_lo, J->slot_hi, P.slot2du.get(),
@@ -1433,7 +1446,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                     // one 16-wave workgroup per CU (128 KiB of LDS); every wave gets >= 8 users to amortise the tile load
                     const int hs = (int)std::max<int64_t>(1, std::min<int64_t>(256, ceil_div(nb, 16 * 8)));
                     ScoreArgs SA{L.M.get(), ldm, Ic, a_rank.get() + pbase, L.hot_off.get(), P.csr_idx.get(), csr_e.get(), pvpi.get(),
-                                 n_out.get(), lo, sbase, s0, nb, L.S.get(), ldS, hs, 0, 1, 0, 0, 0, 0};
+                                 n_out.get(), lo, sbase, s0, nb, L.S.get(), ldS, hs, 0, 1, 0, 0, 0, 0, nullptr, nullptr, nullptr, 0};
                     const size_t lds = (size_t)SCORE_HOT_ROWS * 1024;
                     if (pack24) k_score_hot<true><<<(int)(ldm / 256) * hs, 1024, lds, ls>>>(SA.M, SA.a_rank, SA.rb_off, SA.csr_idx, SA.csr_e, SA.pvpi, SA.n_out, SA.S, SA);
                     else k_score_hot<false><<<(int)(ldm / 256) * hs, 1024, lds, ls>>>(SA.M, SA.a_rank, SA.rb_off, SA.csr_idx, SA.csr_e, SA.pvpi, SA.n_out, SA.S, SA);
@@ -1446,7 +1459,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                     // only the seed columns and the surviving blocks of a score row are ever written or read
                     // (1) exact scores of the seed columns (the most popular candidates)
                     ScoreArgs SA{L.M.get(), ldm, Ic, a_rank.get() + pbase, L.rb_off.get(), P.csr_idx.get(), csr_e.get(), pvpi.get(),
-                                 n_out.get(), lo, sbase, s0, nb, L.S.get(), ldS, n_slices, 0, 1, 0, 0, seed_chunks, 0};
+                                 n_out.get(), lo, sbase, s0, nb, L.S.get(), ldS, n_slices, 0, 1, 0, 0, seed_chunks, 0, nullptr, nullptr, nullptr, 0};
                     k_score<4, true, 8><<<seed_chunks * n_slices, 256, 0, ls>>>(SA.M, SA.a_rank, SA.rb_off, SA.csr_idx, SA.csr_e, SA.pvpi, SA.n_out, SA.S, SA);
                     FY_KERNEL_CHECK();
                     // (2) tau_u = N-th best seed score; the sorted seed head is also the user's list unless a block survives
@@ -1457,30 +1470,33 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                     FY_KERNEL_CHECK();
                     // (3) upper bounds of all 64-column blocks: the scoring kernel on the block-maximum matrix
                     const int bchunks = (int)(p.ldb / 256);
+                    FY_HIP(hipMemsetAsync(L.n_quads.get(), 0, ((size_t)nb + 1) * sizeof(int32_t), ls));
                     ScoreArgs SB_{L.Bmax.get(), p.ldb, p.nblk, L.amax.get(), L.rb_off.get(), P.csr_idx.get(), csr_e.get(), pvpi.get(),
-                                  n_out.get(), lo, sbase, s0, nb, L.UB.get(), p.ldb, n_slices, 0, 1, 0, 0, bchunks, 1};
+                                  n_out.get(), lo, sbase, s0, nb, L.UB.get(), p.ldb, n_slices, 0, 1, 0, 0, bchunks, 1,
+                                  L.tau.get(), L.surv.get(), L.n_quads.get(), seed_blocks};
                     k_score<4, false, 8><<<bchunks * n_slices, 256, 0, ls>>>(SB_.M, SB_.a_rank, SB_.rb_off, SB_.csr_idx, SB_.csr_e, SB_.pvpi, SB_.n_out, SB_.S, SB_);
                     FY_KERNEL_CHECK();
-                    // (4) surviving blocks
-                    FY_HIP(hipMemsetAsync(L.n_quads.get() + nb, 0, sizeof(int32_t), ls));
-                    k_survivors<<<grid_for((int64_t)nb * 64, 256), 256, 0, ls>>>(nb, p.nblk, seed_blocks, p.ldb, L.UB.get(), L.tau.get(), L.surv.get(),
-                                                                                 L.n_quads.get(), prune_counters.get(), P.rowptr.get(), s0,
-                                                                                 seed_chunks * 256 + (int32_t)p.ldb);
-                    FY_KERNEL_CHECK();
+                    // (4) the bound pass appended the surviving blocks to surv / n_quads itself
                     exclusive_scan_i32(ctx, L.n_quads.get(), L.quad_prefix.get(), (size_t)nb + 1, ls);
                     // (5) exact scores of the survivors
                     ScoreArgs SQ{L.M.get(), ldm, Ic, a_rank.get() + pbase, L.rb_off.get(), P.csr_idx.get(), csr_e.get(), pvpi.get(),
-                                 n_out.get(), lo, sbase, s0, nb, L.S.get(), ldS, n_slices, 0, 1, 0, 0, n_chunks, 0};
+                                 n_out.get(), lo, sbase, s0, nb, L.S.get(), ldS, n_slices, 0, 1, 0, 0, n_chunks, 0, nullptr, nullptr, nullptr, 0};
                     k_score_blocks<8><<<ctx->num_cus * 8, 256, 0, ls>>>(SQ.M, SQ.a_rank, P.rowptr.get(), SQ.csr_idx, SQ.csr_e, SQ.pvpi,
-                                                                        L.quad_prefix.get(), L.surv.get(), SQ.S, SQ, p.ldb);
+                                                                        L.quad_prefix.get(), L.surv.get(), SQ.S, SQ, p.ldb, prune_counters.get());
                     FY_KERNEL_CHECK();
                     R->st.score_launches += 3;
                     prune_blocks_total += (int64_t)nb * std::max(0, p.nblk - seed_blocks);
-                    prune_seed_terms_cols += (int64_t)(seed_chunks * 256 + p.ldb);
+                    {   // log terms of the seed and bound passes of this batch: (ratings of its users) x (columns walked)
+                        int32_t r2[2];
+                        d2h(ctx, &r2[0], P.rowptr.get() + s0, 1);
+                        d2h(ctx, &r2[1], P.rowptr.get() + s0 + nb, 1);
+                        sync(ctx);
+                        prune_seed_terms_cols += (int64_t)(r2[1] - r2[0]) * (seed_chunks * 256 + p.ldb);
+                    }
                 }
                 for (int32_t rb = 0; rb < ((use_hot || p.prune) ? 0 : nrb); rb++) {
                     ScoreArgs SA{L.M.get(), ldm, Ic, a_rank.get() + pbase, L.rb_off.get(), P.csr_idx.get(), csr_e.get(), pvpi.get(),
-                                 n_out.get(), lo, sbase, s0, nb, L.S.get(), ldS, n_slices, rb, nrb, tune.nt_rows, tune.xcd_map, n_chunks, 0};
+                                 n_out.get(), lo, sbase, s0, nb, L.S.get(), ldS, n_slices, rb, nrb, tune.nt_rows, tune.xcd_map, n_chunks, 0, nullptr, nullptr, nullptr, 0};
 #define FY_LAUNCH_SCORE(V_, P_, B_) k_score<V_, P_, B_><<<(tune.xcd_map ? (int)round_up(n_chunks, 8) : n_chunks) * n_slices, 256, 0, ls>>>(SA.M, SA.a_rank, SA.rb_off, SA.csr_idx, SA.csr_e, SA.pvpi, SA.n_out, SA.S, SA)
                     if (pack24 && tune.batch == 16) FY_LAUNCH_SCORE(4, true, 16);
                     else if (pack24 && tune.batch == 12) FY_LAUNCH_SCORE(4, true, 12);
@@ -1523,8 +1539,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             sync(ctx);
             R->st.blocks_survived = (int64_t)hc[0];
             R->st.blocks_total = prune_blocks_total;
-            R->st.log_terms_evaluated = (int64_t)hc[1];
-            (void)prune_seed_terms_cols;
+            R->st.log_terms_evaluated = prune_blocks_total ? (int64_t)hc[1] + prune_seed_terms_cols : 0;
         }
     }
     // rm2/userSum and rm2/itemColl stay in HBM until somebody asks for them
