@@ -21,7 +21,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
 SYMBOLS = [
     "fy_abi_version", "fy_last_error", "fy_context_create", "fy_context_destroy", "fy_context_synchronize",
     "fy_context_stream", "fy_ratings_create", "fy_ratings_destroy", "fy_ratings_nnz", "fy_rm2_prepare",
-    "fy_rm2_partial_stats", "fy_rm2_set_global_stats", "fy_rm2_score", "fy_rm2_job_destroy", "fy_rm2_run",
+    "fy_rm2_partial_stats", "fy_rm2_set_global_stats", "fy_rm2_set_collectives", "fy_rm2_score", "fy_rm2_job_destroy", "fy_rm2_run",
     "fy_itemsim_build", "fy_itemsim_run", "fy_itemcf_recommend", "fy_result_size", "fy_result_key0", "fy_result_key1", "fy_result_value",
     "fy_result_aux", "fy_result_n_users", "fy_result_user_id", "fy_result_user_sum", "fy_result_n_items",
     "fy_result_item_id", "fy_result_item_coll", "fy_result_total_sum", "fy_result_free", "fy_result_stats",
@@ -72,6 +72,15 @@ class RM2Params(C.Structure):
     _fields_ = [("lambda_", C.c_double), ("number_of_items", C.c_int32), ("number_of_recommendations", C.c_int32),
                 ("filter_users", C.c_int32), ("number_of_clusters", C.c_int32), ("rank", C.c_int32),
                 ("world", C.c_int32), ("flags", C.c_uint32), ("workspace_bytes", C.c_int64)]
+
+
+# fy_collectives: RCCL-shaped callbacks (device pointers, hipStream_t), see include/filmyou.h
+ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+REDUCE_SCATTER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+
+
+class Collectives(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("all_gather", ALL_GATHER_FN), ("reduce_scatter_f32", REDUCE_SCATTER_FN)]
 
 
 class ItemSimParams(C.Structure):
@@ -127,6 +136,7 @@ def load():
     L.fy_rm2_prepare.argtypes = [vp, C.POINTER(RM2Params), vp, i64, vp, vp, vp, pvp]
     L.fy_rm2_partial_stats.argtypes = [vp, pvp, C.POINTER(i64)]
     L.fy_rm2_set_global_stats.argtypes = [vp, vp, i32]
+    L.fy_rm2_set_collectives.argtypes = [vp, C.POINTER(Collectives)]
     L.fy_rm2_score.argtypes = [vp, pvp]
     L.fy_rm2_job_destroy.argtypes = [vp]
     L.fy_rm2_job_destroy.restype = None

@@ -147,6 +147,13 @@ int fy_rm2_set_global_stats(fy_rm2_job* j, const double* gathered_device, int32_
     FY_CATCH
 }
 
+int fy_rm2_set_collectives(fy_rm2_job* j, const fy_collectives* c) {
+    if (!j || !c) { set_error("NULL argument"); return FY_ERR_INVALID_ARGUMENT; }
+    FY_TRY
+    fy::rm2_set_collectives(j, c);
+    FY_CATCH
+}
+
 int fy_rm2_score(fy_rm2_job* j, fy_result** out) {
     if (!out) { set_error("out is NULL"); return FY_ERR_INVALID_ARGUMENT; }
     *out = nullptr;

@@ -189,13 +189,25 @@ void build_chunk_offsets(Context* ctx, const int32_t* rowptr, const int32_t* csr
 }
 
 // ---- segment table (fy_cooc.hpp): counts, exclusive prefix, fill
+// rows: optional filter (cooperative multi-rank build): only the CSC entries of item rows [row0, row1) get segments
+struct SegRows {
+    const int32_t* __restrict__ csc_pair;
+    const int32_t* __restrict__ pair_rank;
+    int32_t row0, row1;
+};
+__device__ __forceinline__ bool fy_seg_row_ok(const SegRows& F, int32_t q) {
+    if (!F.csc_pair) return true;
+    const int32_t r = F.pair_rank[F.csc_pair[q]];
+    return r >= F.row0 && r < F.row1;
+}
+
 __global__ void k_seg_counts(const int32_t* __restrict__ csc_slot, const int32_t* __restrict__ chunk_off, int32_t slot_base,
-                             int32_t q0, int32_t nq, int32_t nch, int32_t* __restrict__ cnt) {
+                             int32_t q0, int32_t nq, int32_t nch, int32_t* __restrict__ cnt, SegRows F) {
     const int64_t total = (int64_t)nch * (nq + 1);
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
         const int32_t ch = (int32_t)(t / (nq + 1)), q = (int32_t)(t % (nq + 1));
         int32_t n = 0;
-        if (q < nq) {
+        if (q < nq && fy_seg_row_ok(F, q0 + q)) {
             const int32_t* co = chunk_off + (int64_t)(csc_slot[q0 + q] - slot_base) * (nch + 1) + ch;
             n = (co[1] - co[0] + 63) >> 6;
         }
@@ -205,10 +217,11 @@ __global__ void k_seg_counts(const int32_t* __restrict__ csc_slot, const int32_t
 
 __global__ void k_seg_fill(const int32_t* __restrict__ csc_slot, const float* __restrict__ csc_w, const int32_t* __restrict__ chunk_off,
                            int32_t slot_base, int32_t q0, int32_t nq, int32_t nch, const int32_t* __restrict__ ptr,
-                           int2* __restrict__ seg, float* __restrict__ seg_w) {
+                           int2* __restrict__ seg, float* __restrict__ seg_w, SegRows F) {
     const int64_t total = (int64_t)nch * nq;
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
         const int32_t ch = (int32_t)(t / nq), q = (int32_t)(t % nq);
+        if (!fy_seg_row_ok(F, q0 + q)) continue;
         const int32_t* co = chunk_off + (int64_t)(csc_slot[q0 + q] - slot_base) * (nch + 1) + ch;
         const int32_t f0 = co[0], len = co[1] - f0;
         const float w = csc_w[q0 + q];
@@ -221,12 +234,14 @@ __global__ void k_seg_fill(const int32_t* __restrict__ csc_slot, const float* __
 }
 
 void build_segments(Context* ctx, const int32_t* csc_slot, const float* csc_w, const int32_t* chunk_off, int32_t slot_base,
-                    int32_t q0, int32_t nq, int32_t nch, SegTable& out, hipStream_t st) {
+                    int32_t q0, int32_t nq, int32_t nch, SegTable& out, hipStream_t st, const int32_t* csc_pair,
+                    const int32_t* pair_rank, int32_t row0, int32_t row1) {
     if (!st) st = ctx->stream;
+    const SegRows F{csc_pair, pair_rank, row0, row1};
     const size_t np = (size_t)nch * ((size_t)nq + 1);
     out.ptr.alloc(ctx, np);
     DevBuf<int32_t> cnt(ctx, np);
-    k_seg_counts<<<grid_for((int64_t)np), 256, 0, st>>>(csc_slot, chunk_off, slot_base, q0, nq, nch, cnt.get());
+    k_seg_counts<<<grid_for((int64_t)np), 256, 0, st>>>(csc_slot, chunk_off, slot_base, q0, nq, nch, cnt.get(), F);
     FY_KERNEL_CHECK();
     exclusive_scan_i32(ctx, cnt.get(), out.ptr.get(), np, st);
     int32_t total = 0;   // the last count is 0 by construction: the last prefix is the total
@@ -236,7 +251,7 @@ void build_segments(Context* ctx, const int32_t* csc_slot, const float* csc_w, c
     out.w.alloc(ctx, (size_t)total);
     if ((int64_t)nch * nq > 0) {
         k_seg_fill<<<grid_for((int64_t)nch * nq), 256, 0, st>>>(csc_slot, csc_w, chunk_off, slot_base, q0, nq, nch, out.ptr.get(),
-                                                                 out.seg.get(), out.w.get());
+                                                                 out.seg.get(), out.w.get(), F);
         FY_KERNEL_CHECK();
     }
 }
@@ -354,7 +369,8 @@ struct ScoreArgs {
     int32_t nt_rows;                       // rows with index >= nt_rows are loaded non-temporally (0 = never)
     int32_t xcd_map;                       // 1: workgroup b works on chunk 8 * (b / 8 / n_slices) + b % 8 (one chunk per XCD at a time)
     int32_t n_chunks;
-    int32_t no_mask;                       // 1: the columns are not items (bound pass over block maxima): no "already rated" mask
+    int32_t no_mask;                       // 1: the columns are not items (bound pass over block maxima): no "already rated" mask;
+                                           // 2: the same, but the (partial) bounds are stored like scores (cooperative ranks)
     // bound pass only: blocks whose upper bound reaches tau_u are appended to the user's survivor list instead of being stored
     const float* __restrict__ tau;         // [u]
     uint16_t* __restrict__ surv;           // [u * ldS + k]
@@ -410,6 +426,15 @@ __device__ __forceinline__ void fy_unpack24(const U3& d, float* f) {
     f[1] = __uint_as_float(__builtin_amdgcn_perm(d.b, d.a, 0x0504030cu) >> 1);
     f[2] = __uint_as_float(__builtin_amdgcn_perm(d.c, d.b, 0x0403020cu) >> 1);
     f[3] = __uint_as_float(__builtin_amdgcn_perm(0u, d.c, 0x0302010cu) >> 1);
+}
+
+// Does a block with upper bound `ub` have to be scored exactly for a user whose N-th best seed score is `tau`?
+// tau = +inf: the user emits nothing; tau = -inf: fewer than N finite seed scores, nothing can be excluded (ties at -inf
+// are broken by item id, so even a block of -inf scores may contribute).  The margin covers the rounding of both sums.
+__device__ __forceinline__ bool fy_bound_keeps(float ub, float tau) {
+    if (!(ub == ub) || tau == INFINITY) return false;
+    if (tau == -INFINITY) return true;
+    return ub + (1e-5f * fabsf(ub) + 1e-4f) >= tau;
 }
 
 template <int VEC, bool P24, int SB>
@@ -507,7 +532,7 @@ __global__ __launch_bounds__(256) void k_score(const float* __restrict__ M_, con
 #pragma unroll
         for (int v = 0; v < VEC; v++)
             if ((mask >> v) & 1u || col + v >= A.Ic) ov[v] = qnan;
-        if (A.no_mask) {
+        if (A.no_mask == 1) {
             // bound pass: column = candidate block.  Keep the blocks behind the seed whose bound (plus a margin over the
             // rounding of both sums, each accurate to ~1e-7 relative) reaches tau_u.
             const float t = A.tau[u];
@@ -516,8 +541,7 @@ __global__ __launch_bounds__(256) void k_score(const float* __restrict__ M_, con
             unsigned long long bal[VEC];
 #pragma unroll
             for (int v = 0; v < VEC; v++) {
-                const bool keep = (ov[v] == ov[v]) && (col + v >= A.seed_blocks) && t != INFINITY &&
-                                  (ov[v] + (1e-5f * fabsf(ov[v]) + 1e-4f) >= t);
+                const bool keep = fy_bound_keeps(ov[v], t) && (col + v >= A.seed_blocks);
                 bal[v] = __ballot(keep);
                 mine[v] = keep ? base + __popcll(bal[v] & ((1ull << lane) - 1ull)) : -1;
                 base += __popcll(bal[v]);
@@ -681,6 +705,10 @@ struct TopNArgs {
     const int32_t* __restrict__ n_quads;  // [u]: surviving blocks of the user
     int64_t ldb;
     float* __restrict__ tau;              // [u]
+    // cooperative ranks: the survivors' scores are not in the (seed-wide) row but packed, 256 floats per surviving block,
+    // at entry quad_prefix[u] + k; the user's blocks are in ascending order
+    const float* __restrict__ Ssurv;
+    const int32_t* __restrict__ quad_prefix;
 };
 
 __device__ __forceinline__ uint32_t fy_order_key(float f) {
@@ -782,11 +810,13 @@ __global__ __launch_bounds__(256) void k_topn_fast(TopNArgs A, int32_t* __restri
     const int i4_end = A.mode == 2 ? A.n_quads[u] * (PRUNE_BLOCK_COLS / 4) : (A.Ic + 3) >> 2;
     for (int x = i4_begin + tid; x < i4_end; x += blockDim.x) {
         int i4 = x;
+        const float* src = row + 4 * (int64_t)x;
         if (A.mode == 2) {
             const unsigned blk = A.surv[(int64_t)u * A.ldb + (x >> 6)];
             i4 = (int)blk * (PRUNE_BLOCK_COLS / 4) + (x & 63);
+            src = A.Ssurv ? A.Ssurv + ((int64_t)(A.quad_prefix[u] + (x >> 6)) * PRUNE_BLOCK_COLS + 4 * (x & 63)) : row + 4 * (int64_t)i4;
         }
-        const float4 f4 = *reinterpret_cast<const float4*>(row + 4 * i4);
+        const float4 f4 = *reinterpret_cast<const float4*>(src);
         const float fv[4] = {f4.x, f4.y, f4.z, f4.w};
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -840,6 +870,7 @@ __global__ __launch_bounds__(256) void k_topn_select(TopNArgs A, const int32_t* 
     const int tid = threadIdx.x;
     // pruned rows: only the seed columns and the surviving 64-column blocks were ever written
     __shared__ uint32_t live[2048];
+    __shared__ uint16_t live_pre[2048];   // cooperative ranks: surviving blocks in front of word w (position in the packed scores)
     if (A.mode) {
         for (int w = tid; w < 2048; w += blockDim.x) live[w] = 0;
         __syncthreads();
@@ -848,8 +879,22 @@ __global__ __launch_bounds__(256) void k_topn_select(TopNArgs A, const int32_t* 
             atomicOr(&live[blk >> 5], 1u << (blk & 31u));
         }
         __syncthreads();
+        if (A.Ssurv && tid == 0) {
+            unsigned run = 0;
+            for (int w = 0; w < 2048; w++) { live_pre[w] = (uint16_t)run; run += __popc(live[w]); }
+        }
+        __syncthreads();
     }
-#define FY_ROWVAL(i) ((A.mode == 0 || (i) < A.seed_cols || ((live[(i) >> 13] >> (((i) >> 8) & 31)) & 1u)) ? row[(i)] : __builtin_nanf(""))
+    const float* __restrict__ packed = (A.mode && A.Ssurv) ? A.Ssurv + (int64_t)A.quad_prefix[u] * PRUNE_BLOCK_COLS : nullptr;
+    auto rowval = [&](int i) -> float {
+        if (A.mode == 0 || i < A.seed_cols) return row[i];
+        const unsigned blk = (unsigned)i >> 8, w = blk >> 5, bit = blk & 31u;
+        if (!((live[w] >> bit) & 1u)) return __builtin_nanf("");
+        if (!packed) return row[i];
+        const unsigned pos = live_pre[w] + __popc(live[w] & ((1u << bit) - 1u));
+        return packed[(int64_t)pos * PRUNE_BLOCK_COLS + (i & 255)];
+    };
+#define FY_ROWVAL(i) rowval(i)
 
     // ---- radix select: 12 + 10 + 10 bits, most significant first
     uint32_t prefix = 0, prefix_mask = 0, need = (uint32_t)K;
@@ -1054,6 +1099,140 @@ __global__ __launch_bounds__(256) void k_score_blocks(const float* __restrict__ 
     if (lane == 0 && my_terms) atomicAdd(&counters[1], my_terms);
 }
 
+// ================================================================ cooperative ranks (fy_collectives): kernels
+// first CSR entry of every user of the cluster with idx >= r0 and with idx >= r1: the part of the row that meets this
+// rank's item rows [r0, r1) (same layout as a chunk_off table with one chunk)
+__global__ void k_range_offsets(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ csr_idx, int32_t slot_base,
+                                int32_t n_slots, int32_t r0, int32_t r1, int32_t* __restrict__ out) {
+    const int64_t total = (int64_t)n_slots * 2;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t v = (int32_t)(t >> 1);
+        const int32_t key = (t & 1) ? r1 : r0;
+        int32_t lo = rowptr[slot_base + v], hi = rowptr[slot_base + v + 1];
+        while (lo < hi) {
+            const int32_t mid = (lo + hi) >> 1;
+            if (csr_idx[mid] < key) lo = mid + 1; else hi = mid;
+        }
+        out[t] = lo;
+    }
+}
+
+// work model of an item row: the row kernel walks sum_v n_v CSR entries, the scoring passes ~300 columns per rating
+__global__ void k_row_work(int32_t Ic, const int32_t* __restrict__ rank_pair, const int32_t* __restrict__ pair_start,
+                           const int32_t* __restrict__ csc_slot, const int32_t* __restrict__ slot2du,
+                           const int32_t* __restrict__ udeg, int64_t* __restrict__ work, int32_t* __restrict__ count) {
+    const int lane = threadIdx.x & 63;
+    const int wpb = blockDim.x >> 6;
+    for (int32_t row = blockIdx.x * wpb + (threadIdx.x >> 6); row < Ic; row += gridDim.x * wpb) {
+        const int32_t pr = rank_pair[row];
+        long long w = 0;
+        for (int32_t q = pair_start[pr] + lane; q < pair_start[pr + 1]; q += 64) w += udeg[slot2du[csc_slot[q]]] + 300;
+        for (int o = 32; o > 0; o >>= 1) w += __shfl_down(w, o, 64);
+        if (lane == 0) { work[row] = w; count[row] = pair_start[pr + 1] - pair_start[pr]; }
+    }
+}
+
+// owner of the user: blocks behind the seed whose (summed) bound reaches tau_u, in ascending block order
+__global__ __launch_bounds__(256) void k_bound_select(const float* __restrict__ UB, int64_t ldb, int32_t nblk, int32_t seed_blocks,
+                                                      const float* __restrict__ tau, int32_t n_users, uint16_t* __restrict__ surv,
+                                                      int32_t* __restrict__ n_surv) {
+    const int lane = threadIdx.x & 63;
+    const int wpb = blockDim.x >> 6;
+    for (int u = blockIdx.x * wpb + (threadIdx.x >> 6); u < n_users; u += gridDim.x * wpb) {
+        const float t = tau[u];
+        int count = 0;
+        for (int b0 = 0; b0 < nblk; b0 += 64) {
+            const int b = b0 + lane;
+            const bool keep = b < nblk && b >= seed_blocks && fy_bound_keeps(UB[(int64_t)u * ldb + b], t);
+            const unsigned long long bal = __ballot(keep);
+            if (keep) surv[(int64_t)u * ldb + count + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)b;
+            count += __popcll(bal);
+        }
+        if (lane == 0) n_surv[u] = count;
+    }
+}
+
+// (slot, block) of every surviving block of this rank's users, packed for the all-gather
+__global__ void k_surv_entries(int32_t n_users, int32_t slot0, const int32_t* __restrict__ prefix, const uint16_t* __restrict__ surv,
+                               int64_t ldb, long long* __restrict__ entries) {
+    const int lane = threadIdx.x & 63;
+    const int wpb = blockDim.x >> 6;
+    for (int u = blockIdx.x * wpb + (threadIdx.x >> 6); u < n_users; u += gridDim.x * wpb) {
+        const int a = prefix[u], n = prefix[u + 1] - a;
+        for (int k = lane; k < n; k += 64)
+            entries[a + k] = ((long long)(slot0 + u) << 16) | (long long)surv[(int64_t)u * ldb + k];
+    }
+}
+
+// partial exact scores of the surviving blocks of ALL ranks over this rank's item rows: one wave = one entry,
+// 256 floats at Spart[w * 256]; entry w = k * t_max + i belongs to rank k and exists when i < counts[k]
+template <int SB>
+__global__ __launch_bounds__(256) void k_score_entries(const float* __restrict__ M_, const float* __restrict__ a_rank_,
+                                                       const int32_t* __restrict__ range_off_, const int32_t* __restrict__ csr_idx_,
+                                                       const float* __restrict__ csr_e_, const double* __restrict__ pvpi_,
+                                                       const long long* __restrict__ entries_, const int32_t* __restrict__ counts_,
+                                                       int32_t world, int32_t t_max, int32_t slot_base, int32_t Ic, int64_t ldm,
+                                                       float* __restrict__ Spart_, unsigned long long* __restrict__ counters) {
+    const int lane = threadIdx.x & 63;
+    const int wave_in_grid = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    const int n_waves = gridDim.x * (blockDim.x >> 6);
+    const int total = world * t_max;
+    const int64_t pitch = ldm * 3;
+    const double LN2 = 0.69314718055994530942;
+    const float qnan = __builtin_nanf("");
+    unsigned long long my_terms = 0;
+    for (int w = wave_in_grid; w < total; w += n_waves) {
+        const int k = w / t_max;
+        if (w - k * t_max >= counts_[k]) continue;
+        const long long en = entries_[w];
+        const int slot = (int)(en >> 16);
+        const int col0 = (int)(en & 0xFFFF) * PRUNE_BLOCK;
+        const int col = col0 + lane * 4;
+        float a[4];
+#pragma unroll
+        for (int v = 0; v < 4; v++) a[v] = col + v < Ic ? a_rank_[col + v] : 0.0f;
+        const char* __restrict__ Mcol = reinterpret_cast<const char*>(M_) + (int64_t)col * 3;
+        const int beg = range_off_[2 * (slot - slot_base)], end = range_off_[2 * (slot - slot_base) + 1];
+        double t[4] = {0.0, 0.0, 0.0, 0.0};
+        unsigned mask = 0;
+        for (int kk0 = beg; kk0 < end; kk0 += SB) {
+            U3 g[SB];
+            float e[SB];
+            int jj[SB];
+#pragma unroll
+            for (int x = 0; x < SB; x++) {
+                const int kk = min(kk0 + x, end - 1);
+                jj[x] = csr_idx_[kk];
+                e[x] = csr_e_[kk];
+                g[x] = *reinterpret_cast<const U3*>(Mcol + (int64_t)jj[x] * pitch);
+            }
+            float p[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int x = 0; x < SB; x++) {
+                if (kk0 + x < end) {
+                    float gv[4];
+                    fy_unpack24(g[x], gv);
+#pragma unroll
+                    for (int v = 0; v < 4; v++) p[v] += fy_log2(fmaf(a[v], e[x], gv[v]));
+                    const unsigned d = (unsigned)(jj[x] - col);
+                    if (d < 4u) mask |= 1u << d;
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < 4; v++) t[v] += (double)p[v];
+        }
+        const double base = pvpi_[slot - slot_base];
+        float4 o;
+        o.x = ((mask & 1u) || col + 0 >= Ic) ? qnan : (float)(base + LN2 * t[0]);
+        o.y = ((mask & 2u) || col + 1 >= Ic) ? qnan : (float)(base + LN2 * t[1]);
+        o.z = ((mask & 4u) || col + 2 >= Ic) ? qnan : (float)(base + LN2 * t[2]);
+        o.w = ((mask & 8u) || col + 3 >= Ic) ? qnan : (float)(base + LN2 * t[3]);
+        *reinterpret_cast<float4*>(Spart_ + (int64_t)w * PRUNE_BLOCK + lane * 4) = o;
+        my_terms += (unsigned long long)(end - beg) * 256ull;
+    }
+    if (lane == 0 && my_terms) atomicAdd(&counters[1], my_terms);
+}
+
 void launch_topn_rows(Context* ctx, hipStream_t st, const float* S, int64_t ldS, int32_t n_cols, int32_t n_rows,
                       const int32_t* n_out, const int32_t* out_off, const int32_t* rank_item_raw, const int32_t* slot2du,
                       const int32_t* uid, int32_t slot0, int32_t aux_value, int32_t* out_user, int32_t* out_item,
@@ -1062,7 +1241,7 @@ void launch_topn_rows(Context* ctx, hipStream_t st, const float* S, int64_t ldS,
     if (!st) st = ctx->stream;
     // n_out / out_off are indexed by (slot - slot_lo): pass slot_lo = slot0 so that row u reads entry u
     TopNArgs TA{S, ldS, n_cols, n_out, out_off, rank_item_raw, slot2du, uid, slot0, slot0, aux_value, out_user, out_item, out_score, out_aux,
-                0, 0, nullptr, nullptr, 0, nullptr};
+                0, 0, nullptr, nullptr, 0, nullptr, nullptr, nullptr};
     FY_HIP(hipMemsetAsync(any_overflow, 0, sizeof(int32_t), st));
     k_topn_fast<<<n_rows, 256, 0, st>>>(TA, overflow, any_overflow, 0);
     FY_KERNEL_CHECK();
@@ -1084,6 +1263,9 @@ struct fy_rm2_job {
     DevBuf<double> stats;       // nI + 1 : global sums (+ counter)
     bool have_global = false;
     double ms_prepare = 0;
+    fy_collectives coll{};      // process-group collectives (optional)
+    bool have_coll = false;
+    DevBuf<double> gathered;    // world * (nI + 1): the statistics all-gathered by fy_rm2_score itself
 };
 
 // launch-shape knobs; environment overrides exist only for the tuning sweeps recorded in DESIGN.md
@@ -1108,6 +1290,8 @@ struct ScoreTune {
     int hot_lds = 0;                   // k_score_hot: the 128 most popular rows of a chunk stay in LDS (slower: 16 waves/CU)
     int hot_min_items = 2048;
     int64_t tile_bytes = (int64_t)1 << 40;   // M[row block][chunk] tile; default: one row block (sweep r1)
+    int coop = 1;                      // cooperative scoring of clusters that span all ranks (needs fy_collectives)
+    int coop_force = 0;                // test hook: cooperative path also with world == 1 (identity collectives)
 };
 static ScoreTune score_tune() {
     ScoreTune t;
@@ -1121,6 +1305,8 @@ static ScoreTune score_tune() {
     if (const char* e = getenv("FY_SCORE_SLICES")) t.max_slices = atoi(e);
     if (const char* e = getenv("FY_SCORE_UPW")) { int v = atoi(e); if (v >= 1) t.users_per_wave = v; }
     if (const char* e = getenv("FY_PRUNE")) t.prune = atoi(e) != 0;
+    if (const char* e = getenv("FY_COOP")) t.coop = atoi(e) != 0;
+    if (const char* e = getenv("FY_COOP_FORCE")) t.coop_force = atoi(e) != 0;
     if (const char* e = getenv("FY_PRUNE_MIN_ITEMS")) t.prune_min_items = atoi(e);
     if (const char* e = getenv("FY_SEED_CHUNKS")) { int v = atoi(e); if (v >= 1 && v <= 4) t.seed_chunks = v; }
     if (const char* e = getenv("FY_WORKSPACE_GB")) { long v = atol(e); if (v >= 1) t.workspace_default = (int64_t)v << 30; }
@@ -1132,6 +1318,256 @@ static ScoreTune score_tune() {
     if (const char* e = getenv("FY_TOPN_FORCE_SELECT")) t.force_select = atoi(e) != 0;
     if (const char* e = getenv("FY_SCORE_TILE_KB")) { long v = atol(e); if (v >= 16) t.tile_bytes = (int64_t)v << 10; }
     return t;
+}
+
+// one cluster's launch plan
+struct Plan {
+    int c;
+    int32_t Uc, sbase, pbase, Ic, a, b, CH, nch, rb_rows, nrb, q0, nq;
+    int64_t ldm, B;
+    bool pack24, use_hot, prune, coop;
+    int32_t nblk;
+    int64_t ldb;
+};
+
+// ================================================================ cooperative ranks: one cluster scored by all ranks together
+// (include/filmyou.h, fy_collectives).  score(u, i) = pvpi + sum over the user's rated items j of a term that
+// needs only row j of M, so the sum splits over any partition of the item rows: rank r builds rows [r0, r1) of M (and of
+// the block maxima), evaluates for EVERY user of the cluster the partial sums over the rated items that fall into its
+// rows, and a reduce-scatter hands the owner of each user the complete sums.  Three exchanges follow the three pruned
+// passes: seed columns, block bounds, surviving blocks.  Rank 0 contributes pvpi; a rated candidate is masked (NaN) by
+// the rank that holds its row, and NaN survives the sum.
+struct CoopShared {
+    fy_rm2_job* J;
+    fy_result* R;
+    const ScoreTune* tune;
+    const double *p_rank, *b_rank;
+    const float *a_rank, *csc_x, *csr_x, *csr_e;
+    const int32_t *n_out, *out_off;   // this rank's users, by slot - lo
+    int32_t lo;
+    EventTimer *t_cooc, *t_score, *t_topn;
+    unsigned long long* prune_counters;
+    int64_t *blocks_total, *seed_terms_cols, *coop_survived;
+};
+
+static void coll_all_gather(fy_rm2_job* J, const void* send, void* recv, int64_t bytes, hipStream_t st) {
+    if (!J->have_coll) {   // world == 1 (forced cooperative mode, tests): the identity
+        if (bytes) FY_HIP(hipMemcpyAsync(recv, send, (size_t)bytes, hipMemcpyDeviceToDevice, st));
+        return;
+    }
+    const int rc = J->coll.all_gather(J->coll.user, send, recv, bytes, (void*)st);
+    if (rc) FY_FAIL(FY_ERR_COLLECTIVE, "all_gather callback returned %d", rc);
+}
+static void coll_reduce_scatter(fy_rm2_job* J, const float* send, float* recv, int64_t count, hipStream_t st) {
+    if (!J->have_coll) {
+        if (count) FY_HIP(hipMemcpyAsync(recv, send, (size_t)count * sizeof(float), hipMemcpyDeviceToDevice, st));
+        return;
+    }
+    const int rc = J->coll.reduce_scatter_f32(J->coll.user, send, recv, count, (void*)st);
+    if (rc) FY_FAIL(FY_ERR_COLLECTIVE, "reduce_scatter callback returned %d", rc);
+}
+
+static void score_cluster_coop(const CoopShared& X, const Plan& p, hipStream_t ls) {
+    fy_rm2_job* J = X.J;
+    Context* ctx = J->ctx;
+    Prepared& P = J->P;
+    fy_result* R = X.R;
+    const ScoreTune& tune = *X.tune;
+    const fy_rm2_params& prm = J->prm;
+    const int W = prm.world, me = prm.rank;
+    const int32_t Uc = p.Uc, sbase = p.sbase, pbase = p.pbase, Ic = p.Ic, CH = p.CH, nch = p.nch;
+    const int64_t ldm = p.ldm, ldb = p.ldb;
+    const double lambda = prm.lambda;
+
+    // ---- who owns which users of this cluster (identical on every rank)
+    std::vector<int32_t> ua(W), ub(W);
+    int32_t Umax = 1;
+    for (int k = 0; k < W; k++) {
+        int32_t lo_k, hi_k;
+        rank_slot_range(P, k, W, lo_k, hi_k);
+        ua[k] = std::max(lo_k, sbase);
+        ub[k] = std::max(ua[k], std::min(hi_k, sbase + Uc));
+        Umax = std::max(Umax, ub[k] - ua[k]);
+    }
+    const int32_t my_a = ua[me], n_mine = ub[me] - ua[me];
+
+    // ---- item rows of this rank: equal shares of the work model (row kernel + scoring passes)
+    std::vector<int32_t> rsplit(W + 1, Ic), hcnt;
+    {
+        DevBuf<int64_t> work(ctx, (size_t)Ic);
+        DevBuf<int32_t> cnt(ctx, (size_t)Ic);
+        k_row_work<<<grid_for((int64_t)Ic * 64, 256), 256, 0, ls>>>(Ic, P.rank_pair.get() + pbase, P.pair_start.get(), P.csc_slot.get(),
+                                                                    P.slot2du.get(), P.udeg.get(), work.get(), cnt.get());
+        FY_KERNEL_CHECK();
+        std::vector<int64_t> hw((size_t)Ic);
+        hcnt.resize((size_t)Ic);
+        FY_HIP(hipMemcpyAsync(hw.data(), work.get(), (size_t)Ic * sizeof(int64_t), hipMemcpyDeviceToHost, ls));
+        FY_HIP(hipMemcpyAsync(hcnt.data(), cnt.get(), (size_t)Ic * sizeof(int32_t), hipMemcpyDeviceToHost, ls));
+        FY_HIP(hipStreamSynchronize(ls));
+        int64_t total = 0;
+        for (int32_t i = 0; i < Ic; i++) total += hw[i];
+        rsplit[0] = 0;
+        int64_t run = 0;
+        int k = 1;
+        for (int32_t i = 0; i < Ic && k < W; i++) {
+            run += hw[i];
+            while (k < W && run * W >= total * k) rsplit[k++] = i + 1;
+        }
+        // (entries not reached stay at Ic)
+    }
+    const int32_t r0 = rsplit[me], r1 = rsplit[me + 1], nrows = r1 - r0;
+    int64_t my_ratings = 0;
+    for (int32_t i = r0; i < r1; i++) my_ratings += hcnt[i];
+
+    // ---- buffers
+    const int n_chunks = (int)ceil_div(Ic, 256);
+    const int seed_chunks = std::min(n_chunks, tune.seed_chunks);
+    const int seed_blocks = seed_chunks;
+    const int64_t SC = (int64_t)seed_chunks * 256;
+    const int bchunks = (int)(ldb / 256);
+    DevBuf<float> Mloc(ctx, (size_t)std::max<int64_t>(1, (int64_t)nrows * ldm * 3 / 4 + 4)), Bloc(ctx, (size_t)std::max<int64_t>(1, (int64_t)nrows * ldb));
+    DevBuf<float> amax(ctx, (size_t)ldb);
+    DevBuf<int32_t> range_off(ctx, (size_t)Uc * 2), n_out_all(ctx, (size_t)Uc), item_counter(ctx, 1);
+    DevBuf<double> pv_all(ctx, (size_t)Uc);
+    DevBuf<unsigned long long> dummy(ctx, 2);
+    DevBuf<float> seed_send(ctx, (size_t)((int64_t)W * Umax * SC)), seed(ctx, (size_t)((int64_t)Umax * SC));
+    DevBuf<float> ub_send(ctx, (size_t)((int64_t)W * Umax * ldb)), UBsum(ctx, (size_t)((int64_t)Umax * ldb));
+    DevBuf<float> tau(ctx, (size_t)Umax);
+    DevBuf<uint16_t> surv(ctx, (size_t)((int64_t)Umax * ldb));
+    DevBuf<int32_t> n_quads(ctx, (size_t)Umax + 1), quad_prefix(ctx, (size_t)Umax + 1), overflow(ctx, (size_t)Umax), any_overflow(ctx, 1);
+    DevBuf<int32_t> counts(ctx, (size_t)W);
+    // M and Bmax are addressed by absolute row: shift the base so that row r0 is the first one stored
+    const float* Mshift = reinterpret_cast<const float*>(reinterpret_cast<const char*>(Mloc.get()) - (int64_t)r0 * ldm * 3);
+    const float* Bshift = Bloc.get() - (int64_t)r0 * ldb;
+
+    // ---- segment table of my rows, M build
+    {
+        DevBuf<int32_t> co_tmp(ctx, (size_t)Uc * (nch + 1));
+        SegTable seg;
+        build_chunk_offsets(ctx, P.rowptr.get(), P.csr_idx.get(), sbase, Uc, CH, nch, co_tmp.get(), ls);
+        build_segments(ctx, P.csc_slot.get(), X.csc_x, co_tmp.get(), sbase, p.q0, p.nq, nch, seg, ls, P.csc_pair.get(), P.pair_rank.get(), r0, r1);
+        FY_HIP(hipMemsetAsync(Bloc.get(), 0, (size_t)std::max<int64_t>(1, (int64_t)nrows * ldb) * sizeof(float), ls));
+        k_block_amax<<<grid_for(ldb), 256, 0, ls>>>(Ic, (int32_t)ldb, X.a_rank + pbase, amax.get());
+        FY_KERNEL_CHECK();
+        if (nrows > 0) {
+            CoocArgs CA{P.rank_pair.get(), P.pair_start.get(), seg.ptr.get(), seg.seg.get(), seg.w.get(), P.csr_idx.get(),
+                        X.csr_x, pbase, sbase, Ic, CH, nch, r0, nrows, p.q0, p.nq, tune.cooc_debug};
+            MEpilogue ME{const_cast<float*>(Mshift), ldm, X.p_rank + pbase, X.b_rank + pbase, (1.0 - lambda) * (1.0 - lambda),
+                         lambda * (1.0 - lambda), 1, const_cast<float*>(Bshift), ldb};
+            const int block = tune.cooc_block ? tune.cooc_block : ((CH * 8 > 48 * 1024) ? 1024 : 256);
+            const size_t sp = X.t_cooc->begin(ls);
+            const int n_items = nrows * nch;
+            const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2048 / block, (160 * 1024) / ((size_t)CH * 8 + 1024)));
+            const int grid = std::min(n_items, ctx->num_cus * per_cu);
+            FY_HIP(hipMemsetAsync(item_counter.get(), 0, sizeof(int32_t), ls));
+            k_cooc_rm2<<<grid, block, (size_t)CH * 8, ls>>>(CA, ME, n_items, item_counter.get());
+            FY_KERNEL_CHECK();
+            X.t_cooc->end(sp, ls);
+            R->st.cooc_launches++;
+        }
+        FY_HIP(hipStreamSynchronize(ls));   // the segment table is released here
+    }
+
+    // ---- per-user tables over the whole cluster
+    k_range_offsets<<<grid_for((int64_t)Uc * 2), 256, 0, ls>>>(P.rowptr.get(), P.csr_idx.get(), sbase, Uc, r0, r1, range_off.get());
+    FY_KERNEL_CHECK();
+    FY_HIP(hipMemsetAsync(dummy.get(), 0, 2 * sizeof(unsigned long long), ls));
+    k_user_meta<<<grid_for(Uc), 256, 0, ls>>>(sbase, sbase + Uc, P.slot2du.get(), P.uid.get(), P.ucluster.get(), P.udeg.get(),
+                                               P.d_csize.get(), P.d_pcstart.get(), prm.number_of_items, prm.number_of_recommendations,
+                                               prm.filter_users, pv_all.get(), n_out_all.get(), dummy.get());
+    FY_KERNEL_CHECK();
+    if (me != 0) FY_HIP(hipMemsetAsync(pv_all.get(), 0, (size_t)Uc * sizeof(double), ls));   // pvpi enters the sum once
+
+    const size_t ss = X.t_score->begin(ls);
+    auto slices_for = [&](int32_t nb) { return (int)std::max<int64_t>(1, std::min<int64_t>(tune.max_slices, ceil_div(nb, 4 * tune.users_per_wave))); };
+    // ---- (1) partial seed scores of every user, owner by owner; (2) reduce-scatter; (3) tau + the speculative lists
+    for (int k = 0; k < W; k++) {
+        const int32_t nk = ub[k] - ua[k];
+        if (nk <= 0) continue;
+        const int ns = slices_for(nk);
+        ScoreArgs SA{Mshift, ldm, Ic, X.a_rank + pbase, range_off.get(), P.csr_idx.get(), X.csr_e, pv_all.get(), n_out_all.get(),
+                     sbase, sbase, ua[k], nk, seed_send.get() + (int64_t)k * Umax * SC, SC, ns, 0, 1, 0, 0, seed_chunks, 0,
+                     nullptr, nullptr, nullptr, 0};
+        k_score<4, true, 8><<<seed_chunks * ns, 256, 0, ls>>>(SA.M, SA.a_rank, SA.rb_off, SA.csr_idx, SA.csr_e, SA.pvpi, SA.n_out, SA.S, SA);
+        FY_KERNEL_CHECK();
+        R->st.score_launches++;
+    }
+    coll_reduce_scatter(J, seed_send.get(), seed.get(), (int64_t)Umax * SC, ls);
+    if (n_mine > 0) {
+        TopNArgs T1{seed.get(), SC, Ic, X.n_out, X.out_off, P.rank_item_raw.get() + pbase, P.slot2du.get(), P.uid.get(),
+                    X.lo, my_a, p.c, R->d_key0.get(), R->d_key1.get(), R->d_value.get(), R->d_aux.get(),
+                    1, (int32_t)SC, surv.get(), n_quads.get(), ldb, tau.get(), nullptr, nullptr};
+        k_topn_fast<<<n_mine, 256, 0, ls>>>(T1, overflow.get(), any_overflow.get(), 0);
+        FY_KERNEL_CHECK();
+    }
+    // ---- (4) partial block bounds, reduce-scatter, (5) the owner keeps the blocks that reach tau
+    for (int k = 0; k < W; k++) {
+        const int32_t nk = ub[k] - ua[k];
+        if (nk <= 0) continue;
+        const int ns = slices_for(nk);
+        ScoreArgs SB_{Bshift, ldb, p.nblk, amax.get(), range_off.get(), P.csr_idx.get(), X.csr_e, pv_all.get(), n_out_all.get(),
+                      sbase, sbase, ua[k], nk, ub_send.get() + (int64_t)k * Umax * ldb, ldb, ns, 0, 1, 0, 0, bchunks, 2,
+                      nullptr, nullptr, nullptr, seed_blocks};
+        k_score<4, false, 8><<<bchunks * ns, 256, 0, ls>>>(SB_.M, SB_.a_rank, SB_.rb_off, SB_.csr_idx, SB_.csr_e, SB_.pvpi, SB_.n_out, SB_.S, SB_);
+        FY_KERNEL_CHECK();
+        R->st.score_launches++;
+    }
+    coll_reduce_scatter(J, ub_send.get(), UBsum.get(), (int64_t)Umax * ldb, ls);
+    FY_HIP(hipMemsetAsync(n_quads.get(), 0, ((size_t)Umax + 1) * sizeof(int32_t), ls));
+    if (n_mine > 0) {
+        k_bound_select<<<grid_for((int64_t)n_mine * 64, 256), 256, 0, ls>>>(UBsum.get(), ldb, p.nblk, seed_blocks, tau.get(), n_mine,
+                                                                            surv.get(), n_quads.get());
+        FY_KERNEL_CHECK();
+    }
+    exclusive_scan_i32(ctx, n_quads.get(), quad_prefix.get(), (size_t)n_mine + 1, ls);
+    // ---- (6) everybody learns everybody's survivors
+    DevBuf<int32_t> my_count(ctx, 1);
+    FY_HIP(hipMemcpyAsync(my_count.get(), quad_prefix.get() + n_mine, sizeof(int32_t), hipMemcpyDeviceToDevice, ls));
+    coll_all_gather(J, my_count.get(), counts.get(), sizeof(int32_t), ls);
+    std::vector<int32_t> hcounts((size_t)W);
+    FY_HIP(hipMemcpyAsync(hcounts.data(), counts.get(), (size_t)W * sizeof(int32_t), hipMemcpyDeviceToHost, ls));
+    FY_HIP(hipStreamSynchronize(ls));
+    int32_t t_max = 0;
+    for (int k = 0; k < W; k++) t_max = std::max(t_max, hcounts[k]);
+    DevBuf<float> Ssurv;
+    if (t_max > 0) {
+        DevBuf<long long> entries(ctx, (size_t)t_max), entries_all(ctx, (size_t)W * t_max);
+        DevBuf<float> Spart(ctx, (size_t)W * t_max * PRUNE_BLOCK);
+        Ssurv.alloc(ctx, (size_t)t_max * PRUNE_BLOCK);
+        FY_HIP(hipMemsetAsync(entries.get(), 0, (size_t)t_max * sizeof(long long), ls));
+        if (n_mine > 0) {
+            k_surv_entries<<<grid_for((int64_t)n_mine * 64, 256), 256, 0, ls>>>(n_mine, my_a, quad_prefix.get(), surv.get(), ldb, entries.get());
+            FY_KERNEL_CHECK();
+        }
+        coll_all_gather(J, entries.get(), entries_all.get(), (int64_t)t_max * (int64_t)sizeof(long long), ls);
+        // ---- (7) partial exact scores of all survivors over my rows, reduce-scatter to the owners
+        k_score_entries<8><<<ctx->num_cus * 8, 256, 0, ls>>>(Mshift, X.a_rank + pbase, range_off.get(), P.csr_idx.get(), X.csr_e, pv_all.get(),
+                                                             entries_all.get(), counts.get(), W, t_max, sbase, Ic, ldm, Spart.get(),
+                                                             X.prune_counters);
+        FY_KERNEL_CHECK();
+        R->st.score_launches++;
+        coll_reduce_scatter(J, Spart.get(), Ssurv.get(), (int64_t)t_max * PRUNE_BLOCK, ls);
+        FY_HIP(hipStreamSynchronize(ls));   // entries / Spart are released here
+    }
+    X.t_score->end(ss, ls);
+    // ---- (8) the owner merges seed + survivors for the users that have any
+    if (n_mine > 0 && hcounts[me] > 0) {
+        const size_t tt = X.t_topn->begin(ls);
+        TopNArgs TA{seed.get(), SC, Ic, X.n_out, X.out_off, P.rank_item_raw.get() + pbase, P.slot2du.get(), P.uid.get(),
+                    X.lo, my_a, p.c, R->d_key0.get(), R->d_key1.get(), R->d_value.get(), R->d_aux.get(),
+                    2, (int32_t)SC, surv.get(), n_quads.get(), ldb, tau.get(), Ssurv.get(), quad_prefix.get()};
+        FY_HIP(hipMemsetAsync(any_overflow.get(), 0, sizeof(int32_t), ls));
+        k_topn_fast<<<n_mine, 256, 0, ls>>>(TA, overflow.get(), any_overflow.get(), tune.force_select);
+        FY_KERNEL_CHECK();
+        k_topn_select<<<n_mine, 256, 0, ls>>>(TA, overflow.get(), any_overflow.get());
+        FY_KERNEL_CHECK();
+        X.t_topn->end(tt, ls);
+    }
+    // statistics: blocks checked / kept for my users; log terms of my seed and bound passes = (ratings in my rows) x (columns walked)
+    *X.blocks_total += (int64_t)n_mine * std::max(0, p.nblk - seed_blocks);
+    *X.coop_survived += (int64_t)hcounts[me];
+    *X.seed_terms_cols += my_ratings * (SC + ldb);
+    FY_HIP(hipStreamSynchronize(ls));   // every buffer of this function goes back to the allocator after the stream drained
 }
 
 static void validate_params(const fy_rm2_params* p) {
@@ -1193,8 +1629,14 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
     const fy_rm2_params& prm = J->prm;
     hipStream_t st = ctx->stream;
     if (!J->have_global) {
-        if (prm.world != 1) FY_FAIL(FY_ERR_STATE, "fy_rm2_set_global_stats must be called before fy_rm2_score when world > 1");
-        rm2_set_global_stats(J, J->partial.get(), 1);
+        if (prm.world == 1) rm2_set_global_stats(J, J->partial.get(), 1);
+        else if (J->have_coll) {   // the all-gather of the per-item statistics (jobs RM2-1 / RM2-2) through the installed collectives
+            const int64_t len = (int64_t)P.nI + 1;
+            J->gathered.alloc(ctx, (size_t)(len * prm.world));
+            coll_all_gather(J, J->partial.get(), J->gathered.get(), len * (int64_t)sizeof(double), st);
+            rm2_set_global_stats(J, J->gathered.get(), prm.world);
+        } else
+            FY_FAIL(FY_ERR_STATE, "world > 1: call fy_rm2_set_global_stats (or install fy_collectives) before fy_rm2_score");
     }
     std::unique_ptr<fy_result> R(new fy_result);
     R->ctx = ctx;
@@ -1284,14 +1726,6 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
         // ---- per-cluster plan; the clusters are spread over up to four "lanes" (HIP streams with their own M / score
         // scratch): the tail of one cluster's launches -- its heaviest user sits on a single wave for milliseconds, and
         // most of its M rows have a handful of raters -- overlaps the next clusters' work instead of idling the chip.
-        struct Plan {
-            int c;
-            int32_t Uc, sbase, pbase, Ic, a, b, CH, nch, rb_rows, nrb, q0, nq;
-            int64_t ldm, B;
-            bool pack24, use_hot, prune;
-            int32_t nblk;
-            int64_t ldb;
-        };
         std::vector<Plan> plans;
         const int VEC = tune.vec;
         for (int c = 0; c < K; c++) {
@@ -1321,6 +1755,17 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             p.nblk = (int32_t)ceil_div(p.Ic, PRUNE_BLOCK);
             p.ldb = round_up(p.nblk, 256);
             p.prune = tune.prune && p.pack24 && p.nrb == 1 && !p.use_hot && p.Ic >= tune.prune_min_items && p.nblk < 0xFFFF;
+            // all ranks hold users of this cluster and can talk to each other: score it together, every rank with its
+            // share of the matrix rows (score_cluster_coop)
+            p.coop = false;
+            if (p.prune && tune.coop && ((prm.world > 1 && J->have_coll) || tune.coop_force)) {
+                p.coop = true;
+                for (int k = 0; k < prm.world; k++) {
+                    int32_t lo_k, hi_k;
+                    rank_slot_range(P, k, prm.world, lo_k, hi_k);
+                    if (std::max(lo_k, p.sbase) >= std::min(hi_k, p.sbase + p.Uc)) p.coop = false;
+                }
+            }
             plans.push_back(p);
         }
         const int NS = (int)std::min<size_t>(plans.size() > 1 ? (size_t)tune.lanes : 1, plans.size());
@@ -1338,6 +1783,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             size_t m_el = 1, s_el = 1, co_el = 1, rb_el = 1, ho_el = 1, ov_el = 1, sl_el = 1, bm_el = 1, ub_el = 1, am_el = 1;
             for (auto& p : plans) {
                 p.B = std::min<int64_t>(std::max<int64_t>(1, (ws / NS) / (p.ldm * 4)), p.b - p.a);
+                if (p.coop) continue;   // allocates for itself
                 m_el = std::max(m_el, (size_t)(p.Ic * p.ldm));
                 s_el = std::max(s_el, (size_t)(p.B * p.ldm));
                 co_el = std::max(co_el, (size_t)p.Uc * (p.nch + 1));
@@ -1379,7 +1825,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
         }
         DevBuf<unsigned long long> prune_counters(ctx, 2);   // [0] surviving blocks, [1] log terms evaluated by the three pruned passes
         prune_counters.zero();
-        int64_t prune_blocks_total = 0, prune_seed_terms_cols = 0;
+        int64_t prune_blocks_total = 0, prune_seed_terms_cols = 0, coop_survived = 0;
         // segment tables of the row kernel, one per cluster, built on the main stream before the lanes fork
         std::vector<SegTable> segs(plans.size());
         {
@@ -1388,6 +1834,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             DevBuf<int32_t> co_tmp(ctx, co_all);
             for (size_t pi = 0; pi < plans.size(); pi++) {
                 const Plan& p = plans[pi];
+                if (p.coop) continue;
                 build_chunk_offsets(ctx, P.rowptr.get(), P.csr_idx.get(), p.sbase, p.Uc, p.CH, p.nch, co_tmp.get());
                 build_segments(ctx, P.csc_slot.get(), csc_x.get(), co_tmp.get(), p.sbase, p.q0, p.nq, p.nch, segs[pi]);
             }
@@ -1407,6 +1854,13 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             const int32_t Uc = p.Uc, sbase = p.sbase, pbase = p.pbase, Ic = p.Ic, a = p.a, b = p.b, CH = p.CH, nch = p.nch;
             const int64_t ldm = p.ldm;
             const bool pack24 = p.pack24;
+            if (p.coop) {
+                CoopShared X{J, R.get(), &tune, p_rank.get(), b_rank.get(), a_rank.get(), csc_x.get(), csr_x.get(), csr_e.get(),
+                             n_out.get(), out_off.get(), lo, &t_cooc, &t_score, &t_topn, prune_counters.get(),
+                             &prune_blocks_total, &prune_seed_terms_cols, &coop_survived};
+                score_cluster_coop(X, p, ls);
+                continue;
+            }
 
             // -- M build
             CoocArgs CA{P.rank_pair.get(), P.pair_start.get(), segs[pi].ptr.get(), segs[pi].seg.get(), segs[pi].w.get(), P.csr_idx.get(),
@@ -1537,7 +1991,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             unsigned long long hc[2];
             d2h(ctx, hc, prune_counters.get(), 2);
             sync(ctx);
-            R->st.blocks_survived = (int64_t)hc[0];
+            R->st.blocks_survived = (int64_t)hc[0] + coop_survived;
             R->st.blocks_total = prune_blocks_total;
             R->st.log_terms_evaluated = prune_blocks_total ? (int64_t)hc[1] + prune_seed_terms_cols : 0;
         }
@@ -1558,6 +2012,12 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
     R->st.ms_topn = t_topn.total_ms();
     R->st.ms_total = t_total.total_ms();
     return R.release();
+}
+
+void fy::rm2_set_collectives(fy_rm2_job* J, const fy_collectives* c) {
+    if (!c || !c->all_gather || !c->reduce_scatter_f32) FY_FAIL(FY_ERR_INVALID_ARGUMENT, "fy_collectives needs all_gather and reduce_scatter_f32");
+    J->coll = *c;
+    J->have_coll = true;
 }
 
 void fy::rm2_partial_stats(fy_rm2_job* J, double** buf, int64_t* len) {

@@ -27,6 +27,7 @@ fy_rm2_job* rm2_prepare(Context*, const fy_rm2_params*, const fy_ratings*, int64
                         const int32_t* map_cluster, const int32_t* cluster_count);
 void rm2_partial_stats(fy_rm2_job*, double** buf, int64_t* len);
 void rm2_set_global_stats(fy_rm2_job*, const double* gathered, int32_t world);
+void rm2_set_collectives(fy_rm2_job*, const fy_collectives*);
 fy_result* rm2_score(fy_rm2_job*);
 void rm2_job_destroy(fy_rm2_job*);
 fy_result* itemsim_build(Context*, const fy_itemsim_params*, const fy_ratings*);

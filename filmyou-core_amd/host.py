@@ -289,18 +289,25 @@ class RM2Job:
                 r.close()
 
     def run(self, ratings, clustering=None, clustering_count=None, rank=0, world=1, exchange=None,
-            workspace_bytes=0):
+            workspace_bytes=0, collectives=None):
         """ratings: a ``Ratings`` or a (user, item, score) triple of arrays.
         clustering: (users, clusters) arrays = the reference's `clustering` file; None routes everyone to cluster 0.
         clustering_count: array of numberOfClusters sizes = the `clusteringCount` file (validated when given).
-        exchange(device_ptr, length) -> device_ptr of world*length doubles: the all-gather of the per-item statistics
-        (see parallel.StatsExchange); required when world > 1.
+        world > 1 needs one of
+          collectives: an object with ``all_gather(send_ptr, recv_ptr, nbytes, stream_ptr)`` and
+            ``reduce_scatter_f32(send_ptr, recv_ptr, count, stream_ptr)`` on device pointers (parallel.TorchCollectives =
+            RCCL through torch.distributed): the statistics are all-gathered inside the library and clusters that span
+            all ranks are scored cooperatively (every rank builds 1/world of the co-rating matrix);
+          exchange(device_ptr, length) -> device_ptr of world*length doubles: only the all-gather of the per-item
+            statistics (parallel.StatsExchange); every rank then builds the whole matrix of the clusters it holds users of.
         Raises RuntimeError("RM2 failed!: ...") on any failure, like RM2Job.java:144-147."""
-        if world > 1 and exchange is None:
-            raise ValueError("world > 1 needs an exchange (all-gather of the item statistics)")
+        if world > 1 and exchange is None and collectives is None:
+            raise ValueError("world > 1 needs collectives (or at least an exchange for the item statistics)")
         prepared = self.prepare(ratings, clustering, clustering_count, rank, world, workspace_bytes)
         try:
-            if world > 1:
+            if collectives is not None:
+                prepared.set_collectives(collectives)
+            elif world > 1:
                 ptr, n = prepared.partial_stats()
                 prepared.set_global_stats(exchange(ptr, n))
             return prepared.score()
@@ -327,10 +334,35 @@ class PreparedRM2:
     def set_global_stats(self, gathered_device_ptr):
         _check(self._lib.fy_rm2_set_global_stats(self._h, gathered_device_ptr, self.world))
 
+    def set_collectives(self, comm):
+        """Installs the process group's collectives (fy_rm2_set_collectives).  `comm.all_gather(send, recv, nbytes,
+        stream)` / `comm.reduce_scatter_f32(send, recv, count, stream)` get raw device pointers and the hipStream_t the
+        operation has to be ordered on; an exception inside them fails the job (FY_ERR_COLLECTIVE)."""
+        self._comm_error = None
+
+        def guard(fn):
+            def call(_user, send, recv, n, stream):
+                try:
+                    fn(send, recv, n, stream)
+                    return 0
+                except BaseException as e:      # must not unwind through the C frames
+                    self._comm_error = e
+                    return 1
+            return call
+
+        self._callbacks = (_native.ALL_GATHER_FN(guard(comm.all_gather)), _native.REDUCE_SCATTER_FN(guard(comm.reduce_scatter_f32)))
+        self._coll = _native.Collectives(None, self._callbacks[0], self._callbacks[1])
+        _check(self._lib.fy_rm2_set_collectives(self._h, C.byref(self._coll)))
+
     def score(self):
         res = C.c_void_p()
         try:
-            _check(self._lib.fy_rm2_score(self._h, C.byref(res)))
+            try:
+                _check(self._lib.fy_rm2_score(self._h, C.byref(res)))
+            except FilmYouError as e:
+                if getattr(self, "_comm_error", None) is not None:
+                    raise RuntimeError("%s failed!: collective: %r" % (RM2Job.JOB_NAME, self._comm_error)) from self._comm_error
+                raise
         except FilmYouError as e:
             raise RuntimeError("%s failed!: %s" % (RM2Job.JOB_NAME, e.message)) from e
         return Recommendations(res, self._ctx)

@@ -76,3 +76,107 @@ class StatsExchange:
         torch.cuda.current_stream(self.device).synchronize()   # the library continues on its own stream
         self._keep = gathered
         return gathered.data_ptr()
+
+
+def _view(ptr, n, typestr, device):
+    return torch.as_tensor(_DevicePointer(ptr, n, typestr), device=device)
+
+
+class TorchCollectives:
+    """fy_collectives (include/filmyou.h) played by torch.distributed: handed to RM2Job.run(collectives=...).
+
+    Backend "nccl" = RCCL over xGMI: the library's hipStream_t is made torch's current stream (ExternalStream), so the
+    collective is ordered behind the kernels already queued on it and the kernels queued afterwards wait for it -- no
+    host synchronisation.  Backend "gloo" (rehearsal on a one-GPU box / CPU tests of the plumbing) stages through host
+    memory with full synchronisation on both sides."""
+
+    def __init__(self, device_index, group=None):
+        self.device = torch.device("cuda", device_index)
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.nccl = dist.get_backend(group) == "nccl"
+        self.calls = {"all_gather": 0, "reduce_scatter_f32": 0, "bytes": 0}
+
+    def _stream(self, stream_ptr):
+        return torch.cuda.ExternalStream(int(stream_ptr), device=self.device)
+
+    def all_gather(self, send, recv, nbytes, stream):
+        s = _view(send, nbytes, "|u1", self.device)
+        r = _view(recv, nbytes * self.world, "|u1", self.device)
+        self.calls["all_gather"] += 1
+        self.calls["bytes"] += nbytes * self.world
+        ext = self._stream(stream)
+        if self.nccl:
+            with torch.cuda.stream(ext):
+                dist.all_gather_into_tensor(r, s, group=self.group)
+            return
+        ext.synchronize()
+        host = s.cpu()
+        outs = [torch.empty_like(host) for _ in range(self.world)]
+        dist.all_gather(outs, host, group=self.group)
+        r.copy_(torch.cat(outs))
+        torch.cuda.synchronize(self.device)
+
+    def reduce_scatter_f32(self, send, recv, count, stream):
+        s = _view(send, count * self.world, "<f4", self.device)
+        r = _view(recv, count, "<f4", self.device)
+        self.calls["reduce_scatter_f32"] += 1
+        self.calls["bytes"] += 4 * count * self.world
+        ext = self._stream(stream)
+        if self.nccl:
+            with torch.cuda.stream(ext):
+                dist.reduce_scatter_tensor(r, s, op=dist.ReduceOp.SUM, group=self.group)
+            return
+        ext.synchronize()
+        host = s.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)   # gloo has no reduce-scatter
+        r.copy_(host.view(self.world, -1)[self.rank])
+        torch.cuda.synchronize(self.device)
+
+
+class ThreadGroup:
+    """In-process stand-in for a process group: `world` threads of ONE process, each with its own fy context on the
+    same GPU, meet at a barrier.  Test harness for the cooperative multi-rank path on a one-GPU box."""
+
+    def __init__(self, world):
+        import threading
+        self.world = world
+        self.barrier = threading.Barrier(world)
+        self.slots = [None] * world
+
+
+class ThreadCollectives:
+    def __init__(self, group, rank, device_index=0):
+        self.g, self.rank, self.world = group, rank, group.world
+        self.device = torch.device("cuda", device_index)
+        self.calls = {"all_gather": 0, "reduce_scatter_f32": 0, "bytes": 0}
+
+    def _meet(self, mine, stream):
+        torch.cuda.ExternalStream(int(stream), device=self.device).synchronize()
+        self.g.slots[self.rank] = mine.clone()
+        torch.cuda.synchronize(self.device)
+        self.g.barrier.wait()
+        parts = list(self.g.slots)
+        return parts
+
+    def _leave(self):
+        torch.cuda.synchronize(self.device)
+        self.g.barrier.wait()
+
+    def all_gather(self, send, recv, nbytes, stream):
+        parts = self._meet(_view(send, nbytes, "|u1", self.device), stream)
+        _view(recv, nbytes * self.world, "|u1", self.device).copy_(torch.cat(parts))
+        self.calls["all_gather"] += 1
+        self.calls["bytes"] += nbytes * self.world
+        self._leave()
+
+    def reduce_scatter_f32(self, send, recv, count, stream):
+        parts = self._meet(_view(send, count * self.world, "<f4", self.device), stream)
+        total = parts[0].view(self.world, -1)[self.rank].clone()
+        for k in range(1, self.world):            # fixed rank order
+            total += parts[k].view(self.world, -1)[self.rank]
+        _view(recv, count, "<f4", self.device).copy_(total)
+        self.calls["reduce_scatter_f32"] += 1
+        self.calls["bytes"] += 4 * count * self.world
+        self._leave()

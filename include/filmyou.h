@@ -41,7 +41,8 @@ typedef enum {
     FY_ERR_DUPLICATE_RATING = -7,/* two ratings for one (user, item): Cassandra's PRIMARY KEY (user, item) forbids it */
     FY_ERR_NEGATIVE_ID = -8,     /* user / item ids must be >= 0 */
     FY_ERR_STATE = -9,           /* calls made out of order */
-    FY_ERR_UNSUPPORTED = -10
+    FY_ERR_UNSUPPORTED = -10,
+    FY_ERR_COLLECTIVE = -11      /* a fy_collectives callback returned non-zero */
 } fy_status;
 
 typedef struct fy_context fy_context;
@@ -98,6 +99,24 @@ int fy_rm2_prepare(fy_context*, const fy_rm2_params*, const fy_ratings*, int64_t
 int fy_rm2_partial_stats(fy_rm2_job*, double** device_buf, int64_t* len);
 /* `gathered` = world * len doubles in HBM, rank-major.  Summed in rank order (bit-reproducible).  Optional when world == 1. */
 int fy_rm2_set_global_stats(fy_rm2_job*, const double* gathered_device, int32_t world);
+/* Collectives of the process group the `world` ranks form (one process per GPU).  The signatures are RCCL's
+ * (ncclAllGather / ncclReduceScatter with ncclSum on float): device pointers, the operation is enqueued in order on
+ * `stream` (a hipStream_t) -- no host synchronisation is implied.  Return 0 on success.  `user` is handed back verbatim.
+ *   all_gather:      recv[k * bytes .. (k + 1) * bytes) = rank k's send[0 .. bytes)
+ *   reduce_scatter:  recv[i] = sum over ranks k of send_k[rank * count + i],  i < count   (send holds world * count floats)
+ * With collectives installed, a cluster whose users span ALL ranks is scored cooperatively: every rank
+ * builds only its row range of the cluster's co-rating matrix, evaluates every user's partial log-sums over those rows, and
+ * the partial sums of the seed columns, of the block bounds and of the surviving blocks are reduce-scattered to the rank
+ * that owns the user -- about 1/world of the single-GPU work and matrix per rank.  Without them (or when a cluster lives on
+ * fewer ranks) every rank builds the whole matrix of the clusters it holds users of, and only the user loop is sharded.
+ * If fy_rm2_set_global_stats was not called, fy_rm2_score all-gathers the partial statistics through `all_gather` itself.
+ * Every rank must install collectives (or none), and all ranks must call fy_rm2_score together. */
+typedef struct {
+    void* user;
+    int (*all_gather)(void* user, const void* send, void* recv, int64_t bytes, void* stream);
+    int (*reduce_scatter_f32)(void* user, const float* send, float* recv, int64_t count, void* stream);
+} fy_collectives;
+int fy_rm2_set_collectives(fy_rm2_job*, const fy_collectives*);
 /* Stage 2 (job RM2-3): per-cluster co-rating matrix, p(i|u) scoring of this rank's users, top-N. */
 int fy_rm2_score(fy_rm2_job*, fy_result** out);
 void fy_rm2_job_destroy(fy_rm2_job*);

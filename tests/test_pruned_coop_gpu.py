@@ -1,0 +1,165 @@
+"""The branch-and-bound path and the cooperative multi-rank path on data small enough for the oracle.
+
+Both are switched on by size in production (clusters of >= 8192 items); the tuning knobs FY_PRUNE_MIN_ITEMS /
+FY_M24_MIN_ITEMS / FY_SEED_CHUNKS force them onto MovieLens-100K-shaped data here, where the brute-force oracle decides.
+
+The cooperative path (fy_collectives, include/filmyou.h) is rehearsed on ONE GPU by `world` threads of this process,
+each with its own fy context, meeting in parallel.ThreadCollectives (a barrier + torch copies): the same library code
+and the same callback interface as the RCCL run, another transport."""
+import functools
+import threading
+
+import numpy as np
+import pytest
+
+import oracle
+from util import assert_topn_matches, pkg, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def forced(monkeypatch):
+    monkeypatch.setenv("FY_PRUNE_MIN_ITEMS", "256")
+    monkeypatch.setenv("FY_M24_MIN_ITEMS", "0")
+    monkeypatch.setenv("FY_SEED_CHUNKS", "1")
+
+
+@functools.lru_cache(maxsize=None)
+def oracle_case(shape, K, lam):
+    S = synth()
+    u, i, s, facts = S.generate(shape)
+    u, i, s = u.numpy(), i.numpy(), s.numpy()
+    uu = np.unique(u)
+    clustering = (uu, S.hash_clustering(uu, K))
+    ref = oracle.rm2(u, i, s, lam=float(lam), number_of_items=facts["n_items"], number_of_recommendations=1 << 30,
+                     number_of_clusters=K, map_user=clustering[0], map_cluster=clustering[1], n_threads=8)
+    return (u, i, s), clustering, facts, ref
+
+
+def make(shape, K, lam="0.1", top_n=20):
+    P = pkg()
+    (u, i, s), clustering, facts, ref = oracle_case(shape, K, lam)
+    conf = P.Configuration()
+    conf.set("lambda", lam)
+    conf.setInt("numberOfItems", facts["n_items"])
+    conf.setInt("numberOfClusters", K)
+    conf.setInt("numberOfRecommendations", top_n)
+    return (u, i, s), clustering, conf, ref
+
+
+def same_rows(a, b, tol=2e-6):
+    ka = sorted(zip(a["user"].tolist(), a["item"].tolist()))
+    kb = sorted(zip(b["user"].tolist(), b["item"].tolist()))
+    assert ka == kb
+    da = dict(zip(zip(a["user"].tolist(), a["item"].tolist()), a["score"].tolist()))
+    db = dict(zip(zip(b["user"].tolist(), b["item"].tolist()), b["score"].tolist()))
+    assert max(abs(da[k] - db[k]) / max(1e-3, abs(db[k])) for k in da) < tol
+
+
+@pytest.mark.parametrize("shape,K,lam,top_n", [("ml100k", 1, "0.1", 20), ("ml100k", 3, "0.5", 100), ("tiny", 1, "0.1", 10),
+                                              ("ml100k", 1, "0.0", 30)])
+def test_pruned_path_vs_oracle(forced, shape, K, lam, top_n):
+    P = pkg()
+    data, clustering, conf, ref = make(shape, K, lam, top_n)
+    ctx = P.Context(0)
+    rec = P.RM2Job(conf, ctx).run(data, clustering=clustering)
+    assert rec.stats["blocks_total"] > 0, "the branch and bound did not run"
+    assert rec.stats["blocks_survived"] < rec.stats["blocks_total"]
+    assert_topn_matches(rec.rows(), ref, top_n)
+    ctx.close()
+
+
+@pytest.mark.parametrize("select", [0, 1])
+def test_cooperative_path_world_1(forced, monkeypatch, select):
+    """identity collectives: the cooperative kernels alone (range offsets, partial bounds, packed survivors)"""
+    P = pkg()
+    data, clustering, conf, ref = make("ml100k", 1, "0.1", 20)
+    ctx = P.Context(0)
+    plain = P.RM2Job(conf, ctx).run(data, clustering=clustering).rows()
+    monkeypatch.setenv("FY_COOP_FORCE", "1")
+    monkeypatch.setenv("FY_TOPN_FORCE_SELECT", str(select))
+    rec = P.RM2Job(conf, ctx).run(data, clustering=clustering)
+    assert rec.stats["blocks_total"] > 0
+    assert_topn_matches(rec.rows(), ref, 20)
+    same_rows(rec.rows(), plain)
+    ctx.close()
+
+
+def run_threads(world, data, clustering, conf):
+    P = pkg()
+    par = __import__("importlib").import_module("filmyou-core_amd.parallel")
+    group = par.ThreadGroup(world)
+    out, err, comms = [None] * world, [None] * world, [None] * world
+
+    def body(rank):
+        try:
+            ctx = P.Context(0)
+            comms[rank] = par.ThreadCollectives(group, rank, 0)
+            rec = P.RM2Job(conf, ctx).run(data, clustering=clustering, rank=rank, world=world, collectives=comms[rank])
+            out[rank] = (rec.rows(), dict(rec.stats))
+            rec.close()
+            ctx.close()
+        except BaseException as e:      # a dead rank must not leave the others at the barrier
+            err[rank] = e
+            group.barrier.abort()
+
+    threads = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(600)
+    for e in err:
+        if e is not None and not isinstance(e, threading.BrokenBarrierError):
+            raise e
+    assert all(o is not None for o in out), err
+    return out, comms
+
+
+@pytest.mark.parametrize("world,K,select", [(2, 1, 0), (3, 1, 0), (4, 1, 1), (8, 1, 0), (2, 2, 0)])
+def test_cooperative_ranks_equal_single(forced, monkeypatch, world, K, select):
+    P = pkg()
+    data, clustering, conf, ref = make("ml100k", K, "0.1", 20)
+    ctx = P.Context(0)
+    single = P.RM2Job(conf, ctx).run(data, clustering=clustering)
+    single_rows, single_stats = single.rows(), dict(single.stats)
+    ctx.close()
+    monkeypatch.setenv("FY_TOPN_FORCE_SELECT", str(select))
+    out, comms = run_threads(world, data, clustering, conf)
+    rows = {k: np.concatenate([o[0][k] for o in out]) for k in ("user", "item", "score", "cluster")}
+    owners = [set(o[0]["user"].tolist()) for o in out]
+    assert sum(len(o) for o in owners) == len(set().union(*owners)) == len(np.unique(single_rows["user"]))
+    assert_topn_matches(rows, ref, 20)
+    same_rows(rows, single_rows)
+    if K == 1:
+        # one all-gather for the statistics, then per cooperative cluster: seed + bounds (+ survivors) reduce-scatters
+        assert all(c.calls["reduce_scatter_f32"] >= 2 for c in comms), [c.calls for c in comms]
+        # every rank built only its share of the matrix rows
+        assert sum(o[1]["users_scored"] for o in out) == single_stats["users_scored"]
+    assert all(c.calls["all_gather"] >= 1 for c in comms)
+
+
+def test_collectives_installed_but_clusters_stay_local(forced):
+    """K = 12 clusters on 2 ranks: no cluster spans... at most the boundary cluster spans both ranks; every other
+    cluster takes the replicated path while the statistics still travel through the callbacks"""
+    data, clustering, conf, ref = make("ml100k", 12, "0.1", 20)
+    out, comms = run_threads(2, data, clustering, conf)
+    rows = {k: np.concatenate([o[0][k] for o in out]) for k in ("user", "item", "score", "cluster")}
+    assert_topn_matches(rows, ref, 20)
+
+
+def test_failing_collective_fails_the_job(forced):
+    P = pkg()
+    data, clustering, conf, _ = make("tiny", 1)
+
+    class Broken:
+        def all_gather(self, *a):
+            raise OSError("link down")
+
+        def reduce_scatter_f32(self, *a):
+            raise OSError("link down")
+
+    ctx = P.Context(0)
+    with pytest.raises(RuntimeError, match="RM2 failed!: collective"):
+        P.RM2Job(conf, ctx).run(data, clustering=clustering, rank=0, world=2, collectives=Broken())
+    ctx.close()
