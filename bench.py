@@ -99,11 +99,19 @@ def main():
     conf.setInt("numberOfRecommendations", top_n)
     ctx = P.Context(local_rank)
     ratings = P.Ratings(ctx, user, item, score)       # resident in HBM before the timed region
-    exchange = par.StatsExchange(local_rank) if world > 1 else None
+    # world > 1: RCCL collectives through torch.distributed (fy_collectives): the item statistics are all-gathered and
+    # a cluster that spans all ranks is scored cooperatively (row-sharded matrix build, reduce-scattered partial sums);
+    # FY_BENCH_EXCHANGE_ONLY=1 keeps the round-1 flow (statistics exchange only, matrix replicated) for comparison
+    exchange = collectives = None
+    if world > 1:
+        if os.environ.get("FY_BENCH_EXCHANGE_ONLY") == "1":
+            exchange = par.StatsExchange(local_rank)
+        else:
+            collectives = par.TorchCollectives(local_rank)
     job = P.RM2Job(conf, ctx)
 
     def step():
-        rec = job.run(ratings, clustering=clustering, rank=rank, world=world, exchange=exchange)
+        rec = job.run(ratings, clustering=clustering, rank=rank, world=world, exchange=exchange, collectives=collectives)
         st = rec.stats
         rec.close()
         return st

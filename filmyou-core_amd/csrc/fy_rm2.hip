@@ -1347,7 +1347,7 @@ struct CoopShared {
     int32_t lo;
     EventTimer *t_cooc, *t_score, *t_topn;
     unsigned long long* prune_counters;
-    int64_t *blocks_total, *seed_terms_cols, *coop_survived;
+    int64_t *blocks_total, *seed_terms_cols, *coop_survived, *coop_pair_contribs;
 };
 
 static void coll_all_gather(fy_rm2_job* J, const void* send, void* recv, int64_t bytes, hipStream_t st) {
@@ -1393,6 +1393,7 @@ static void score_cluster_coop(const CoopShared& X, const Plan& p, hipStream_t l
 
     // ---- item rows of this rank: equal shares of the work model (row kernel + scoring passes)
     std::vector<int32_t> rsplit(W + 1, Ic), hcnt;
+    std::vector<int64_t> all_hw;
     {
         DevBuf<int64_t> work(ctx, (size_t)Ic);
         DevBuf<int32_t> cnt(ctx, (size_t)Ic);
@@ -1414,10 +1415,12 @@ static void score_cluster_coop(const CoopShared& X, const Plan& p, hipStream_t l
             while (k < W && run * W >= total * k) rsplit[k++] = i + 1;
         }
         // (entries not reached stay at Ic)
+        all_hw.swap(hw);
     }
     const int32_t r0 = rsplit[me], r1 = rsplit[me + 1], nrows = r1 - r0;
-    int64_t my_ratings = 0;
-    for (int32_t i = r0; i < r1; i++) my_ratings += hcnt[i];
+    int64_t my_ratings = 0, my_walk = 0;
+    for (int32_t i = r0; i < r1; i++) { my_ratings += hcnt[i]; my_walk += all_hw[i] - 300 * (int64_t)hcnt[i]; }
+    *X.coop_pair_contribs += my_walk - my_ratings;   // ordered off-diagonal co-rating pairs whose row is mine
 
     // ---- buffers
     const int n_chunks = (int)ceil_div(Ic, 256);
@@ -1656,6 +1659,8 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
     const double lambda = prm.lambda;
     const ScoreTune tune = score_tune();
     const bool pack24_allowed = tune.pack24 && tune.vec == 4;
+    int64_t coop_pair_contribs = 0;   // cooperative clusters: ordered off-diagonal co-rating pairs of this rank's matrix rows
+    bool any_coop = false;
 
     // ---- p(i|C), per-(cluster,item) statistics, per-rating values
     R->d_icoll.alloc(ctx, nI);
@@ -1826,6 +1831,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
         DevBuf<unsigned long long> prune_counters(ctx, 2);   // [0] surviving blocks, [1] log terms evaluated by the three pruned passes
         prune_counters.zero();
         int64_t prune_blocks_total = 0, prune_seed_terms_cols = 0, coop_survived = 0;
+        for (auto& p : plans) any_coop = any_coop || p.coop;
         // segment tables of the row kernel, one per cluster, built on the main stream before the lanes fork
         std::vector<SegTable> segs(plans.size());
         {
@@ -1857,7 +1863,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             if (p.coop) {
                 CoopShared X{J, R.get(), &tune, p_rank.get(), b_rank.get(), a_rank.get(), csc_x.get(), csr_x.get(), csr_e.get(),
                              n_out.get(), out_off.get(), lo, &t_cooc, &t_score, &t_topn, prune_counters.get(),
-                             &prune_blocks_total, &prune_seed_terms_cols, &coop_survived};
+                             &prune_blocks_total, &prune_seed_terms_cols, &coop_survived, &coop_pair_contribs};
                 score_cluster_coop(X, p, ls);
                 continue;
             }
@@ -2006,7 +2012,8 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
     t_total.end(span_total);
     d2h(ctx, &R->total_sum, d_total.get(), 1);
     sync(ctx);
-    R->st.pair_contribs = P.sum_deg2;
+    // (bench.py prices the row kernel with (pair_contribs - nnz) / 2 unordered pairs: a cooperative rank walked only its rows)
+    R->st.pair_contribs = any_coop ? coop_pair_contribs + P.nnz : P.sum_deg2;
     R->st.ms_cooc = t_cooc.total_ms();
     R->st.ms_score = t_score.total_ms();
     R->st.ms_topn = t_topn.total_ms();

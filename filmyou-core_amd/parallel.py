@@ -79,6 +79,14 @@ class StatsExchange:
 
 
 def _view(ptr, n, typestr, device):
+    """n elements of `typestr` at raw address `ptr` as a torch tensor without a copy (HBM, or host memory when the
+    device is the CPU: the gloo tests of the collective contract)."""
+    if device.type == "cpu":
+        import ctypes
+        import numpy as np
+        dt = np.dtype(typestr)
+        buf = (ctypes.c_char * (n * dt.itemsize)).from_address(int(ptr))
+        return torch.from_numpy(np.frombuffer(buf, dtype=dt))
     return torch.as_tensor(_DevicePointer(ptr, n, typestr), device=device)
 
 
@@ -91,7 +99,7 @@ class TorchCollectives:
     memory with full synchronisation on both sides."""
 
     def __init__(self, device_index, group=None):
-        self.device = torch.device("cuda", device_index)
+        self.device = torch.device("cuda", device_index) if device_index is not None else torch.device("cpu")
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
@@ -101,49 +109,62 @@ class TorchCollectives:
     def _stream(self, stream_ptr):
         return torch.cuda.ExternalStream(int(stream_ptr), device=self.device)
 
+    def _before_host(self, stream_ptr):
+        if self.device.type == "cuda":
+            self._stream(stream_ptr).synchronize()
+
+    def _after_host(self):
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+
     def all_gather(self, send, recv, nbytes, stream):
         s = _view(send, nbytes, "|u1", self.device)
         r = _view(recv, nbytes * self.world, "|u1", self.device)
         self.calls["all_gather"] += 1
         self.calls["bytes"] += nbytes * self.world
-        ext = self._stream(stream)
         if self.nccl:
-            with torch.cuda.stream(ext):
+            with torch.cuda.stream(self._stream(stream)):
                 dist.all_gather_into_tensor(r, s, group=self.group)
             return
-        ext.synchronize()
+        self._before_host(stream)
         host = s.cpu()
         outs = [torch.empty_like(host) for _ in range(self.world)]
         dist.all_gather(outs, host, group=self.group)
         r.copy_(torch.cat(outs))
-        torch.cuda.synchronize(self.device)
+        self._after_host()
 
     def reduce_scatter_f32(self, send, recv, count, stream):
         s = _view(send, count * self.world, "<f4", self.device)
         r = _view(recv, count, "<f4", self.device)
         self.calls["reduce_scatter_f32"] += 1
         self.calls["bytes"] += 4 * count * self.world
-        ext = self._stream(stream)
         if self.nccl:
-            with torch.cuda.stream(ext):
+            with torch.cuda.stream(self._stream(stream)):
                 dist.reduce_scatter_tensor(r, s, op=dist.ReduceOp.SUM, group=self.group)
             return
-        ext.synchronize()
-        host = s.cpu()
+        self._before_host(stream)
+        host = s.cpu().clone()
         dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)   # gloo has no reduce-scatter
         r.copy_(host.view(self.world, -1)[self.rank])
-        torch.cuda.synchronize(self.device)
+        self._after_host()
 
 
 class ThreadGroup:
     """In-process stand-in for a process group: `world` threads of ONE process, each with its own fy context on the
-    same GPU, meet at a barrier.  Test harness for the cooperative multi-rank path on a one-GPU box."""
+    same GPU, meet at a barrier.  Test harness for the cooperative multi-rank path on a one-GPU box.
 
-    def __init__(self, world):
+    serialize=True: only one rank computes at a time (a lock handed over at every collective), so each rank's HIP-event
+    and wall-clock phase times are those of a GPU it has to itself; `busy_s[rank]` adds up the time a rank held the GPU,
+    i.e. its compute critical path without communication (tools/coop_rehearsal.py)."""
+
+    def __init__(self, world, serialize=False):
         import threading
         self.world = world
         self.barrier = threading.Barrier(world)
         self.slots = [None] * world
+        self.lock = threading.Lock() if serialize else None
+        self.busy_s = [0.0] * world
+        self.busy_log = [[] for _ in range(world)]
 
 
 class ThreadCollectives:
@@ -151,28 +172,46 @@ class ThreadCollectives:
         self.g, self.rank, self.world = group, rank, group.world
         self.device = torch.device("cuda", device_index)
         self.calls = {"all_gather": 0, "reduce_scatter_f32": 0, "bytes": 0}
+        self._t0 = None
 
-    def _meet(self, mine, stream):
+    # -- serialised rehearsal: the rank owns the GPU between enter() / a collective / the next collective / leave()
+    def enter(self):
+        if self.g.lock is not None:
+            import time
+            self.g.lock.acquire()
+            self._t0 = time.perf_counter()
+
+    def leave(self, what="end"):
+        if self.g.lock is not None:
+            import time
+            torch.cuda.synchronize(self.device)
+            dt = time.perf_counter() - self._t0
+            self.g.busy_s[self.rank] += dt
+            self.g.busy_log[self.rank].append((what, dt))
+            self.g.lock.release()
+
+    def _meet(self, mine, stream, what):
         torch.cuda.ExternalStream(int(stream), device=self.device).synchronize()
+        self.leave(what)
         self.g.slots[self.rank] = mine.clone()
         torch.cuda.synchronize(self.device)
         self.g.barrier.wait()
-        parts = list(self.g.slots)
-        return parts
+        return list(self.g.slots)
 
     def _leave(self):
         torch.cuda.synchronize(self.device)
         self.g.barrier.wait()
+        self.enter()
 
     def all_gather(self, send, recv, nbytes, stream):
-        parts = self._meet(_view(send, nbytes, "|u1", self.device), stream)
+        parts = self._meet(_view(send, nbytes, "|u1", self.device), stream, "all_gather %d B" % nbytes)
         _view(recv, nbytes * self.world, "|u1", self.device).copy_(torch.cat(parts))
         self.calls["all_gather"] += 1
         self.calls["bytes"] += nbytes * self.world
         self._leave()
 
     def reduce_scatter_f32(self, send, recv, count, stream):
-        parts = self._meet(_view(send, count * self.world, "<f4", self.device), stream)
+        parts = self._meet(_view(send, count * self.world, "<f4", self.device), stream, "reduce_scatter %d B" % (4 * count * self.world))
         total = parts[0].view(self.world, -1)[self.rank].clone()
         for k in range(1, self.world):            # fixed rank order
             total += parts[k].view(self.world, -1)[self.rank]

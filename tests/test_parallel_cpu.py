@@ -66,3 +66,71 @@ def test_single_process_degenerates():
     assert torch.equal(par.combine_in_rank_order(torch.cat([t, t, t]), 3), 3 * t)
     assert par.env_world() == (int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)),
                                int(os.environ.get("WORLD_SIZE", 1)))
+
+
+# ---------------------------------------------------------------- the cooperative decomposition (fy_collectives)
+def _coop_worker(rank, world, port, golden_path, out_dir):
+    """Every rank holds a ROW RANGE of M and evaluates every user's partial log-sums over the rated items in its rows;
+    reduce_scatter_f32 (parallel.TorchCollectives, gloo, host pointers) hands each user's owner the complete sums.
+    numpy stands in for the HIP kernels; the collective contract and the decomposition are what is tested."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    par = importlib.import_module("filmyou-core_amd.parallel")
+    par.init_distributed(backend="gloo")
+    import json
+    g = json.load(open(golden_path))
+    A = np.asarray(g["A_items_by_users"], dtype=np.float64).T              # users x items, one cluster (all users)
+    U, I = A.shape
+    lam, n_items_conf = 0.1, I
+    su = A.sum(1)
+    X = A / su[:, None]
+    p = A.sum(0) / np.floor(su).sum()
+    b = X.sum(0)
+    M = (1 - lam) ** 2 * (X.T @ X) + lam * (1 - lam) * np.outer(p, b)       # M[j][i]
+    r0, r1 = rank * I // world, (rank + 1) * I // world                    # my item rows
+    bounds = [k * U // world for k in range(world + 1)]                    # user ownership
+    umax = max(bounds[k + 1] - bounds[k] for k in range(world))
+    send = np.zeros((world, umax, I), dtype=np.float32)
+    for k in range(world):
+        for u in range(bounds[k], bounds[k + 1]):
+            J = np.flatnonzero(A[u] > 0)
+            mine = J[(J >= r0) & (J < r1)]
+            e = (1 - lam) * (b[mine] - X[u, mine]) + lam * (U - 1) * p[mine]
+            part = np.log(M[mine, :] + np.outer(e, lam * p)).sum(0)
+            if rank == 0:                                                   # pvpi enters the sum once
+                part = part + (len(J) - 1) * np.log(n_items_conf) - len(J) * np.log(U)
+            part[mine] = np.nan                                             # the row's holder masks the rated candidate
+            send[k, u - bounds[k]] = part
+    recv = np.full((umax, I), -1.0, dtype=np.float32)
+    coll = par.TorchCollectives(None)
+    coll.reduce_scatter_f32(send.ctypes.data, recv.ctypes.data, umax * I, 0)
+    # all-gather contract: rank-major byte segments
+    mine8 = np.full(5, rank, dtype=np.uint8)
+    got = np.zeros(5 * world, dtype=np.uint8)
+    coll.all_gather(mine8.ctypes.data, got.ctypes.data, 5, 0)
+    assert got.reshape(world, 5).tolist() == [[k] * 5 for k in range(world)]
+    np.save(os.path.join(out_dir, "scores_%d.npy" % rank), recv[:bounds[rank + 1] - bounds[rank]])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("world", [2, 3])
+def test_cooperative_partial_sums_reduce_to_the_oracle_scores(tmp_path, world):
+    import oracle
+    port = _free_port()
+    golden = os.path.join(ROOT, "tests", "golden", "rm_test_data.json")
+    mp.spawn(_coop_worker, args=(world, port, golden, str(tmp_path)), nprocs=world, join=True)
+    scores = np.concatenate([np.load(tmp_path / ("scores_%d.npy" % r)) for r in range(world)])     # users x items
+    import json
+    A = np.asarray(json.load(open(golden))["A_items_by_users"], dtype=np.float64).T
+    U, I = A.shape
+    uu, ii = np.nonzero(A)
+    ref = oracle.rm2(uu + 1, ii + 1, A[uu, ii].astype(np.float32), lam=0.1, number_of_items=I,
+                     number_of_recommendations=1 << 30, number_of_clusters=1)
+    assert scores.shape == (U, I)
+    got = scores[ref["rec_user"] - 1, ref["rec_item"] - 1].astype(np.float64)
+    np.testing.assert_allclose(got, ref["rec_score"].astype(np.float64), rtol=1e-5)
+    # rated candidates stayed masked through the sum, everything else is a score
+    assert np.array_equal(np.isnan(scores), A > 0)
