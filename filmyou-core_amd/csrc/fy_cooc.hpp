@@ -37,6 +37,9 @@ struct CoocArgs {
     int32_t q0;         // first CSC entry of the cluster
     int32_t nq;         // CSC entries of the cluster
     int32_t debug;      // timing experiments only (wrong results): 1 = no LDS atomics
+    // optional (cooperative ranks): the segment table covers only the CSC entries of rows [row0, row0 + nrows), renumbered
+    // row by row; local_start[row - row0] = first local entry of the row (then q0 = 0, nq = local entries)
+    const int32_t* __restrict__ local_start;
 };
 
 // Accumulates chunk `ch` of row `row` into the workgroup's dynamic LDS (fy_cooc_acc[0..CH), zeroed by the caller; all
@@ -58,7 +61,8 @@ __device__ __forceinline__ void cooc_accumulate_row(const CoocArgs& A, int row, 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = blockDim.x >> 6;
     const int pair = A.rank_pair[A.pbase + row];
-    const int e0 = A.pair_start[pair], e1 = A.pair_start[pair + 1];
+    int e0 = A.pair_start[pair], e1 = A.pair_start[pair + 1];
+    if (A.local_start) { e0 = A.local_start[row - A.row0]; e1 = A.local_start[row - A.row0 + 1]; }
     const int32_t* __restrict__ sp = A.seg_ptr + (int64_t)ch * (A.nq + 1) - A.q0;
     const int s_begin = sp[e0], s_end = sp[e1];
     const int c0 = ch * A.CH;

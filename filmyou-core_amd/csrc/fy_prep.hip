@@ -73,19 +73,39 @@ static inline int grid_for(int64_t n, int block = 256, int cap = 256 * 16) {
     return (int)std::max<int64_t>(1, std::min<int64_t>(g, cap));
 }
 
-// key = user:item for kept ratings, all-ones for dropped ones (they sort to the end)
+// largest user / item id among the kept ratings: the sort keys are packed into as few bits as the ids need (every 8 bits
+// less is one radix pass over 25 M pairs less)
+__global__ void k_max_ids(int64_t n, const int32_t* __restrict__ user, const int32_t* __restrict__ item,
+                          const float* __restrict__ score, int keep_nonpositive, int32_t* __restrict__ max_ids) {
+    int32_t mu = -1, mi = -1;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        const float s = score[t];
+        if (keep_nonpositive ? (s == s) : (s > 0.0f)) { mu = max(mu, user[t]); mi = max(mi, item[t]); }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        mu = max(mu, __shfl_down(mu, o, 64));
+        mi = max(mi, __shfl_down(mi, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (mu >= 0) atomicMax(&max_ids[0], mu);
+        if (mi >= 0) atomicMax(&max_ids[1], mi);
+    }
+}
+
+// key = (user << ib) | item for kept ratings; dropped ones get the key of user `drop_user` (beyond every kept user: they
+// sort to the end)
 __global__ void k_user_item_keys(int64_t n, const int32_t* __restrict__ user, const int32_t* __restrict__ item,
-                                 const float* __restrict__ score, int keep_nonpositive, uint64_t* __restrict__ keys,
-                                 unsigned long long* __restrict__ kept, int* __restrict__ err) {
+                                 const float* __restrict__ score, int keep_nonpositive, int ib, uint32_t drop_user,
+                                 uint64_t* __restrict__ keys, unsigned long long* __restrict__ kept, int* __restrict__ err) {
     unsigned long long local = 0;
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
         const float s = score[t];
         const bool keep = keep_nonpositive ? (s == s) : (s > 0.0f);   // NaN never passes "score > 0"
-        uint64_t k = ~0ull;
+        uint64_t k = (uint64_t)drop_user << ib;
         if (keep) {
             const int32_t u = user[t], i = item[t];
             if (u < 0 || i < 0) atomicOr(err, ERR_NEG_ID);
-            k = ((uint64_t)(uint32_t)u << 32) | (uint32_t)i;
+            k = ((uint64_t)(uint32_t)u << ib) | (uint32_t)i;
             local++;
         }
         keys[t] = k;
@@ -96,12 +116,12 @@ __global__ void k_user_item_keys(int64_t n, const int32_t* __restrict__ user, co
 }
 
 __global__ void k_heads_hi32(int64_t n, const uint64_t* __restrict__ keys, uint32_t* __restrict__ head, int check_dup,
-                             int* __restrict__ err) {
+                             int* __restrict__ err, int ib) {
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
         uint32_t h = 1;
         if (t > 0) {
             const uint64_t a = keys[t - 1], b = keys[t];
-            h = (a >> 32) != (b >> 32);
+            h = (a >> ib) != (b >> ib);
             if (check_dup && a == b) atomicOr(err, ERR_DUP);
         }
         head[t] = h;
@@ -115,11 +135,11 @@ __global__ void k_heads_full(int64_t n, const uint64_t* __restrict__ keys, uint3
 
 // at every user head: uid[du] = raw id, ustart[du] = t
 __global__ void k_scatter_users(int64_t n, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ head,
-                                const uint32_t* __restrict__ du1, int32_t* __restrict__ uid, int32_t* __restrict__ ustart) {
+                                const uint32_t* __restrict__ du1, int32_t* __restrict__ uid, int32_t* __restrict__ ustart, int ib) {
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x)
         if (head[t]) {
             const uint32_t d = du1[t] - 1;
-            uid[d] = (int32_t)(keys[t] >> 32);
+            uid[d] = (int32_t)(keys[t] >> ib);
             ustart[d] = (int32_t)t;
         }
 }
@@ -182,23 +202,26 @@ __global__ void k_invert_perm(int32_t n, const uint32_t* __restrict__ perm, int3
 
 // (cluster : raw item) key of every rating, payload = position in the user-major order
 __global__ void k_cluster_item_keys(int64_t n, const uint64_t* __restrict__ ukeys, const uint32_t* __restrict__ du1,
-                                    const int32_t* __restrict__ ucluster, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+                                    const int32_t* __restrict__ ucluster, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                    int ib) {
+    const uint64_t mask = ((uint64_t)1 << ib) - 1;
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
         const uint32_t c = (uint32_t)ucluster[du1[t] - 1];
-        keys[t] = ((uint64_t)c << 32) | (uint32_t)ukeys[t];
+        keys[t] = ((uint64_t)c << ib) | (ukeys[t] & mask);
         vals[t] = (uint32_t)t;
     }
 }
 
 __global__ void k_scatter_pairs(int64_t n, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ head,
                                 const uint32_t* __restrict__ pr1, int32_t* __restrict__ pair_cluster,
-                                int32_t* __restrict__ pair_item, int32_t* __restrict__ pair_start, int32_t* __restrict__ pcount) {
+                                int32_t* __restrict__ pair_item, int32_t* __restrict__ pair_start, int32_t* __restrict__ pcount, int ib) {
+    const uint64_t mask = ((uint64_t)1 << ib) - 1;
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x)
         if (head[t]) {
             const uint32_t p = pr1[t] - 1;
-            const int32_t c = (int32_t)(keys[t] >> 32);
+            const int32_t c = (int32_t)(keys[t] >> ib);
             pair_cluster[p] = c;
-            pair_item[p] = (int32_t)(uint32_t)keys[t];
+            pair_item[p] = (int32_t)(uint32_t)(keys[t] & mask);
             pair_start[p] = (int32_t)t;
             atomicAdd(&pcount[c], 1);
         }
@@ -257,14 +280,15 @@ __global__ void k_scatter_ranks(int32_t nP, const uint32_t* __restrict__ rank_pa
 }
 
 __global__ void k_csr_keys(int64_t n, const int32_t* __restrict__ csc_slot, const int32_t* __restrict__ csc_pair,
-                           const int32_t* __restrict__ pair_rank, uint64_t* __restrict__ keys) {
+                           const int32_t* __restrict__ pair_rank, uint64_t* __restrict__ keys, int rb) {
     for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x)
-        keys[q] = ((uint64_t)(uint32_t)csc_slot[q] << 32) | (uint32_t)pair_rank[csc_pair[q]];
+        keys[q] = ((uint64_t)(uint32_t)csc_slot[q] << rb) | (uint32_t)pair_rank[csc_pair[q]];
 }
 
-__global__ void k_low32(int64_t n, const uint64_t* __restrict__ keys, int32_t* __restrict__ out) {
+__global__ void k_low_bits(int64_t n, const uint64_t* __restrict__ keys, int32_t* __restrict__ out, int rb) {
+    const uint64_t mask = ((uint64_t)1 << rb) - 1;
     for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x)
-        out[q] = (int32_t)(uint32_t)keys[q];
+        out[q] = (int32_t)(uint32_t)(keys[q] & mask);
 }
 
 __global__ void k_slot_degrees(int32_t nU, const int32_t* __restrict__ slot2du, const int32_t* __restrict__ udeg,
@@ -302,11 +326,23 @@ void build_structure(Context* ctx, const fy_ratings* R, int32_t K, int64_t n_map
     // ---- sort #1: user-major order, duplicates / negative ids detected
     DevBuf<uint64_t> k1a(ctx, n_in), k1b(ctx, n_in);
     DevBuf<float> sc_um(ctx, n_in);
+    auto bits_for = [](uint64_t v) { int b = 0; while (v) { b++; v >>= 1; } return b; };   // bits that hold every value <= v
+    int ib = 1;   // bits of the item field of the sort keys
     if (n_in) {
-        k_user_item_keys<<<grid_for(n_in), 256, 0, st>>>(n_in, R->user.get(), R->item.get(), R->score.get(),
-                                                          keep_nonpositive ? 1 : 0, k1a.get(), kept.get(), err.get());
+        DevBuf<int32_t> max_ids(ctx, 2);
+        FY_HIP(hipMemsetAsync(max_ids.get(), 0xFF, 2 * sizeof(int32_t), st));   // -1
+        k_max_ids<<<grid_for(n_in), 256, 0, st>>>(n_in, R->user.get(), R->item.get(), R->score.get(), keep_nonpositive ? 1 : 0, max_ids.get());
         FY_KERNEL_CHECK();
-        sort_pairs_u64_f32(ctx, k1a.get(), k1b.get(), const_cast<float*>(R->score.get()), sc_um.get(), n_in);
+        int32_t hmax[2];
+        d2h(ctx, hmax, max_ids.get(), 2);
+        sync(ctx);
+        const uint32_t drop_user = (uint32_t)(hmax[0] + 1);
+        ib = std::max(1, bits_for((uint64_t)std::max(0, hmax[1])));
+        const int ub = std::max(1, bits_for(drop_user));
+        k_user_item_keys<<<grid_for(n_in), 256, 0, st>>>(n_in, R->user.get(), R->item.get(), R->score.get(),
+                                                          keep_nonpositive ? 1 : 0, ib, drop_user, k1a.get(), kept.get(), err.get());
+        FY_KERNEL_CHECK();
+        sort_pairs_u64_f32(ctx, k1a.get(), k1b.get(), const_cast<float*>(R->score.get()), sc_um.get(), n_in, std::min(64, ib + ub));
     }
     const int64_t nnz = (int64_t)fetch(ctx, kept.get());
     P.nnz = nnz;
@@ -323,7 +359,7 @@ void build_structure(Context* ctx, const fy_ratings* R, int32_t K, int64_t n_map
     uint64_t* ukeys = k1b.get();   // (user:item) ascending, first nnz entries are the kept ratings
 
     DevBuf<uint32_t> head(ctx, nnz), du1(ctx, nnz);
-    k_heads_hi32<<<grid_for(nnz), 256, 0, st>>>(nnz, ukeys, head.get(), 1, err.get());
+    k_heads_hi32<<<grid_for(nnz), 256, 0, st>>>(nnz, ukeys, head.get(), 1, err.get(), ib);
     FY_KERNEL_CHECK();
     inclusive_scan_u32(ctx, head.get(), du1.get(), nnz);
     const int32_t nU = (int32_t)fetch(ctx, du1.get() + (nnz - 1));
@@ -332,7 +368,7 @@ void build_structure(Context* ctx, const fy_ratings* R, int32_t K, int64_t n_map
 
     P.uid.alloc(ctx, nU);
     DevBuf<int32_t> ustart(ctx, (size_t)nU + 1);
-    k_scatter_users<<<grid_for(nnz), 256, 0, st>>>(nnz, ukeys, head.get(), du1.get(), P.uid.get(), ustart.get());
+    k_scatter_users<<<grid_for(nnz), 256, 0, st>>>(nnz, ukeys, head.get(), du1.get(), P.uid.get(), ustart.get(), ib);
     FY_KERNEL_CHECK();
     {
         const int32_t last = (int32_t)nnz;
@@ -396,9 +432,9 @@ void build_structure(Context* ctx, const fy_ratings* R, int32_t K, int64_t n_map
     {
         DevBuf<uint64_t> k3a(ctx, nnz);
         DevBuf<uint32_t> v3a(ctx, nnz);
-        k_cluster_item_keys<<<grid_for(nnz), 256, 0, st>>>(nnz, ukeys, du1.get(), P.ucluster.get(), k3a.get(), v3a.get());
+        k_cluster_item_keys<<<grid_for(nnz), 256, 0, st>>>(nnz, ukeys, du1.get(), P.ucluster.get(), k3a.get(), v3a.get(), ib);
         FY_KERNEL_CHECK();
-        sort_pairs_u64_u32(ctx, k3a.get(), k3b.get(), v3a.get(), t_sorted.get(), nnz);
+        sort_pairs_u64_u32(ctx, k3a.get(), k3b.get(), v3a.get(), t_sorted.get(), nnz, std::min(64, ib + bits_for((uint64_t)(K - 1))));
     }
     DevBuf<uint32_t> pr1(ctx, nnz);
     k_heads_full<<<grid_for(nnz), 256, 0, st>>>(nnz, k3b.get(), head.get());
@@ -411,7 +447,7 @@ void build_structure(Context* ctx, const fy_ratings* R, int32_t K, int64_t n_map
     DevBuf<int32_t> pair_item(ctx, nP), pcount(ctx, (size_t)K);
     pcount.zero();
     k_scatter_pairs<<<grid_for(nnz), 256, 0, st>>>(nnz, k3b.get(), head.get(), pr1.get(), P.pair_cluster.get(),
-                                                    pair_item.get(), P.pair_start.get(), pcount.get());
+                                                    pair_item.get(), P.pair_start.get(), pcount.get(), ib);
     FY_KERNEL_CHECK();
     const int32_t last_pair = (int32_t)nnz;   // must outlive the copy (synchronised just below)
     h2d(ctx, P.pair_start.get() + nP, &last_pair, 1);
@@ -474,12 +510,15 @@ void build_structure(Context* ctx, const fy_ratings* R, int32_t K, int64_t n_map
     // ---- sort #6: CSR in slot order, compact index ascending inside a row
     {
         DevBuf<uint64_t> ka(ctx, nnz), kb(ctx, nnz);
-        k_csr_keys<<<grid_for(nnz), 256, 0, st>>>(nnz, P.csc_slot.get(), P.csc_pair.get(), P.pair_rank.get(), ka.get());
+        int32_t max_Ic = 1;
+        for (int c = 0; c < K; c++) max_Ic = std::max(max_Ic, P.pcstart[c + 1] - P.pcstart[c]);
+        const int rb = std::max(1, bits_for((uint64_t)(max_Ic - 1)));   // key = (slot << rb) | compact item index
+        k_csr_keys<<<grid_for(nnz), 256, 0, st>>>(nnz, P.csc_slot.get(), P.csc_pair.get(), P.pair_rank.get(), ka.get(), rb);
         FY_KERNEL_CHECK();
         P.csr_r.alloc(ctx, nnz);
-        sort_pairs_u64_f32(ctx, ka.get(), kb.get(), P.csc_r.get(), P.csr_r.get(), nnz);
+        sort_pairs_u64_f32(ctx, ka.get(), kb.get(), P.csc_r.get(), P.csr_r.get(), nnz, std::min(64, rb + std::max(1, bits_for((uint64_t)(nU - 1)))));
         P.csr_idx.alloc(ctx, nnz);
-        k_low32<<<grid_for(nnz), 256, 0, st>>>(nnz, kb.get(), P.csr_idx.get());
+        k_low_bits<<<grid_for(nnz), 256, 0, st>>>(nnz, kb.get(), P.csr_idx.get(), rb);
         FY_KERNEL_CHECK();
     }
 

@@ -29,20 +29,94 @@ static inline int grid_for(int64_t n, int block = 256, int cap = 256 * 16) {
 }
 
 // ================================================================ statistics (jobs RM2-1 / RM2-2)
-// this rank's partial per-item sums: sum of (double) score over the ratings of the users in [lo, hi).  One wave per
-// (cluster, item) column of the CSC, one atomic per column (a per-rating atomic version spent 4 ms on the popular items).
-__global__ void k_partial_item_sums(int32_t nP, const int32_t* __restrict__ pair_start, const int32_t* __restrict__ csc_slot,
-                                    const float* __restrict__ csc_r, const int32_t* __restrict__ pair_di, int32_t lo,
-                                    int32_t hi, double* __restrict__ partial) {
+// One walk over the CSC gives everything that is summed per (cluster, item) column: this rank's PARTIAL rating sum (users
+// in slots [lo, hi), the exchange buffer), b = sum_v r_vi / s_v, and the row kernel's work model sum_v n_v.
+// Columns are processed in popularity-rank order.  A wave owns a column of up to PAIR_HEAVY raters; the few heavier
+// columns (the most popular item of ML-25M shape has ~10^5 raters: one wave would walk it for a millisecond) are
+// appended to a list and taken by whole workgroups in k_pair_pass_heavy.  Every column is reduced in a fixed order.
+constexpr int PAIR_HEAVY = 2048;
+struct PairPass {
+    const int32_t* __restrict__ rank_pair;
+    const int32_t* __restrict__ pair_start;
+    const int32_t* __restrict__ pair_di;
+    const int32_t* __restrict__ csc_slot;
+    const float* __restrict__ csc_r;
+    const double* __restrict__ usum_slot;
+    const int32_t* __restrict__ deg_slot;
+    int32_t lo, hi;
+    double* __restrict__ partial;      // by dense item (several clusters may add to one item)
+    double* __restrict__ b_rank;       // by rank position
+    long long* __restrict__ walk_rank; // by rank position: sum of the raters' degrees
+    int32_t* __restrict__ cnt_rank;    // by rank position: raters
+};
+__device__ __forceinline__ void fy_pair_entry(const PairPass& A, int32_t q, double& ps, double& b, long long& w) {
+    const int32_t slot = A.csc_slot[q];
+    const double r = (double)A.csc_r[q];
+    if (slot >= A.lo && slot < A.hi) ps += r;
+    b += r / A.usum_slot[slot];
+    w += A.deg_slot[slot];
+}
+__device__ __forceinline__ void fy_pair_store(const PairPass& A, int32_t pos, int32_t pr, int32_t n, double ps, double b, long long w) {
+    if (ps != 0.0) atomicAdd(&A.partial[A.pair_di[pr]], ps);
+    A.b_rank[pos] = b;
+    A.walk_rank[pos] = w;
+    A.cnt_rank[pos] = n;
+}
+__global__ void k_pair_pass(int32_t nP, PairPass A, int32_t* __restrict__ heavy, int32_t* __restrict__ n_heavy) {
     const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
-    for (int32_t p = blockIdx.x * wpb + (threadIdx.x >> 6); p < nP; p += gridDim.x * wpb) {
-        double s = 0.0;
-        for (int32_t q = pair_start[p] + lane; q < pair_start[p + 1]; q += 64) {
-            const int32_t slot = csc_slot[q];
-            if (slot >= lo && slot < hi) s += (double)csc_r[q];
+    for (int32_t pos = blockIdx.x * wpb + (threadIdx.x >> 6); pos < nP; pos += gridDim.x * wpb) {
+        const int32_t pr = A.rank_pair[pos];
+        const int32_t q0 = A.pair_start[pr], q1 = A.pair_start[pr + 1];
+        if (q1 - q0 > PAIR_HEAVY) {
+            if (lane == 0) heavy[atomicAdd(n_heavy, 1)] = pos;
+            continue;
         }
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
-        if (lane == 0 && s != 0.0) atomicAdd(&partial[pair_di[p]], s);
+        double ps = 0.0, b = 0.0;
+        long long w = 0;
+        for (int32_t q = q0 + lane; q < q1; q += 64) fy_pair_entry(A, q, ps, b, w);
+        for (int o = 32; o > 0; o >>= 1) {
+            ps += __shfl_down(ps, o, 64);
+            b += __shfl_down(b, o, 64);
+            w += __shfl_down(w, o, 64);
+        }
+        if (lane == 0) fy_pair_store(A, pos, pr, q1 - q0, ps, b, w);
+    }
+}
+__global__ __launch_bounds__(1024) void k_pair_pass_heavy(PairPass A, const int32_t* __restrict__ heavy, const int32_t* __restrict__ n_heavy) {
+    __shared__ double sh_ps[16], sh_b[16];
+    __shared__ long long sh_w[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = *n_heavy;
+    for (int k = blockIdx.x; k < n; k += gridDim.x) {
+        const int32_t pos = heavy[k];
+        const int32_t pr = A.rank_pair[pos];
+        const int32_t q0 = A.pair_start[pr], q1 = A.pair_start[pr + 1];
+        double ps = 0.0, b = 0.0;
+        long long w = 0;
+        for (int32_t q = q0 + threadIdx.x; q < q1; q += 1024) fy_pair_entry(A, q, ps, b, w);
+        for (int o = 32; o > 0; o >>= 1) {
+            ps += __shfl_down(ps, o, 64);
+            b += __shfl_down(b, o, 64);
+            w += __shfl_down(w, o, 64);
+        }
+        if (lane == 0) { sh_ps[wave] = ps; sh_b[wave] = b; sh_w[wave] = w; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double tps = 0.0, tb = 0.0;
+            long long tw = 0;
+            for (int x = 0; x < 16; x++) { tps += sh_ps[x]; tb += sh_b[x]; tw += sh_w[x]; }
+            fy_pair_store(A, pos, pr, q1 - q0, tps, tb, tw);
+        }
+        __syncthreads();
+    }
+}
+// per-slot copies of the user sums and degrees: one gather per CSC entry instead of two dependent ones
+__global__ void k_slot_user_arrays(int32_t nU, const int32_t* __restrict__ slot2du, const double* __restrict__ usum,
+                                   const int32_t* __restrict__ udeg, double* __restrict__ usum_slot, int32_t* __restrict__ deg_slot) {
+    for (int32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < nU; s += gridDim.x * blockDim.x) {
+        const int32_t du = slot2du[s];
+        usum_slot[s] = usum[du];
+        deg_slot[s] = udeg[du];
     }
 }
 
@@ -76,33 +150,20 @@ __global__ void k_item_coll(int32_t nI, const double* __restrict__ stats, double
     if (blockIdx.x == 0 && threadIdx.x == 0) *total_out = total;
 }
 
-// one wave per (cluster, item) in rank order: b = sum_v r_vi / s_v (fixed order), p, a = l * p
-__global__ void k_pair_stats(int32_t nP, const int32_t* __restrict__ rank_pair, const int32_t* __restrict__ pair_start,
-                             const int32_t* __restrict__ pair_di, const int32_t* __restrict__ csc_slot,
-                             const float* __restrict__ csc_r, const int32_t* __restrict__ slot2du, const double* __restrict__ usum,
-                             const double* __restrict__ icoll, double lambda, double* __restrict__ p_rank,
-                             double* __restrict__ b_rank, float* __restrict__ a_rank) {
-    const int lane = threadIdx.x & 63;
-    const int wpb = blockDim.x >> 6;
-    for (int32_t pos = blockIdx.x * wpb + (threadIdx.x >> 6); pos < nP; pos += gridDim.x * wpb) {
-        const int32_t pr = rank_pair[pos];
-        const int32_t q0 = pair_start[pr], q1 = pair_start[pr + 1];
-        double b = 0.0;
-        for (int32_t q = q0 + lane; q < q1; q += 64) b += (double)csc_r[q] / usum[slot2du[csc_slot[q]]];
-        for (int o = 32; o > 0; o >>= 1) b += __shfl_down(b, o, 64);
-        if (lane == 0) {
-            const double p = icoll[pair_di[pr]];
-            p_rank[pos] = p;
-            b_rank[pos] = b;
-            a_rank[pos] = (float)(lambda * p);
-        }
+// p(i|C) of every (cluster, item) in rank order, a = l * p
+__global__ void k_pair_p(int32_t nP, const int32_t* __restrict__ rank_pair, const int32_t* __restrict__ pair_di,
+                         const double* __restrict__ icoll, double lambda, double* __restrict__ p_rank, float* __restrict__ a_rank) {
+    for (int32_t pos = blockIdx.x * blockDim.x + threadIdx.x; pos < nP; pos += gridDim.x * blockDim.x) {
+        const double p = icoll[pair_di[rank_pair[pos]]];
+        p_rank[pos] = p;
+        a_rank[pos] = (float)(lambda * p);
     }
 }
 
 __global__ void k_csc_x(int64_t nnz, const int32_t* __restrict__ csc_slot, const float* __restrict__ csc_r,
-                        const int32_t* __restrict__ slot2du, const double* __restrict__ usum, float* __restrict__ csc_x) {
+                        const double* __restrict__ usum_slot, float* __restrict__ csc_x) {
     for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < nnz; q += (int64_t)gridDim.x * blockDim.x)
-        csc_x[q] = (float)((double)csc_r[q] / usum[slot2du[csc_slot[q]]]);
+        csc_x[q] = (float)((double)csc_r[q] / usum_slot[csc_slot[q]]);
 }
 
 // one wave per user row: x = r / s_u and e = (1-l)(b_j - x) + l (U_c - 1) p_j  (all fp64, rounded once)
@@ -203,32 +264,39 @@ __device__ __forceinline__ bool fy_seg_row_ok(const SegRows& F, int32_t q) {
 
 __global__ void k_seg_counts(const int32_t* __restrict__ csc_slot, const int32_t* __restrict__ chunk_off, int32_t slot_base,
                              int32_t q0, int32_t nq, int32_t nch, int32_t* __restrict__ cnt, SegRows F) {
-    const int64_t total = (int64_t)nch * (nq + 1);
-    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-        const int32_t ch = (int32_t)(t / (nq + 1)), q = (int32_t)(t % (nq + 1));
-        int32_t n = 0;
-        if (q < nq && fy_seg_row_ok(F, q0 + q)) {
-            const int32_t* co = chunk_off + (int64_t)(csc_slot[q0 + q] - slot_base) * (nch + 1) + ch;
-            n = (co[1] - co[0] + 63) >> 6;
+    // one thread per CSC entry: the rater's nch + 1 chunk offsets are one contiguous gather
+    for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q <= nq; q += (int64_t)gridDim.x * blockDim.x) {
+        const bool live = q < nq && fy_seg_row_ok(F, q0 + (int32_t)q);
+        const int32_t* co = live ? chunk_off + (int64_t)(csc_slot[q0 + q] - slot_base) * (nch + 1) : nullptr;
+        int32_t prev = live ? co[0] : 0;
+        for (int32_t ch = 0; ch < nch; ch++) {
+            int32_t n = 0;
+            if (live) {
+                const int32_t next = co[ch + 1];
+                n = (next - prev + 63) >> 6;
+                prev = next;
+            }
+            cnt[(int64_t)ch * (nq + 1) + q] = n;
         }
-        cnt[t] = n;
     }
 }
 
 __global__ void k_seg_fill(const int32_t* __restrict__ csc_slot, const float* __restrict__ csc_w, const int32_t* __restrict__ chunk_off,
                            int32_t slot_base, int32_t q0, int32_t nq, int32_t nch, const int32_t* __restrict__ ptr,
                            int2* __restrict__ seg, float* __restrict__ seg_w, SegRows F) {
-    const int64_t total = (int64_t)nch * nq;
-    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-        const int32_t ch = (int32_t)(t / nq), q = (int32_t)(t % nq);
-        if (!fy_seg_row_ok(F, q0 + q)) continue;
-        const int32_t* co = chunk_off + (int64_t)(csc_slot[q0 + q] - slot_base) * (nch + 1) + ch;
-        const int32_t f0 = co[0], len = co[1] - f0;
+    for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
+        if (!fy_seg_row_ok(F, q0 + (int32_t)q)) continue;
+        const int32_t* co = chunk_off + (int64_t)(csc_slot[q0 + q] - slot_base) * (nch + 1);
         const float w = csc_w[q0 + q];
-        int32_t k = ptr[(int64_t)ch * (nq + 1) + q];
-        for (int32_t off = 0; off < len; off += 64, k++) {
-            seg[k] = make_int2(f0 + off, min(64, len - off));
-            seg_w[k] = w;
+        int32_t f0 = co[0];
+        for (int32_t ch = 0; ch < nch; ch++) {
+            const int32_t f1 = co[ch + 1];
+            int32_t k = ptr[(int64_t)ch * (nq + 1) + q];
+            for (int32_t f = f0; f < f1; f += 64, k++) {
+                seg[k] = make_int2(f, min(64, f1 - f));
+                seg_w[k] = w;
+            }
+            f0 = f1;
         }
     }
 }
@@ -241,7 +309,7 @@ void build_segments(Context* ctx, const int32_t* csc_slot, const float* csc_w, c
     const size_t np = (size_t)nch * ((size_t)nq + 1);
     out.ptr.alloc(ctx, np);
     DevBuf<int32_t> cnt(ctx, np);
-    k_seg_counts<<<grid_for((int64_t)np), 256, 0, st>>>(csc_slot, chunk_off, slot_base, q0, nq, nch, cnt.get(), F);
+    k_seg_counts<<<grid_for((int64_t)nq + 1), 256, 0, st>>>(csc_slot, chunk_off, slot_base, q0, nq, nch, cnt.get(), F);
     FY_KERNEL_CHECK();
     exclusive_scan_i32(ctx, cnt.get(), out.ptr.get(), np, st);
     int32_t total = 0;   // the last count is 0 by construction: the last prefix is the total
@@ -250,7 +318,7 @@ void build_segments(Context* ctx, const int32_t* csc_slot, const float* csc_w, c
     out.seg.alloc(ctx, (size_t)total);
     out.w.alloc(ctx, (size_t)total);
     if ((int64_t)nch * nq > 0) {
-        k_seg_fill<<<grid_for((int64_t)nch * nq), 256, 0, st>>>(csc_slot, csc_w, chunk_off, slot_base, q0, nq, nch, out.ptr.get(),
+        k_seg_fill<<<grid_for((int64_t)nq), 256, 0, st>>>(csc_slot, csc_w, chunk_off, slot_base, q0, nq, nch, out.ptr.get(),
                                                                  out.seg.get(), out.w.get(), F);
         FY_KERNEL_CHECK();
     }
@@ -1117,18 +1185,17 @@ __global__ void k_range_offsets(const int32_t* __restrict__ rowptr, const int32_
     }
 }
 
-// work model of an item row: the row kernel walks sum_v n_v CSR entries, the scoring passes ~300 columns per rating
-__global__ void k_row_work(int32_t Ic, const int32_t* __restrict__ rank_pair, const int32_t* __restrict__ pair_start,
-                           const int32_t* __restrict__ csc_slot, const int32_t* __restrict__ slot2du,
-                           const int32_t* __restrict__ udeg, int64_t* __restrict__ work, int32_t* __restrict__ count) {
+// CSC entries (rater slot, weight) of item rows [r0, r0 + nrows), row by row: the compact CSC a cooperative rank builds its
+// segment table from
+__global__ void k_gather_rows(int32_t r0, int32_t nrows, const int32_t* __restrict__ rank_pair, const int32_t* __restrict__ pair_start,
+                              const int32_t* __restrict__ local_start, const int32_t* __restrict__ csc_slot,
+                              const float* __restrict__ csc_w, int32_t* __restrict__ my_slot, float* __restrict__ my_w) {
     const int lane = threadIdx.x & 63;
     const int wpb = blockDim.x >> 6;
-    for (int32_t row = blockIdx.x * wpb + (threadIdx.x >> 6); row < Ic; row += gridDim.x * wpb) {
-        const int32_t pr = rank_pair[row];
-        long long w = 0;
-        for (int32_t q = pair_start[pr] + lane; q < pair_start[pr + 1]; q += 64) w += udeg[slot2du[csc_slot[q]]] + 300;
-        for (int o = 32; o > 0; o >>= 1) w += __shfl_down(w, o, 64);
-        if (lane == 0) { work[row] = w; count[row] = pair_start[pr + 1] - pair_start[pr]; }
+    for (int32_t i = blockIdx.x * wpb + (threadIdx.x >> 6); i < nrows; i += gridDim.x * wpb) {
+        const int32_t pr = rank_pair[r0 + i];
+        const int32_t q0 = pair_start[pr], n = pair_start[pr + 1] - q0, l0 = local_start[i];
+        for (int32_t k = lane; k < n; k += 64) { my_slot[l0 + k] = csc_slot[q0 + k]; my_w[l0 + k] = csc_w[q0 + k]; }
     }
 }
 
@@ -1266,7 +1333,23 @@ struct fy_rm2_job {
     fy_collectives coll{};      // process-group collectives (optional)
     bool have_coll = false;
     DevBuf<double> gathered;    // world * (nI + 1): the statistics all-gathered by fy_rm2_score itself
+    // per (cluster, item) in rank order, from the one CSC walk of fy_rm2_prepare (k_pair_pass)
+    DevBuf<double> b_rank, usum_slot;
+    DevBuf<long long> walk_rank;
+    DevBuf<int32_t> cnt_rank, deg_slot;
+    bool count_balanced = false;   // scoring ownership of the users: equal counts instead of equal work (see owner_range)
 };
+
+// Which users does rank k emit lists for?  By default the work-balanced slot range of fy_prep (the rank scores its
+// users alone, so equal work).  A single cluster scored cooperatively shares all scoring work anyway and only the top-N
+// merge is per owner: equal COUNTS keep the padded reduce-scatter segments small (slots are degree-descending, the
+// work-balanced last rank would own four times the average number of users).
+static void owner_range(const fy_rm2_job* J, int k, int32_t& lo, int32_t& hi) {
+    if (!J->count_balanced) { rank_slot_range(J->P, k, J->prm.world, lo, hi); return; }
+    const int64_t n = J->P.nU, W = J->prm.world;
+    lo = (int32_t)(n * k / W);
+    hi = (int32_t)(n * (k + 1) / W);
+}
 
 // launch-shape knobs; environment overrides exist only for the tuning sweeps recorded in DESIGN.md
 struct ScoreTune {
@@ -1384,7 +1467,7 @@ static void score_cluster_coop(const CoopShared& X, const Plan& p, hipStream_t l
     int32_t Umax = 1;
     for (int k = 0; k < W; k++) {
         int32_t lo_k, hi_k;
-        rank_slot_range(P, k, W, lo_k, hi_k);
+        owner_range(J, k, lo_k, hi_k);
         ua[k] = std::max(lo_k, sbase);
         ub[k] = std::max(ua[k], std::min(hi_k, sbase + Uc));
         Umax = std::max(Umax, ub[k] - ua[k]);
@@ -1393,18 +1476,18 @@ static void score_cluster_coop(const CoopShared& X, const Plan& p, hipStream_t l
 
     // ---- item rows of this rank: equal shares of the work model (row kernel + scoring passes)
     std::vector<int32_t> rsplit(W + 1, Ic), hcnt;
-    std::vector<int64_t> all_hw;
+    std::vector<long long> all_hw;
     {
-        DevBuf<int64_t> work(ctx, (size_t)Ic);
-        DevBuf<int32_t> cnt(ctx, (size_t)Ic);
-        k_row_work<<<grid_for((int64_t)Ic * 64, 256), 256, 0, ls>>>(Ic, P.rank_pair.get() + pbase, P.pair_start.get(), P.csc_slot.get(),
-                                                                    P.slot2du.get(), P.udeg.get(), work.get(), cnt.get());
-        FY_KERNEL_CHECK();
-        std::vector<int64_t> hw((size_t)Ic);
+        // work model of an item row, in CSR entries walked by the row kernel: sum_v n_v for the walk itself (k_pair_pass),
+        // ~300 per rating for the scoring passes over the row, and a constant for the row's epilogue (calibrated on ML-25M
+        // shape at 8 ranks, tools/coop_rehearsal.py)
+        const int64_t row_const = ldm;
+        std::vector<long long> hw((size_t)Ic);
         hcnt.resize((size_t)Ic);
-        FY_HIP(hipMemcpyAsync(hw.data(), work.get(), (size_t)Ic * sizeof(int64_t), hipMemcpyDeviceToHost, ls));
-        FY_HIP(hipMemcpyAsync(hcnt.data(), cnt.get(), (size_t)Ic * sizeof(int32_t), hipMemcpyDeviceToHost, ls));
+        FY_HIP(hipMemcpyAsync(hw.data(), J->walk_rank.get() + pbase, (size_t)Ic * sizeof(long long), hipMemcpyDeviceToHost, ls));
+        FY_HIP(hipMemcpyAsync(hcnt.data(), J->cnt_rank.get() + pbase, (size_t)Ic * sizeof(int32_t), hipMemcpyDeviceToHost, ls));
         FY_HIP(hipStreamSynchronize(ls));
+        for (int32_t i = 0; i < Ic; i++) hw[i] += 300 * (long long)hcnt[i] + row_const;
         int64_t total = 0;
         for (int32_t i = 0; i < Ic; i++) total += hw[i];
         rsplit[0] = 0;
@@ -1419,7 +1502,7 @@ static void score_cluster_coop(const CoopShared& X, const Plan& p, hipStream_t l
     }
     const int32_t r0 = rsplit[me], r1 = rsplit[me + 1], nrows = r1 - r0;
     int64_t my_ratings = 0, my_walk = 0;
-    for (int32_t i = r0; i < r1; i++) { my_ratings += hcnt[i]; my_walk += all_hw[i] - 300 * (int64_t)hcnt[i]; }
+    for (int32_t i = r0; i < r1; i++) { my_ratings += hcnt[i]; my_walk += all_hw[i] - 300 * (int64_t)hcnt[i] - ldm; }
     *X.coop_pair_contribs += my_walk - my_ratings;   // ordered off-diagonal co-rating pairs whose row is mine
 
     // ---- buffers
@@ -1443,18 +1526,28 @@ static void score_cluster_coop(const CoopShared& X, const Plan& p, hipStream_t l
     const float* Mshift = reinterpret_cast<const float*>(reinterpret_cast<const char*>(Mloc.get()) - (int64_t)r0 * ldm * 3);
     const float* Bshift = Bloc.get() - (int64_t)r0 * ldb;
 
-    // ---- segment table of my rows, M build
+    // ---- segment table of my rows (over a compact copy of their CSC entries), M build
     {
         DevBuf<int32_t> co_tmp(ctx, (size_t)Uc * (nch + 1));
         SegTable seg;
         build_chunk_offsets(ctx, P.rowptr.get(), P.csr_idx.get(), sbase, Uc, CH, nch, co_tmp.get(), ls);
-        build_segments(ctx, P.csc_slot.get(), X.csc_x, co_tmp.get(), sbase, p.q0, p.nq, nch, seg, ls, P.csc_pair.get(), P.pair_rank.get(), r0, r1);
+        std::vector<int32_t> hls((size_t)nrows + 1, 0);
+        for (int32_t i = 0; i < nrows; i++) hls[i + 1] = hls[i] + hcnt[r0 + i];
+        DevBuf<int32_t> local_start(ctx, (size_t)nrows + 1), my_slot(ctx, (size_t)std::max<int64_t>(1, my_ratings));
+        DevBuf<float> my_w(ctx, (size_t)std::max<int64_t>(1, my_ratings));
+        FY_HIP(hipMemcpyAsync(local_start.get(), hls.data(), ((size_t)nrows + 1) * sizeof(int32_t), hipMemcpyHostToDevice, ls));
+        if (nrows > 0) {
+            k_gather_rows<<<grid_for((int64_t)nrows * 64, 256), 256, 0, ls>>>(r0, nrows, P.rank_pair.get() + pbase, P.pair_start.get(),
+                                                                              local_start.get(), P.csc_slot.get(), X.csc_x, my_slot.get(), my_w.get());
+            FY_KERNEL_CHECK();
+        }
+        build_segments(ctx, my_slot.get(), my_w.get(), co_tmp.get(), sbase, 0, (int32_t)my_ratings, nch, seg, ls);
         FY_HIP(hipMemsetAsync(Bloc.get(), 0, (size_t)std::max<int64_t>(1, (int64_t)nrows * ldb) * sizeof(float), ls));
         k_block_amax<<<grid_for(ldb), 256, 0, ls>>>(Ic, (int32_t)ldb, X.a_rank + pbase, amax.get());
         FY_KERNEL_CHECK();
         if (nrows > 0) {
             CoocArgs CA{P.rank_pair.get(), P.pair_start.get(), seg.ptr.get(), seg.seg.get(), seg.w.get(), P.csr_idx.get(),
-                        X.csr_x, pbase, sbase, Ic, CH, nch, r0, nrows, p.q0, p.nq, tune.cooc_debug};
+                        X.csr_x, pbase, sbase, Ic, CH, nch, r0, nrows, 0, (int32_t)my_ratings, tune.cooc_debug, local_start.get()};
             MEpilogue ME{const_cast<float*>(Mshift), ldm, X.p_rank + pbase, X.b_rank + pbase, (1.0 - lambda) * (1.0 - lambda),
                          lambda * (1.0 - lambda), 1, const_cast<float*>(Bshift), ldb};
             const int block = tune.cooc_block ? tune.cooc_block : ((CH * 8 > 48 * 1024) ? 1024 : 256);
@@ -1599,8 +1692,21 @@ fy_rm2_job* fy::rm2_prepare(Context* ctx, const fy_rm2_params* prm, const fy_rat
     if (P.nnz > 0) {
         DevBuf<unsigned long long> counter(ctx, 1);
         counter.zero();
-        k_partial_item_sums<<<grid_for((int64_t)P.nP * 64, 256), 256, 0, ctx->stream>>>(P.nP, P.pair_start.get(), P.csc_slot.get(), P.csc_r.get(),
-                                                                                        P.pair_di.get(), J->slot_lo, J->slot_hi, J->partial.get());
+        J->usum_slot.alloc(ctx, (size_t)P.nU);
+        J->deg_slot.alloc(ctx, (size_t)P.nU);
+        k_slot_user_arrays<<<grid_for(P.nU), 256, 0, ctx->stream>>>(P.nU, P.slot2du.get(), P.usum.get(), P.udeg.get(), J->usum_slot.get(),
+                                                                    J->deg_slot.get());
+        FY_KERNEL_CHECK();
+        J->b_rank.alloc(ctx, (size_t)P.nP);
+        J->walk_rank.alloc(ctx, (size_t)P.nP);
+        J->cnt_rank.alloc(ctx, (size_t)P.nP);
+        DevBuf<int32_t> heavy(ctx, (size_t)P.nP), n_heavy(ctx, 1);
+        n_heavy.zero();
+        const PairPass PA{P.rank_pair.get(), P.pair_start.get(), P.pair_di.get(), P.csc_slot.get(), P.csc_r.get(), J->usum_slot.get(),
+                          J->deg_slot.get(), J->slot_lo, J->slot_hi, J->partial.get(), J->b_rank.get(), J->walk_rank.get(), J->cnt_rank.get()};
+        k_pair_pass<<<grid_for((int64_t)P.nP * 64, 256), 256, 0, ctx->stream>>>(P.nP, PA, heavy.get(), n_heavy.get());
+        FY_KERNEL_CHECK();
+        k_pair_pass_heavy<<<ctx->num_cus * 2, 1024, 0, ctx->stream>>>(PA, heavy.get(), n_heavy.get());
         FY_KERNEL_CHECK();
         if (J->slot_hi > J->slot_lo) {
             k_partial_total<<<grid_for(J->slot_hi - J->slot_lo), 256, 0, ctx->stream>>>(J->slot_lo, J->slot_hi, P.slot2du.get(),
@@ -1667,22 +1773,35 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
     DevBuf<double> d_total(ctx, 1);
     k_item_coll<<<grid_for(nI), 256, 0, st>>>(nI, J->stats.get(), R->d_icoll.get(), d_total.get());
     FY_KERNEL_CHECK();
-    DevBuf<double> p_rank(ctx, nP), b_rank(ctx, nP);
+    DevBuf<double> p_rank(ctx, nP);
+    DevBuf<double>& b_rank = J->b_rank;
     DevBuf<float> a_rank(ctx, nP);
-    k_pair_stats<<<grid_for((int64_t)nP * 64, 256), 256, 0, st>>>(nP, P.rank_pair.get(), P.pair_start.get(), P.pair_di.get(),
-                                                                   P.csc_slot.get(), P.csc_r.get(), P.slot2du.get(), P.usum.get(),
-                                                                   R->d_icoll.get(), lambda, p_rank.get(), b_rank.get(), a_rank.get());
+    k_pair_p<<<grid_for(nP), 256, 0, st>>>(nP, P.rank_pair.get(), P.pair_di.get(), R->d_icoll.get(), lambda, p_rank.get(), a_rank.get());
     FY_KERNEL_CHECK();
     DevBuf<float> csc_x(ctx, P.nnz), csr_x(ctx, P.nnz), csr_e(ctx, P.nnz);
-    k_csc_x<<<grid_for(P.nnz), 256, 0, st>>>(P.nnz, P.csc_slot.get(), P.csc_r.get(), P.slot2du.get(), P.usum.get(), csc_x.get());
+    k_csc_x<<<grid_for(P.nnz), 256, 0, st>>>(P.nnz, P.csc_slot.get(), P.csc_r.get(), J->usum_slot.get(), csc_x.get());
     FY_KERNEL_CHECK();
     k_csr_values<<<grid_for((int64_t)nU * 64, 256), 256, 0, st>>>(nU, P.rowptr.get(), P.csr_idx.get(), P.csr_r.get(), P.slot2du.get(),
                                                                    P.ucluster.get(), P.usum.get(), P.d_csize.get(), P.d_pcstart.get(),
                                                                    p_rank.get(), b_rank.get(), lambda, csr_x.get(), csr_e.get());
     FY_KERNEL_CHECK();
 
+    // ---- which users this rank emits lists for
+    J->count_balanced = false;
+    if (prm.world > 1 && J->have_coll && tune.coop && tune.prune && pack24_allowed && tune.tile_bytes >= ((int64_t)1 << 40) && !tune.hot_lds) {
+        int nonempty = 0, c1 = -1;
+        for (int c = 0; c < K; c++)
+            if (P.csize[c] > 0) { nonempty++; c1 = c; }
+        if (nonempty == 1) {   // one neighbourhood: it is scored cooperatively when it is big enough for the branch and bound
+            const int32_t Ic1 = P.pcstart[c1 + 1] - P.pcstart[c1];
+            J->count_balanced = Ic1 >= tune.pack24_min_items && Ic1 >= tune.prune_min_items && ceil_div(Ic1, PRUNE_BLOCK) < 0xFFFF &&
+                                P.nU >= prm.world;
+        }
+    }
+    int32_t own_lo, own_hi;
+    owner_range(J, prm.rank, own_lo, own_hi);
     // ---- per-user meta for this rank's slots, output offsets
-    const int32_t lo = J->slot_lo, hi = J->slot_hi, nmine = hi - lo;
+    const int32_t lo = own_lo, hi = own_hi, nmine = hi - lo;
     DevBuf<double> pvpi(ctx, (size_t)nmine + 1);
     DevBuf<int32_t> n_out(ctx, (size_t)nmine + 1), out_off(ctx, (size_t)nmine + 1);
     DevBuf<unsigned long long> counters(ctx, 2);
@@ -1760,6 +1879,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             p.nblk = (int32_t)ceil_div(p.Ic, PRUNE_BLOCK);
             p.ldb = round_up(p.nblk, 256);
             p.prune = tune.prune && p.pack24 && p.nrb == 1 && !p.use_hot && p.Ic >= tune.prune_min_items && p.nblk < 0xFFFF;
+            if (J->count_balanced && !p.prune) FY_FAIL(FY_ERR_STATE, "internal: count-balanced ownership without a cooperative cluster");
             // all ranks hold users of this cluster and can talk to each other: score it together, every rank with its
             // share of the matrix rows (score_cluster_coop)
             p.coop = false;
@@ -1767,7 +1887,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 p.coop = true;
                 for (int k = 0; k < prm.world; k++) {
                     int32_t lo_k, hi_k;
-                    rank_slot_range(P, k, prm.world, lo_k, hi_k);
+                    owner_range(J, k, lo_k, hi_k);
                     if (std::max(lo_k, p.sbase) >= std::min(hi_k, p.sbase + p.Uc)) p.coop = false;
                 }
             }

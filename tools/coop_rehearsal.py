@@ -63,46 +63,58 @@ def main():
     W = a.world
     out = [None] * W
     err = [None] * W
-    report = []
-    for rep in range(a.reps):
-        group = par.ThreadGroup(W, serialize=True)
-        comms = [par.ThreadCollectives(group, k, 0) for k in range(W)]
+    group = par.ThreadGroup(W, serialize=True)
+    comms = [par.ThreadCollectives(group, k, 0) for k in range(W)]
+    rep_gate = threading.Barrier(W)
+    report = [None] * a.reps
 
-        def body(rank):
-            try:
-                ctx = P.Context(0)
-                r = P.Ratings(ctx, user, item, score)
+    def body(rank):
+        try:
+            ctx = P.Context(0)          # the context (and its caching allocator) lives across the repetitions, like in bench.py
+            r = P.Ratings(ctx, user, item, score)
+            job = P.RM2Job(conf, ctx)
+            for rep in range(a.reps):
                 ctx.synchronize()
+                rep_gate.wait()
+                if rank == 0:
+                    group.busy_s = [0.0] * W
+                    group.busy_log = [[] for _ in range(W)]
+                    for c in comms:
+                        c.calls = {"all_gather": 0, "reduce_scatter_f32": 0, "bytes": 0}
+                rep_gate.wait()
                 comms[rank].enter()
-                rec = P.RM2Job(conf, ctx).run(r, clustering=clustering, rank=rank, world=W, collectives=comms[rank])
+                rec = job.run(r, clustering=clustering, rank=rank, world=W, collectives=comms[rank])
                 ctx.synchronize()
                 comms[rank].leave("tail")
                 out[rank] = (rec.rows() if rep == a.reps - 1 and not a.no_check else None, dict(rec.stats))
                 rec.close()
-                r.close()
-                ctx.close()
-            except BaseException as e:
-                err[rank] = e
-                group.barrier.abort()
-                if group.lock.locked():
-                    try:
-                        group.lock.release()
-                    except RuntimeError:
-                        pass
+                rep_gate.wait()
+                if rank == 0:
+                    report[rep] = {"busy_ms": [round(1e3 * x, 2) for x in group.busy_s],
+                                   "ms_cooc": [round(o[1]["ms_cooc"], 2) for o in out],
+                                   "ms_prepare": [round(o[1]["ms_prepare"], 2) for o in out],
+                                   "comm_MB_sent_per_rank": round(comms[0].calls["bytes"] / 1e6, 1), "calls": dict(comms[0].calls),
+                                   "phases_rank0": [(w, round(1e3 * d, 2)) for w, d in group.busy_log[0]],
+                                   "phases_last_rank": [(w, round(1e3 * d, 2)) for w, d in group.busy_log[W - 1]]}
+            r.close()
+            ctx.close()
+        except BaseException as e:
+            err[rank] = e
+            group.barrier.abort()
+            rep_gate.abort()
+            try:
+                group.lock.release()
+            except RuntimeError:
+                pass
 
-        th = [threading.Thread(target=body, args=(k,)) for k in range(W)]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join(900)
-        for e in err:
-            if e is not None and not isinstance(e, threading.BrokenBarrierError):
-                raise e
-        report.append({"busy_ms": [round(1e3 * b, 2) for b in group.busy_s],
-                       "ms_cooc": [round(o[1]["ms_cooc"], 2) for o in out], "ms_score": [round(o[1]["ms_score"], 2) for o in out],
-                       "ms_prepare": [round(o[1]["ms_prepare"], 2) for o in out],
-                       "comm_MB_per_rank": round(comms[0].calls["bytes"] / 1e6, 1), "calls": comms[0].calls,
-                       "phases_rank0": [(w, round(1e3 * d, 2)) for w, d in group.busy_log[0]]})
+    th = [threading.Thread(target=body, args=(k,)) for k in range(W)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(900)
+    for e in err:
+        if e is not None and not isinstance(e, threading.BrokenBarrierError):
+            raise e
     res = {"shape": a.shape, "world": W, "single_gpu_ms": single_ms, "reps": report}
     if single_rows is not None:
         rows = {k: np.concatenate([o[0][k] for o in out]) for k in ("user", "item", "score")}
