@@ -38,8 +38,9 @@ struct CoocArgs {
     int32_t nq;         // CSC entries of the cluster
     int32_t debug;      // timing experiments only (wrong results): 1 = no LDS atomics
     // optional (cooperative ranks): the segment table covers only the CSC entries of rows [row0, row0 + nrows), renumbered
-    // row by row; local_start[row - row0] = first local entry of the row (then q0 = 0, nq = local entries)
+    // row by row; local_start[k] = first local entry of the launch's k-th row (then q0 = 0, nq = local entries)
     const int32_t* __restrict__ local_start;
+    int32_t row_stride;  // the launch's k-th row is row0 + k * row_stride (0 = 1): a cooperative rank owns rows r, r + world, ...
 };
 
 // Accumulates chunk `ch` of row `row` into the workgroup's dynamic LDS (fy_cooc_acc[0..CH), zeroed by the caller; all
@@ -56,13 +57,13 @@ struct CoocArgs {
 // metadata 90; persistent workgroups 47; this version (segments precomputed per CSC entry): DESIGN.md section 7.
 extern __shared__ double fy_cooc_acc[];
 
-__device__ __forceinline__ void cooc_accumulate_row(const CoocArgs& A, int row, int ch) {
+__device__ __forceinline__ void cooc_accumulate_row(const CoocArgs& A, int row, int ch, int lrow = 0) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = blockDim.x >> 6;
     const int pair = A.rank_pair[A.pbase + row];
     int e0 = A.pair_start[pair], e1 = A.pair_start[pair + 1];
-    if (A.local_start) { e0 = A.local_start[row - A.row0]; e1 = A.local_start[row - A.row0 + 1]; }
+    if (A.local_start) { e0 = A.local_start[lrow]; e1 = A.local_start[lrow + 1]; }
     const int32_t* __restrict__ sp = A.seg_ptr + (int64_t)ch * (A.nq + 1) - A.q0;
     const int s_begin = sp[e0], s_end = sp[e1];
     const int c0 = ch * A.CH;

@@ -34,6 +34,9 @@ void sort_pairs_u64_u32(Context* c, uint64_t* kin, uint64_t* kout, uint32_t* vin
 void sort_pairs_u64_f32(Context* c, uint64_t* kin, uint64_t* kout, float* vin, float* vout, size_t n, int end_bit) {
     sort_pairs_impl(c, kin, kout, vin, vout, n, end_bit);
 }
+void sort_pairs_u64_u64(Context* c, uint64_t* kin, uint64_t* kout, uint64_t* vin, uint64_t* vout, size_t n, int end_bit) {
+    sort_pairs_impl(c, kin, kout, vin, vout, n, end_bit);
+}
 void inclusive_scan_u32(Context* c, const uint32_t* in, uint32_t* out, size_t n) {
     if (n == 0) return;
     size_t tmp = 0;
@@ -200,15 +203,16 @@ __global__ void k_invert_perm(int32_t n, const uint32_t* __restrict__ perm, int3
     }
 }
 
-// (cluster : raw item) key of every rating, payload = position in the user-major order
+// (cluster : raw item) key of every rating; the payload travels with it through the sort: (slot of the rater, rating bits),
+// so the CSC arrays fall out of the sorted values without a gather
 __global__ void k_cluster_item_keys(int64_t n, const uint64_t* __restrict__ ukeys, const uint32_t* __restrict__ du1,
-                                    const int32_t* __restrict__ ucluster, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                    int ib) {
+                                    const int32_t* __restrict__ ucluster, const int32_t* __restrict__ du2slot,
+                                    const float* __restrict__ score_um, uint64_t* __restrict__ keys, uint64_t* __restrict__ vals, int ib) {
     const uint64_t mask = ((uint64_t)1 << ib) - 1;
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
-        const uint32_t c = (uint32_t)ucluster[du1[t] - 1];
-        keys[t] = ((uint64_t)c << ib) | (ukeys[t] & mask);
-        vals[t] = (uint32_t)t;
+        const uint32_t du = du1[t] - 1;
+        keys[t] = ((uint64_t)(uint32_t)ucluster[du] << ib) | (ukeys[t] & mask);
+        vals[t] = ((uint64_t)(uint32_t)du2slot[du] << 32) | __float_as_uint(score_um[t]);
     }
 }
 
@@ -223,7 +227,15 @@ __global__ void k_scatter_pairs(int64_t n, const uint64_t* __restrict__ keys, co
             pair_cluster[p] = c;
             pair_item[p] = (int32_t)(uint32_t)(keys[t] & mask);
             pair_start[p] = (int32_t)t;
-            atomicAdd(&pcount[c], 1);
+            // one atomic per wave when all its heads sit in one cluster (always, with a single cluster)
+            const unsigned long long act = __ballot(1);
+            const int c0 = __shfl(c, __ffsll((long long)act) - 1, 64);
+            const unsigned long long same = __ballot(c == c0);
+            if (same == act) {
+                if ((int)(threadIdx.x & 63) == __ffsll((long long)act) - 1) atomicAdd(&pcount[c0], (int)__popcll(act));
+            } else {
+                atomicAdd(&pcount[c], 1);
+            }
         }
 }
 
@@ -246,14 +258,12 @@ __global__ void k_scatter_items(int32_t nP, const uint64_t* __restrict__ keys, c
 }
 
 // CSC payload in pair order: slot of the rater, its raw rating, and the pair every entry belongs to
-__global__ void k_fill_csc(int64_t n, const uint32_t* __restrict__ t_sorted, const uint32_t* __restrict__ du1,
-                           const int32_t* __restrict__ du2slot, const float* __restrict__ score_um,
-                           const uint32_t* __restrict__ pr1, int32_t* __restrict__ csc_slot, float* __restrict__ csc_r,
-                           int32_t* __restrict__ csc_pair) {
+__global__ void k_fill_csc(int64_t n, const uint64_t* __restrict__ sorted_vals, const uint32_t* __restrict__ pr1,
+                           int32_t* __restrict__ csc_slot, float* __restrict__ csc_r, int32_t* __restrict__ csc_pair) {
     for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) {
-        const uint32_t t = t_sorted[q];
-        csc_slot[q] = du2slot[du1[t] - 1];
-        csc_r[q] = score_um[t];
+        const uint64_t v = sorted_vals[q];
+        csc_slot[q] = (int32_t)(v >> 32);
+        csc_r[q] = __uint_as_float((uint32_t)v);
         csc_pair[q] = (int32_t)(pr1[q] - 1);
     }
 }
@@ -428,13 +438,13 @@ void build_structure(Context* ctx, const fy_ratings* R, int32_t K, int64_t n_map
 
     // ---- sort #3: (cluster, item) order = the CSC
     DevBuf<uint64_t> k3b(ctx, nnz);
-    DevBuf<uint32_t> t_sorted(ctx, nnz);
+    DevBuf<uint64_t> v_sorted(ctx, nnz);
     {
-        DevBuf<uint64_t> k3a(ctx, nnz);
-        DevBuf<uint32_t> v3a(ctx, nnz);
-        k_cluster_item_keys<<<grid_for(nnz), 256, 0, st>>>(nnz, ukeys, du1.get(), P.ucluster.get(), k3a.get(), v3a.get(), ib);
+        DevBuf<uint64_t> k3a(ctx, nnz), v3a(ctx, nnz);
+        k_cluster_item_keys<<<grid_for(nnz), 256, 0, st>>>(nnz, ukeys, du1.get(), P.ucluster.get(), P.du2slot.get(), sc_um.get(), k3a.get(),
+                                                            v3a.get(), ib);
         FY_KERNEL_CHECK();
-        sort_pairs_u64_u32(ctx, k3a.get(), k3b.get(), v3a.get(), t_sorted.get(), nnz, std::min(64, ib + bits_for((uint64_t)(K - 1))));
+        sort_pairs_u64_u64(ctx, k3a.get(), k3b.get(), v3a.get(), v_sorted.get(), nnz, std::min(64, ib + bits_for((uint64_t)(K - 1))));
     }
     DevBuf<uint32_t> pr1(ctx, nnz);
     k_heads_full<<<grid_for(nnz), 256, 0, st>>>(nnz, k3b.get(), head.get());
@@ -488,8 +498,7 @@ void build_structure(Context* ctx, const fy_ratings* R, int32_t K, int64_t n_map
     P.csc_slot.alloc(ctx, nnz);
     P.csc_r.alloc(ctx, nnz);
     P.csc_pair.alloc(ctx, nnz);
-    k_fill_csc<<<grid_for(nnz), 256, 0, st>>>(nnz, t_sorted.get(), du1.get(), P.du2slot.get(), sc_um.get(), pr1.get(),
-                                               P.csc_slot.get(), P.csc_r.get(), P.csc_pair.get());
+    k_fill_csc<<<grid_for(nnz), 256, 0, st>>>(nnz, v_sorted.get(), pr1.get(), P.csc_slot.get(), P.csc_r.get(), P.csc_pair.get());
     FY_KERNEL_CHECK();
 
     // ---- popularity rank inside the cluster = compact item index

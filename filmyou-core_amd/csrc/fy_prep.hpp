@@ -55,6 +55,7 @@ void rank_slot_range(const Prepared& P, int rank, int world, int32_t& lo, int32_
 // generic device helpers implemented with rocPRIM (radix sort / scan), all on ctx->stream
 void sort_pairs_u64_u32(Context*, uint64_t* kin, uint64_t* kout, uint32_t* vin, uint32_t* vout, size_t n, int end_bit = 64);
 void sort_pairs_u64_f32(Context*, uint64_t* kin, uint64_t* kout, float* vin, float* vout, size_t n, int end_bit = 64);
+void sort_pairs_u64_u64(Context*, uint64_t* kin, uint64_t* kout, uint64_t* vin, uint64_t* vout, size_t n, int end_bit = 64);
 void inclusive_scan_u32(Context*, const uint32_t* in, uint32_t* out, size_t n);
 void exclusive_scan_i32(Context*, const int32_t* in, int32_t* out, size_t n, hipStream_t st = nullptr);
 void inclusive_scan_i64(Context*, const int64_t* in, int64_t* out, size_t n);

@@ -335,6 +335,7 @@ struct MEpilogue {
     int pack24;   // 3 bytes per element: 8 exponent + 16 mantissa bits of the (non-negative) fp32, rounded to nearest
     float* __restrict__ Bmax;   // optional [row][ldb]: maximum of the (rounded) row over every 64-column block
     int64_t ldb;
+    int local_rows;   // 1: M / Bmax hold only this launch's rows, k-th row of the launch at index k (cooperative ranks)
 };
 
 // Persistent workgroups pull (row, chunk) items from a global counter (rows are in popularity order: heavy items first);
@@ -346,14 +347,20 @@ __global__ void k_cooc_rm2(CoocArgs A, MEpilogue E, int n_items, int* __restrict
     for (int t = threadIdx.x; t < A.CH; t += blockDim.x) acc[t] = 0.0;
     // items are handed out by a global counter: the chunks of a row differ a lot in weight (chunk 0 holds the popular
     // columns), a static stride would leave three quarters of the workgroups idle behind the chunk-0 owners
+    int next = 0;
+    if (threadIdx.x == 0) next = atomicAdd(next_item, 1);
     for (;;) {
-        if (threadIdx.x == 0) sh_item = atomicAdd(next_item, 1);
+        if (threadIdx.x == 0) sh_item = next;
         __syncthreads();
         const int item = sh_item;
         if (item >= n_items) break;
-        const int row = A.row0 + item / A.nch;
+        // the counter's round trip for the NEXT item hides behind this item's work
+        if (threadIdx.x == 0) next = atomicAdd(next_item, 1);
+        const int lrow = item / A.nch;
+        const int row = A.row0 + lrow * (A.row_stride ? A.row_stride : 1);
+        const int mrow = E.local_rows ? lrow : row;
         const int ch = item % A.nch;
-        if (A.debug != 3) cooc_accumulate_row(A, row, ch);
+        if (A.debug != 3) cooc_accumulate_row(A, row, ch, lrow);
         __syncthreads();
         if (A.debug == 4) continue;   // timing experiment: no epilogue (block-uniform)
         const int c0 = ch * A.CH;
@@ -362,7 +369,7 @@ __global__ void k_cooc_rm2(CoocArgs A, MEpilogue E, int n_items, int* __restrict
         const double pj = E.p_rank[row];
         if (E.pack24) {
             // four columns -> three dwords (c0 and c1 are multiples of 64)
-            uint32_t* __restrict__ out3 = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(E.M) + (int64_t)row * E.ldm * 3);
+            uint32_t* __restrict__ out3 = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(E.M) + (int64_t)mrow * E.ldm * 3);
             for (int c4 = (c0 >> 2) + threadIdx.x; 4 * c4 < c1; c4 += blockDim.x) {
                 uint32_t v[4];
 #pragma unroll
@@ -386,11 +393,11 @@ __global__ void k_cooc_rm2(CoocArgs A, MEpilogue E, int n_items, int* __restrict
                     for (int q = 0; q < 4; q++) m = fmaxf(m, __uint_as_float((v[q] << 8) >> 1));
 #pragma unroll
                     for (int o = 1; o < 64; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-                    if ((threadIdx.x & 63) == 0) E.Bmax[(int64_t)row * E.ldb + (c4 >> 6)] = m;
+                    if ((threadIdx.x & 63) == 0) E.Bmax[(int64_t)mrow * E.ldb + (c4 >> 6)] = m;
                 }
             }
         } else {
-            float* __restrict__ out = E.M + (int64_t)row * E.ldm;
+            float* __restrict__ out = E.M + (int64_t)mrow * E.ldm;
             for (int col = c0 + threadIdx.x; col < c1; col += blockDim.x) {
                 float v = 0.0f;
                 if (col < A.Ic) {
@@ -444,6 +451,9 @@ struct ScoreArgs {
     uint16_t* __restrict__ surv;           // [u * ldS + k]
     int32_t* __restrict__ n_surv;          // [u], zeroed before the launch
     int32_t seed_blocks;
+    // cooperative ranks: csr_idx holds LOCAL row indices of M (k-th row of the rank); the item it stands for is
+    // k * row_mul + row_add (row_mul == 0: the index is the item itself)
+    int32_t row_mul, row_add;
 };
 
 __device__ __forceinline__ float fy_log2(float x) { return __builtin_amdgcn_logf(x); }   // v_log_f32
@@ -536,6 +546,7 @@ __global__ __launch_bounds__(256) void k_score(const float* __restrict__ M_, con
     const float qnan = __builtin_nanf("");
     const bool first = A.rb == 0;
     const int stride = A.nrb + 1;
+    const int row_mul = A.row_mul ? A.row_mul : 1;
     for (int u = slice * 4 + wave; u < A.n_users; u += A.n_slices * 4) {
         const int slot = A.slot0 + u;
         if (n_out_[slot - A.slot_lo] == 0) continue;
@@ -579,7 +590,7 @@ __global__ __launch_bounds__(256) void k_score(const float* __restrict__ M_, con
                     }
 #pragma unroll
                     for (int v = 0; v < VEC; v++) p[v] += fy_log2(fmaf(a[v], e[q], gv[v]));
-                    const unsigned d = (unsigned)(jj[q] - col0);
+                    const unsigned d = (unsigned)(jj[q] * row_mul + A.row_add - col0);
                     if (!A.no_mask && d < (unsigned)CW && (int)(d / VEC) == lane) mask |= 1u << (d % VEC);
                 }
             }
@@ -1168,32 +1179,52 @@ __global__ __launch_bounds__(256) void k_score_blocks(const float* __restrict__ 
 }
 
 // ================================================================ cooperative ranks (fy_collectives): kernels
-// first CSR entry of every user of the cluster with idx >= r0 and with idx >= r1: the part of the row that meets this
-// rank's item rows [r0, r1) (same layout as a chunk_off table with one chunk)
-__global__ void k_range_offsets(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ csr_idx, int32_t slot_base,
-                                int32_t n_slots, int32_t r0, int32_t r1, int32_t* __restrict__ out) {
-    const int64_t total = (int64_t)n_slots * 2;
-    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-        const int32_t v = (int32_t)(t >> 1);
-        const int32_t key = (t & 1) ? r1 : r0;
-        int32_t lo = rowptr[slot_base + v], hi = rowptr[slot_base + v + 1];
-        while (lo < hi) {
-            const int32_t mid = (lo + hi) >> 1;
-            if (csr_idx[mid] < key) lo = mid + 1; else hi = mid;
+// A cooperative rank owns the item rows  me, me + world, me + 2 world, ...  (rows are in popularity order, so every rank
+// gets the same mix of heavy and light rows -- no work model needed).  Its view of the users is a compact CSR that keeps only
+// the rated items falling into its rows, renumbered to the LOCAL row index (idx / world): one wave per user, ballot
+// compaction, order preserved.
+__global__ void k_my_csr_count(int32_t n_slots, int32_t slot_base, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ csr_idx,
+                               int32_t world, int32_t me, int32_t* __restrict__ cnt) {
+    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    for (int32_t v = blockIdx.x * wpb + (threadIdx.x >> 6); v <= n_slots; v += gridDim.x * wpb) {
+        int c = 0;
+        if (v < n_slots)
+            for (int32_t f = rowptr[slot_base + v] + lane; f < rowptr[slot_base + v + 1]; f += 64) c += (csr_idx[f] % world) == me;
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+        if (lane == 0) cnt[v] = c;     // cnt[n_slots] = 0: the exclusive scan's last element is the total
+    }
+}
+__global__ void k_my_csr_fill(int32_t n_slots, int32_t slot_base, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ csr_idx,
+                              const float* __restrict__ csr_e, int32_t world, int32_t me, const int32_t* __restrict__ my_rowptr,
+                              int32_t* __restrict__ my_idx, float* __restrict__ my_e) {
+    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    for (int32_t v = blockIdx.x * wpb + (threadIdx.x >> 6); v < n_slots; v += gridDim.x * wpb) {
+        int at = my_rowptr[v];
+        const int32_t a = rowptr[slot_base + v], b = rowptr[slot_base + v + 1];
+        for (int32_t f0 = a; f0 < b; f0 += 64) {
+            const int32_t f = f0 + lane;
+            const int32_t j = f < b ? csr_idx[f] : -1;
+            const bool mine = j >= 0 && (j % world) == me;
+            const unsigned long long bal = __ballot(mine);
+            if (mine) {
+                const int k = at + __popcll(bal & ((1ull << lane) - 1ull));
+                my_idx[k] = j / world;
+                my_e[k] = csr_e[f];
+            }
+            at += __popcll(bal);
         }
-        out[t] = lo;
     }
 }
 
-// CSC entries (rater slot, weight) of item rows [r0, r0 + nrows), row by row: the compact CSC a cooperative rank builds its
+// CSC entries (rater slot, weight) of item rows r0, r0 + stride, ... (nrows of them), row by row: the compact CSC a cooperative rank builds its
 // segment table from
-__global__ void k_gather_rows(int32_t r0, int32_t nrows, const int32_t* __restrict__ rank_pair, const int32_t* __restrict__ pair_start,
+__global__ void k_gather_rows(int32_t r0, int32_t stride, int32_t nrows, const int32_t* __restrict__ rank_pair, const int32_t* __restrict__ pair_start,
                               const int32_t* __restrict__ local_start, const int32_t* __restrict__ csc_slot,
                               const float* __restrict__ csc_w, int32_t* __restrict__ my_slot, float* __restrict__ my_w) {
     const int lane = threadIdx.x & 63;
     const int wpb = blockDim.x >> 6;
     for (int32_t i = blockIdx.x * wpb + (threadIdx.x >> 6); i < nrows; i += gridDim.x * wpb) {
-        const int32_t pr = rank_pair[r0 + i];
+        const int32_t pr = rank_pair[r0 + i * stride];
         const int32_t q0 = pair_start[pr], n = pair_start[pr + 1] - q0, l0 = local_start[i];
         for (int32_t k = lane; k < n; k += 64) { my_slot[l0 + k] = csc_slot[q0 + k]; my_w[l0 + k] = csc_w[q0 + k]; }
     }
@@ -1239,7 +1270,8 @@ __global__ __launch_bounds__(256) void k_score_entries(const float* __restrict__
                                                        const float* __restrict__ csr_e_, const double* __restrict__ pvpi_,
                                                        const long long* __restrict__ entries_, const int32_t* __restrict__ counts_,
                                                        int32_t world, int32_t t_max, int32_t slot_base, int32_t Ic, int64_t ldm,
-                                                       float* __restrict__ Spart_, unsigned long long* __restrict__ counters) {
+                                                       int32_t row_mul, int32_t row_add, float* __restrict__ Spart_,
+                                                       unsigned long long* __restrict__ counters) {
     const int lane = threadIdx.x & 63;
     const int wave_in_grid = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
     const int n_waves = gridDim.x * (blockDim.x >> 6);
@@ -1259,7 +1291,7 @@ __global__ __launch_bounds__(256) void k_score_entries(const float* __restrict__
 #pragma unroll
         for (int v = 0; v < 4; v++) a[v] = col + v < Ic ? a_rank_[col + v] : 0.0f;
         const char* __restrict__ Mcol = reinterpret_cast<const char*>(M_) + (int64_t)col * 3;
-        const int beg = range_off_[2 * (slot - slot_base)], end = range_off_[2 * (slot - slot_base) + 1];
+        const int beg = range_off_[slot - slot_base], end = range_off_[slot - slot_base + 1];
         double t[4] = {0.0, 0.0, 0.0, 0.0};
         unsigned mask = 0;
         for (int kk0 = beg; kk0 < end; kk0 += SB) {
@@ -1281,7 +1313,7 @@ __global__ __launch_bounds__(256) void k_score_entries(const float* __restrict__
                     fy_unpack24(g[x], gv);
 #pragma unroll
                     for (int v = 0; v < 4; v++) p[v] += fy_log2(fmaf(a[v], e[x], gv[v]));
-                    const unsigned d = (unsigned)(jj[x] - col);
+                    const unsigned d = (unsigned)(jj[x] * row_mul + row_add - col);
                     if (d < 4u) mask |= 1u << d;
                 }
             }
@@ -1415,7 +1447,7 @@ struct Plan {
 
 // ================================================================ cooperative ranks: one cluster scored by all ranks together
 // (include/filmyou.h, fy_collectives).  score(u, i) = pvpi + sum over the user's rated items j of a term that
-// needs only row j of M, so the sum splits over any partition of the item rows: rank r builds rows [r0, r1) of M (and of
+// needs only row j of M, so the sum splits over any partition of the item rows: rank r builds rows r, r + world, ... of M (and of
 // the block maxima), evaluates for EVERY user of the cluster the partial sums over the rated items that fall into its
 // rows, and a reduce-scatter hands the owner of each user the complete sums.  Three exchanges follow the three pruned
 // passes: seed columns, block bounds, surviving blocks.  Rank 0 contributes pvpi; a rated candidate is masked (NaN) by
@@ -1474,35 +1506,17 @@ static void score_cluster_coop(const CoopShared& X, const Plan& p, hipStream_t l
     }
     const int32_t my_a = ua[me], n_mine = ub[me] - ua[me];
 
-    // ---- item rows of this rank: equal shares of the work model (row kernel + scoring passes)
-    std::vector<int32_t> rsplit(W + 1, Ic), hcnt;
-    std::vector<long long> all_hw;
+    // ---- item rows of this rank: me, me + W, me + 2 W, ... (popularity order: every rank gets the same mix of rows)
+    const int32_t r0 = me, nrows = Ic > me ? (Ic - me + W - 1) / W : 0;
+    std::vector<int32_t> hcnt((size_t)Ic);
+    int64_t my_ratings = 0, my_walk = 0;
     {
-        // work model of an item row, in CSR entries walked by the row kernel: sum_v n_v for the walk itself (k_pair_pass),
-        // ~300 per rating for the scoring passes over the row, and a constant for the row's epilogue (calibrated on ML-25M
-        // shape at 8 ranks, tools/coop_rehearsal.py)
-        const int64_t row_const = ldm;
         std::vector<long long> hw((size_t)Ic);
-        hcnt.resize((size_t)Ic);
         FY_HIP(hipMemcpyAsync(hw.data(), J->walk_rank.get() + pbase, (size_t)Ic * sizeof(long long), hipMemcpyDeviceToHost, ls));
         FY_HIP(hipMemcpyAsync(hcnt.data(), J->cnt_rank.get() + pbase, (size_t)Ic * sizeof(int32_t), hipMemcpyDeviceToHost, ls));
         FY_HIP(hipStreamSynchronize(ls));
-        for (int32_t i = 0; i < Ic; i++) hw[i] += 300 * (long long)hcnt[i] + row_const;
-        int64_t total = 0;
-        for (int32_t i = 0; i < Ic; i++) total += hw[i];
-        rsplit[0] = 0;
-        int64_t run = 0;
-        int k = 1;
-        for (int32_t i = 0; i < Ic && k < W; i++) {
-            run += hw[i];
-            while (k < W && run * W >= total * k) rsplit[k++] = i + 1;
-        }
-        // (entries not reached stay at Ic)
-        all_hw.swap(hw);
+        for (int32_t i = r0; i < Ic; i += W) { my_ratings += hcnt[i]; my_walk += hw[i]; }
     }
-    const int32_t r0 = rsplit[me], r1 = rsplit[me + 1], nrows = r1 - r0;
-    int64_t my_ratings = 0, my_walk = 0;
-    for (int32_t i = r0; i < r1; i++) { my_ratings += hcnt[i]; my_walk += all_hw[i] - 300 * (int64_t)hcnt[i] - ldm; }
     *X.coop_pair_contribs += my_walk - my_ratings;   // ordered off-diagonal co-rating pairs whose row is mine
 
     // ---- buffers
@@ -1513,7 +1527,11 @@ static void score_cluster_coop(const CoopShared& X, const Plan& p, hipStream_t l
     const int bchunks = (int)(ldb / 256);
     DevBuf<float> Mloc(ctx, (size_t)std::max<int64_t>(1, (int64_t)nrows * ldm * 3 / 4 + 4)), Bloc(ctx, (size_t)std::max<int64_t>(1, (int64_t)nrows * ldb));
     DevBuf<float> amax(ctx, (size_t)ldb);
-    DevBuf<int32_t> range_off(ctx, (size_t)Uc * 2), n_out_all(ctx, (size_t)Uc), item_counter(ctx, 1);
+    DevBuf<int32_t> n_out_all(ctx, (size_t)Uc), item_counter(ctx, 1);
+    // my compact CSR over all users of the cluster (local row indices); its size is not known on the host: room for all
+    const int64_t nnz_c = (int64_t)p.nq;
+    DevBuf<int32_t> my_cnt(ctx, (size_t)Uc + 1), my_rowptr(ctx, (size_t)Uc + 1), my_idx(ctx, (size_t)std::max<int64_t>(1, nnz_c));
+    DevBuf<float> my_e(ctx, (size_t)std::max<int64_t>(1, nnz_c));
     DevBuf<double> pv_all(ctx, (size_t)Uc);
     DevBuf<unsigned long long> dummy(ctx, 2);
     DevBuf<float> seed_send(ctx, (size_t)((int64_t)W * Umax * SC)), seed(ctx, (size_t)((int64_t)Umax * SC));
@@ -1522,9 +1540,8 @@ static void score_cluster_coop(const CoopShared& X, const Plan& p, hipStream_t l
     DevBuf<uint16_t> surv(ctx, (size_t)((int64_t)Umax * ldb));
     DevBuf<int32_t> n_quads(ctx, (size_t)Umax + 1), quad_prefix(ctx, (size_t)Umax + 1), overflow(ctx, (size_t)Umax), any_overflow(ctx, 1);
     DevBuf<int32_t> counts(ctx, (size_t)W);
-    // M and Bmax are addressed by absolute row: shift the base so that row r0 is the first one stored
-    const float* Mshift = reinterpret_cast<const float*>(reinterpret_cast<const char*>(Mloc.get()) - (int64_t)r0 * ldm * 3);
-    const float* Bshift = Bloc.get() - (int64_t)r0 * ldb;
+    const float* Mshift = Mloc.get();    // M / Bmax are indexed by the LOCAL row (k-th row of this rank)
+    const float* Bshift = Bloc.get();
 
     // ---- segment table of my rows (over a compact copy of their CSC entries), M build
     {
@@ -1532,12 +1549,12 @@ static void score_cluster_coop(const CoopShared& X, const Plan& p, hipStream_t l
         SegTable seg;
         build_chunk_offsets(ctx, P.rowptr.get(), P.csr_idx.get(), sbase, Uc, CH, nch, co_tmp.get(), ls);
         std::vector<int32_t> hls((size_t)nrows + 1, 0);
-        for (int32_t i = 0; i < nrows; i++) hls[i + 1] = hls[i] + hcnt[r0 + i];
+        for (int32_t i = 0; i < nrows; i++) hls[i + 1] = hls[i] + hcnt[r0 + (int64_t)i * W];
         DevBuf<int32_t> local_start(ctx, (size_t)nrows + 1), my_slot(ctx, (size_t)std::max<int64_t>(1, my_ratings));
         DevBuf<float> my_w(ctx, (size_t)std::max<int64_t>(1, my_ratings));
         FY_HIP(hipMemcpyAsync(local_start.get(), hls.data(), ((size_t)nrows + 1) * sizeof(int32_t), hipMemcpyHostToDevice, ls));
         if (nrows > 0) {
-            k_gather_rows<<<grid_for((int64_t)nrows * 64, 256), 256, 0, ls>>>(r0, nrows, P.rank_pair.get() + pbase, P.pair_start.get(),
+            k_gather_rows<<<grid_for((int64_t)nrows * 64, 256), 256, 0, ls>>>(r0, W, nrows, P.rank_pair.get() + pbase, P.pair_start.get(),
                                                                               local_start.get(), P.csc_slot.get(), X.csc_x, my_slot.get(), my_w.get());
             FY_KERNEL_CHECK();
         }
@@ -1547,9 +1564,9 @@ static void score_cluster_coop(const CoopShared& X, const Plan& p, hipStream_t l
         FY_KERNEL_CHECK();
         if (nrows > 0) {
             CoocArgs CA{P.rank_pair.get(), P.pair_start.get(), seg.ptr.get(), seg.seg.get(), seg.w.get(), P.csr_idx.get(),
-                        X.csr_x, pbase, sbase, Ic, CH, nch, r0, nrows, 0, (int32_t)my_ratings, tune.cooc_debug, local_start.get()};
+                        X.csr_x, pbase, sbase, Ic, CH, nch, r0, nrows, 0, (int32_t)my_ratings, tune.cooc_debug, local_start.get(), W};
             MEpilogue ME{const_cast<float*>(Mshift), ldm, X.p_rank + pbase, X.b_rank + pbase, (1.0 - lambda) * (1.0 - lambda),
-                         lambda * (1.0 - lambda), 1, const_cast<float*>(Bshift), ldb};
+                         lambda * (1.0 - lambda), 1, const_cast<float*>(Bshift), ldb, 1};
             const int block = tune.cooc_block ? tune.cooc_block : ((CH * 8 > 48 * 1024) ? 1024 : 256);
             const size_t sp = X.t_cooc->begin(ls);
             const int n_items = nrows * nch;
@@ -1565,7 +1582,11 @@ static void score_cluster_coop(const CoopShared& X, const Plan& p, hipStream_t l
     }
 
     // ---- per-user tables over the whole cluster
-    k_range_offsets<<<grid_for((int64_t)Uc * 2), 256, 0, ls>>>(P.rowptr.get(), P.csr_idx.get(), sbase, Uc, r0, r1, range_off.get());
+    k_my_csr_count<<<grid_for(((int64_t)Uc + 1) * 64, 256), 256, 0, ls>>>(Uc, sbase, P.rowptr.get(), P.csr_idx.get(), W, me, my_cnt.get());
+    FY_KERNEL_CHECK();
+    exclusive_scan_i32(ctx, my_cnt.get(), my_rowptr.get(), (size_t)Uc + 1, ls);
+    k_my_csr_fill<<<grid_for((int64_t)Uc * 64, 256), 256, 0, ls>>>(Uc, sbase, P.rowptr.get(), P.csr_idx.get(), X.csr_e, W, me, my_rowptr.get(),
+                                                                   my_idx.get(), my_e.get());
     FY_KERNEL_CHECK();
     FY_HIP(hipMemsetAsync(dummy.get(), 0, 2 * sizeof(unsigned long long), ls));
     k_user_meta<<<grid_for(Uc), 256, 0, ls>>>(sbase, sbase + Uc, P.slot2du.get(), P.uid.get(), P.ucluster.get(), P.udeg.get(),
@@ -1581,9 +1602,9 @@ static void score_cluster_coop(const CoopShared& X, const Plan& p, hipStream_t l
         const int32_t nk = ub[k] - ua[k];
         if (nk <= 0) continue;
         const int ns = slices_for(nk);
-        ScoreArgs SA{Mshift, ldm, Ic, X.a_rank + pbase, range_off.get(), P.csr_idx.get(), X.csr_e, pv_all.get(), n_out_all.get(),
-                     sbase, sbase, ua[k], nk, seed_send.get() + (int64_t)k * Umax * SC, SC, ns, 0, 1, 0, 0, seed_chunks, 0,
-                     nullptr, nullptr, nullptr, 0};
+        ScoreArgs SA{Mshift, ldm, Ic, X.a_rank + pbase, my_rowptr.get(), my_idx.get(), my_e.get(), pv_all.get(), n_out_all.get(),
+                     sbase, sbase, ua[k], nk, seed_send.get() + (int64_t)k * Umax * SC, SC, ns, 0, 0, 0, 0, seed_chunks, 0,
+                     nullptr, nullptr, nullptr, 0, W, me};
         k_score<4, true, 8><<<seed_chunks * ns, 256, 0, ls>>>(SA.M, SA.a_rank, SA.rb_off, SA.csr_idx, SA.csr_e, SA.pvpi, SA.n_out, SA.S, SA);
         FY_KERNEL_CHECK();
         R->st.score_launches++;
@@ -1601,9 +1622,9 @@ static void score_cluster_coop(const CoopShared& X, const Plan& p, hipStream_t l
         const int32_t nk = ub[k] - ua[k];
         if (nk <= 0) continue;
         const int ns = slices_for(nk);
-        ScoreArgs SB_{Bshift, ldb, p.nblk, amax.get(), range_off.get(), P.csr_idx.get(), X.csr_e, pv_all.get(), n_out_all.get(),
-                      sbase, sbase, ua[k], nk, ub_send.get() + (int64_t)k * Umax * ldb, ldb, ns, 0, 1, 0, 0, bchunks, 2,
-                      nullptr, nullptr, nullptr, seed_blocks};
+        ScoreArgs SB_{Bshift, ldb, p.nblk, amax.get(), my_rowptr.get(), my_idx.get(), my_e.get(), pv_all.get(), n_out_all.get(),
+                      sbase, sbase, ua[k], nk, ub_send.get() + (int64_t)k * Umax * ldb, ldb, ns, 0, 0, 0, 0, bchunks, 2,
+                      nullptr, nullptr, nullptr, seed_blocks, W, me};
         k_score<4, false, 8><<<bchunks * ns, 256, 0, ls>>>(SB_.M, SB_.a_rank, SB_.rb_off, SB_.csr_idx, SB_.csr_e, SB_.pvpi, SB_.n_out, SB_.S, SB_);
         FY_KERNEL_CHECK();
         R->st.score_launches++;
@@ -1637,8 +1658,8 @@ static void score_cluster_coop(const CoopShared& X, const Plan& p, hipStream_t l
         }
         coll_all_gather(J, entries.get(), entries_all.get(), (int64_t)t_max * (int64_t)sizeof(long long), ls);
         // ---- (7) partial exact scores of all survivors over my rows, reduce-scatter to the owners
-        k_score_entries<8><<<ctx->num_cus * 8, 256, 0, ls>>>(Mshift, X.a_rank + pbase, range_off.get(), P.csr_idx.get(), X.csr_e, pv_all.get(),
-                                                             entries_all.get(), counts.get(), W, t_max, sbase, Ic, ldm, Spart.get(),
+        k_score_entries<8><<<ctx->num_cus * 8, 256, 0, ls>>>(Mshift, X.a_rank + pbase, my_rowptr.get(), my_idx.get(), my_e.get(), pv_all.get(),
+                                                             entries_all.get(), counts.get(), W, t_max, sbase, Ic, ldm, W, me, Spart.get(),
                                                              X.prune_counters);
         FY_KERNEL_CHECK();
         R->st.score_launches++;
