@@ -200,6 +200,15 @@ def main():
         "datagen_s": gen_s, "roofline": roofline, "roofline_other_kernel": other,
     }
 
+    if world > 1:
+        n_runs = a.steps + a.warmup
+        out["multi_gpu"] = {"mode": "statistics exchange only (matrix replicated per rank)" if collectives is None else
+                            "fy_collectives over torch.distributed/%s: statistics all-gather + cooperative scoring of clusters "
+                            "that span all ranks" % dist.get_backend(),
+                            "collective_calls_per_step": None if collectives is None else
+                            {k: v / n_runs for k, v in collectives.calls.items() if k != "bytes"},
+                            "payload_bytes_per_rank_per_step": None if collectives is None else collectives.calls["bytes"] / n_runs}
+
     # ---- item-item similarity build on the same ratings (second headline unit: pairs/s)
     if not a.no_itemsim:
         try:
