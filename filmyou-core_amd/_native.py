@@ -118,6 +118,15 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise OSError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                       "(the HIP extension is required; there is no CPU fallback)" % LIB_PATH)
+    # One HIP runtime per process: the torch wheel bundles its own libamdhip64.so / libhsa-runtime64.so under the same
+    # SONAMEs as /opt/rocm's.  Whichever is loaded first serves both torch and this library; if this library came first,
+    # torch would later run on a runtime it was not built with (observed: "No HIP GPUs are available" from torch.cuda.init()).
+    # The Python host layer hands torch tensors / streams to the library anyway, so torch goes first.  A host without torch
+    # (the JNI shim, the C++ driver) simply uses the system ROCm.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, i64, i32, pvp = C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_void_p)
     L.fy_abi_version.restype = C.c_int

@@ -160,10 +160,22 @@ __global__ void k_pair_p(int32_t nP, const int32_t* __restrict__ rank_pair, cons
     }
 }
 
+// x = r / s_v per CSC entry; for the packed row kernel also x / s_v (the CSR side then carries the raw rating)
 __global__ void k_csc_x(int64_t nnz, const int32_t* __restrict__ csc_slot, const float* __restrict__ csc_r,
-                        const double* __restrict__ usum_slot, float* __restrict__ csc_x) {
-    for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < nnz; q += (int64_t)gridDim.x * blockDim.x)
-        csc_x[q] = (float)((double)csc_r[q] / usum_slot[csc_slot[q]]);
+                        const double* __restrict__ usum_slot, float* __restrict__ csc_x, float* __restrict__ csc_x_over_s) {
+    for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < nnz; q += (int64_t)gridDim.x * blockDim.x) {
+        const double s = usum_slot[csc_slot[q]];
+        const double x = (double)csc_r[q] / s;
+        csc_x[q] = (float)x;
+        if (csc_x_over_s) csc_x_over_s[q] = (float)(x / s);
+    }
+}
+
+// packed CSR of one cluster for the row kernel (fy_cooc.hpp): column index relative to its chunk | fp16 raw rating
+__global__ void k_pack_csr(int32_t f0, int32_t f1, int32_t CH, const int32_t* __restrict__ csr_idx, const float* __restrict__ csr_r,
+                           uint32_t* __restrict__ pk) {
+    for (int64_t f = f0 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; f < f1; f += (int64_t)gridDim.x * blockDim.x)
+        pk[f] = (uint32_t)(csr_idx[f] % CH) | ((uint32_t)__half_as_ushort(__float2half(csr_r[f])) << 16);
 }
 
 // one wave per user row: x = r / s_u and e = (1-l)(b_j - x) + l (U_c - 1) p_j  (all fp64, rounded once)
@@ -341,6 +353,7 @@ struct MEpilogue {
 // Persistent workgroups pull (row, chunk) items from a global counter (rows are in popularity order: heavy items first);
 // the epilogue re-zeroes the accumulators it reads, so an item costs one accumulate phase, one barrier, one epilogue and
 // one barrier -- no dispatch, no separate clearing pass.
+template <bool PK>
 __global__ void k_cooc_rm2(CoocArgs A, MEpilogue E, int n_items, int* __restrict__ next_item) {
     double* acc = fy_cooc_acc;
     __shared__ int sh_item;
@@ -360,7 +373,7 @@ __global__ void k_cooc_rm2(CoocArgs A, MEpilogue E, int n_items, int* __restrict
         const int row = A.row0 + lrow * (A.row_stride ? A.row_stride : 1);
         const int mrow = E.local_rows ? lrow : row;
         const int ch = item % A.nch;
-        if (A.debug != 3) cooc_accumulate_row(A, row, ch, lrow);
+        if (A.debug != 3) cooc_accumulate_row<PK>(A, row, ch, lrow);
         __syncthreads();
         if (A.debug == 4) continue;   // timing experiment: no epilogue (block-uniform)
         const int c0 = ch * A.CH;
@@ -1407,6 +1420,7 @@ struct ScoreTune {
     int64_t tile_bytes = (int64_t)1 << 40;   // M[row block][chunk] tile; default: one row block (sweep r1)
     int coop = 1;                      // cooperative scoring of clusters that span all ranks (needs fy_collectives)
     int coop_force = 0;                // test hook: cooperative path also with world == 1 (identity collectives)
+    int cooc_pk = 1;                   // packed 4-byte CSR entries for the row kernel when the ratings are fp16-exact
 };
 static ScoreTune score_tune() {
     ScoreTune t;
@@ -1422,6 +1436,7 @@ static ScoreTune score_tune() {
     if (const char* e = getenv("FY_PRUNE")) t.prune = atoi(e) != 0;
     if (const char* e = getenv("FY_COOP")) t.coop = atoi(e) != 0;
     if (const char* e = getenv("FY_COOP_FORCE")) t.coop_force = atoi(e) != 0;
+    if (const char* e = getenv("FY_COOC_PK")) t.cooc_pk = atoi(e) != 0;
     if (const char* e = getenv("FY_PRUNE_MIN_ITEMS")) t.prune_min_items = atoi(e);
     if (const char* e = getenv("FY_SEED_CHUNKS")) { int v = atoi(e); if (v >= 1 && v <= 4) t.seed_chunks = v; }
     if (const char* e = getenv("FY_WORKSPACE_GB")) { long v = atol(e); if (v >= 1) t.workspace_default = (int64_t)v << 30; }
@@ -1458,6 +1473,7 @@ struct CoopShared {
     const ScoreTune* tune;
     const double *p_rank, *b_rank;
     const float *a_rank, *csc_x, *csr_x, *csr_e;
+    const uint32_t* csr_pk;        // packed CSR for the row kernel (nullptr: csr_idx / csr_x); csc_x then holds x / s_v
     const int32_t *n_out, *out_off;   // this rank's users, by slot - lo
     int32_t lo;
     EventTimer *t_cooc, *t_score, *t_topn;
@@ -1564,7 +1580,7 @@ static void score_cluster_coop(const CoopShared& X, const Plan& p, hipStream_t l
         FY_KERNEL_CHECK();
         if (nrows > 0) {
             CoocArgs CA{P.rank_pair.get(), P.pair_start.get(), seg.ptr.get(), seg.seg.get(), seg.w.get(), P.csr_idx.get(),
-                        X.csr_x, pbase, sbase, Ic, CH, nch, r0, nrows, 0, (int32_t)my_ratings, tune.cooc_debug, local_start.get(), W};
+                        X.csr_x, pbase, sbase, Ic, CH, nch, r0, nrows, 0, (int32_t)my_ratings, tune.cooc_debug, local_start.get(), W, X.csr_pk};
             MEpilogue ME{const_cast<float*>(Mshift), ldm, X.p_rank + pbase, X.b_rank + pbase, (1.0 - lambda) * (1.0 - lambda),
                          lambda * (1.0 - lambda), 1, const_cast<float*>(Bshift), ldb, 1};
             const int block = tune.cooc_block ? tune.cooc_block : ((CH * 8 > 48 * 1024) ? 1024 : 256);
@@ -1573,7 +1589,8 @@ static void score_cluster_coop(const CoopShared& X, const Plan& p, hipStream_t l
             const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2048 / block, (160 * 1024) / ((size_t)CH * 8 + 1024)));
             const int grid = std::min(n_items, ctx->num_cus * per_cu);
             FY_HIP(hipMemsetAsync(item_counter.get(), 0, sizeof(int32_t), ls));
-            k_cooc_rm2<<<grid, block, (size_t)CH * 8, ls>>>(CA, ME, n_items, item_counter.get());
+            if (X.csr_pk) k_cooc_rm2<true><<<grid, block, (size_t)CH * 8, ls>>>(CA, ME, n_items, item_counter.get());
+            else k_cooc_rm2<false><<<grid, block, (size_t)CH * 8, ls>>>(CA, ME, n_items, item_counter.get());
             FY_KERNEL_CHECK();
             X.t_cooc->end(sp, ls);
             R->st.cooc_launches++;
@@ -1800,7 +1817,11 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
     k_pair_p<<<grid_for(nP), 256, 0, st>>>(nP, P.rank_pair.get(), P.pair_di.get(), R->d_icoll.get(), lambda, p_rank.get(), a_rank.get());
     FY_KERNEL_CHECK();
     DevBuf<float> csc_x(ctx, P.nnz), csr_x(ctx, P.nnz), csr_e(ctx, P.nnz);
-    k_csc_x<<<grid_for(P.nnz), 256, 0, st>>>(P.nnz, P.csc_slot.get(), P.csc_r.get(), J->usum_slot.get(), csc_x.get());
+    const bool use_pk = tune.cooc_pk && P.ratings_fp16_exact;   // packed CSR for the row kernel
+    DevBuf<float> csc_x_over_s(ctx, use_pk ? (size_t)P.nnz : 1);
+    DevBuf<uint32_t> csr_pk(ctx, use_pk ? (size_t)P.nnz : 1);
+    k_csc_x<<<grid_for(P.nnz), 256, 0, st>>>(P.nnz, P.csc_slot.get(), P.csc_r.get(), J->usum_slot.get(), csc_x.get(),
+                                             use_pk ? csc_x_over_s.get() : nullptr);
     FY_KERNEL_CHECK();
     k_csr_values<<<grid_for((int64_t)nU * 64, 256), 256, 0, st>>>(nU, P.rowptr.get(), P.csr_idx.get(), P.csr_r.get(), P.slot2du.get(),
                                                                    P.ucluster.get(), P.usum.get(), P.d_csize.get(), P.d_pcstart.get(),
@@ -1864,7 +1885,8 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
     if (n_recs > 0 && max_Ic > 0) {
         const int64_t ws = prm.workspace_bytes > 0 ? prm.workspace_bytes : tune.workspace_default;
         const int max_ch_lds = tune.cooc_max_ch;   // fp64 accumulators: 128 KiB of the 160 KiB LDS
-        FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cooc_rm2), hipFuncAttributeMaxDynamicSharedMemorySize, max_ch_lds * 8));
+        FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cooc_rm2<false>), hipFuncAttributeMaxDynamicSharedMemorySize, max_ch_lds * 8));
+        FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cooc_rm2<true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_ch_lds * 8));
         FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_score_hot<true>), hipFuncAttributeMaxDynamicSharedMemorySize, SCORE_HOT_ROWS * 1024));
         FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_score_hot<false>), hipFuncAttributeMaxDynamicSharedMemorySize, SCORE_HOT_ROWS * 1024));
 
@@ -1981,9 +2003,19 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             DevBuf<int32_t> co_tmp(ctx, co_all);
             for (size_t pi = 0; pi < plans.size(); pi++) {
                 const Plan& p = plans[pi];
+                if (use_pk) {   // the cluster's CSR range (slots are cluster-major), chunk-relative indices for its CH
+                    int32_t fr[2];
+                    d2h(ctx, &fr[0], P.rowptr.get() + p.sbase, 1);
+                    d2h(ctx, &fr[1], P.rowptr.get() + p.sbase + p.Uc, 1);
+                    sync(ctx);
+                    if (fr[1] > fr[0]) {
+                        k_pack_csr<<<grid_for(fr[1] - fr[0]), 256, 0, st>>>(fr[0], fr[1], p.CH, P.csr_idx.get(), P.csr_r.get(), csr_pk.get());
+                        FY_KERNEL_CHECK();
+                    }
+                }
                 if (p.coop) continue;
                 build_chunk_offsets(ctx, P.rowptr.get(), P.csr_idx.get(), p.sbase, p.Uc, p.CH, p.nch, co_tmp.get());
-                build_segments(ctx, P.csc_slot.get(), csc_x.get(), co_tmp.get(), p.sbase, p.q0, p.nq, p.nch, segs[pi]);
+                build_segments(ctx, P.csc_slot.get(), use_pk ? csc_x_over_s.get() : csc_x.get(), co_tmp.get(), p.sbase, p.q0, p.nq, p.nch, segs[pi]);
             }
         }
         hipEvent_t fork = nullptr;
@@ -2002,7 +2034,8 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             const int64_t ldm = p.ldm;
             const bool pack24 = p.pack24;
             if (p.coop) {
-                CoopShared X{J, R.get(), &tune, p_rank.get(), b_rank.get(), a_rank.get(), csc_x.get(), csr_x.get(), csr_e.get(),
+                CoopShared X{J, R.get(), &tune, p_rank.get(), b_rank.get(), a_rank.get(), use_pk ? csc_x_over_s.get() : csc_x.get(), csr_x.get(), csr_e.get(),
+                             use_pk ? csr_pk.get() : nullptr,
                              n_out.get(), out_off.get(), lo, &t_cooc, &t_score, &t_topn, prune_counters.get(),
                              &prune_blocks_total, &prune_seed_terms_cols, &coop_survived, &coop_pair_contribs};
                 score_cluster_coop(X, p, ls);
@@ -2011,7 +2044,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
 
             // -- M build
             CoocArgs CA{P.rank_pair.get(), P.pair_start.get(), segs[pi].ptr.get(), segs[pi].seg.get(), segs[pi].w.get(), P.csr_idx.get(),
-                        csr_x.get(), pbase, sbase, Ic, CH, nch, 0, Ic, p.q0, p.nq, tune.cooc_debug};
+                        csr_x.get(), pbase, sbase, Ic, CH, nch, 0, Ic, p.q0, p.nq, tune.cooc_debug, nullptr, 0, use_pk ? csr_pk.get() : nullptr};
             MEpilogue ME{L.M.get(), ldm, p_rank.get() + pbase, b_rank.get() + pbase, (1.0 - lambda) * (1.0 - lambda), lambda * (1.0 - lambda),
                          pack24 ? 1 : 0, p.prune ? L.Bmax.get() : nullptr, p.ldb};
             if (p.prune) {
@@ -2026,7 +2059,8 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2048 / block, (160 * 1024) / ((size_t)CH * 8 + 1024)));
                 const int grid = std::min(n_items, ctx->num_cus * per_cu);
                 FY_HIP(hipMemsetAsync(L.any_overflow.get(), 0, sizeof(int32_t), ls));   // reused as the item counter
-                k_cooc_rm2<<<grid, block, (size_t)CH * 8, ls>>>(CA, ME, n_items, L.any_overflow.get());
+                if (use_pk) k_cooc_rm2<true><<<grid, block, (size_t)CH * 8, ls>>>(CA, ME, n_items, L.any_overflow.get());
+                else k_cooc_rm2<false><<<grid, block, (size_t)CH * 8, ls>>>(CA, ME, n_items, L.any_overflow.get());
             }
             FY_KERNEL_CHECK();
             t_cooc.end(sp, ls);

@@ -159,6 +159,7 @@ class ThreadGroup:
 
     def __init__(self, world, serialize=False):
         import threading
+        torch.cuda.init()      # torch's lazy CUDA initialisation is not safe to race from the rank threads
         self.world = world
         self.barrier = threading.Barrier(world)
         self.slots = [None] * world
