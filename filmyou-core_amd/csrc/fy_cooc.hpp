@@ -47,6 +47,9 @@ struct CoocArgs {
     // entry = column index relative to its chunk (16 bits) | the raw rating as fp16; the rater's 1 / s_v is folded into
     // seg_w.  Halves the bytes of the stream that bounds the row kernel.
     const uint32_t* __restrict__ csr_pk;
+    // optional: [k * nch + ch] = {first, end} segment of chunk ch of the launch's k-th row, precomputed (k_item_segments):
+    // one load instead of the rank_pair -> pair_start -> seg_ptr chain in front of every (row, chunk) item
+    const int2* __restrict__ item_seg;
 };
 
 // Accumulates chunk `ch` of row `row` into the workgroup's dynamic LDS (fy_cooc_acc[0..CH), zeroed by the caller; all
@@ -61,6 +64,9 @@ struct CoocArgs {
 // 4 raters per wave-step 84; + pipelined long-slice loop 48 (of which 28 were waves idling behind the wave that held a
 // long slice); LDS queue for the remainders 104; segment s of rater r -> wave (r + s) mod 16 with every wave reading all
 // metadata 90; persistent workgroups 47; this version (segments precomputed per CSC entry): DESIGN.md section 7.
+#ifndef FY_COOC_NB
+#define FY_COOC_NB 8    // segment loads per group; two groups are in flight per wave (see cooc_accumulate_row)
+#endif
 extern __shared__ double fy_cooc_acc[];
 
 template <bool PK = false>
@@ -68,66 +74,97 @@ __device__ __forceinline__ void cooc_accumulate_row(const CoocArgs& A, int row, 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = blockDim.x >> 6;
-    const int pair = A.rank_pair[A.pbase + row];
-    int e0 = A.pair_start[pair], e1 = A.pair_start[pair + 1];
-    if (A.local_start) { e0 = A.local_start[lrow]; e1 = A.local_start[lrow + 1]; }
-    const int32_t* __restrict__ sp = A.seg_ptr + (int64_t)ch * (A.nq + 1) - A.q0;
-    const int s_begin = sp[e0], s_end = sp[e1];
+    int s_begin, s_end;
+    if (A.item_seg) {
+        const int2 se = A.item_seg[(int64_t)lrow * A.nch + ch];
+        s_begin = se.x;
+        s_end = se.y;
+    } else {
+        const int pair = A.rank_pair[A.pbase + row];
+        int e0 = A.pair_start[pair], e1 = A.pair_start[pair + 1];
+        if (A.local_start) { e0 = A.local_start[lrow]; e1 = A.local_start[lrow + 1]; }
+        const int32_t* __restrict__ sp = A.seg_ptr + (int64_t)ch * (A.nq + 1) - A.q0;
+        s_begin = sp[e0];
+        s_end = sp[e1];
+    }
     const int c0 = ch * A.CH;
     const int32_t* __restrict__ csr_idx = A.csr_idx;
     const float* __restrict__ csr_w = A.csr_w;
     const uint32_t* __restrict__ csr_pk = A.csr_pk;
-    constexpr int NB = 8;
-    // a wave fetches 64 segment descriptors with one vector load (one round trip per 64 segments) and then works through
-    // them eight at a time: eight coalesced slice loads in flight, then eight LDS atomics
-    for (int sb = s_begin + wave * 64; sb < s_end; sb += nwaves * 64) {   // wave-uniform
-        int2 d = make_int2(0, 0);
-        float w = 0.0f;
-        if (sb + lane < s_end) { d = A.seg[sb + lane]; w = A.seg_w[sb + lane]; }
-        const int nloc = min(64, s_end - sb);
-        for (int g = 0; g < nloc; g += NB) {
-            int F[NB], L[NB];
-            float W[NB];
+    constexpr int NB = FY_COOC_NB;
+    // A wave fetches 64 segment descriptors with one vector load and works through them in groups of NB: NB coalesced
+    // slice loads, then NB LDS atomics.  Software-pipelined by hand (the compiler keeps the order it is given): the loads
+    // of group g + 1 are issued BEFORE the atomics of group g, and the descriptors of the wave's next batch before the
+    // first group of this one -- the kernel is bound by round trips to L2 / Infinity Cache per wave, not by bytes or by the
+    // LDS atomics (FY_COOC_DEBUG=1, no atomics: 19.6 of 20.9 ms).
+    struct Group {
+        int L[NB];
+        float W[NB];
+        int idx[NB];
+        float x[NB];
+    };
+    auto issue = [&](Group& G, const int2& d, float w, int g) __attribute__((always_inline)) {
 #pragma unroll
-            for (int q = 0; q < NB; q++) {
-                F[q] = __builtin_amdgcn_readlane(d.x, g + q);
-                L[q] = __builtin_amdgcn_readlane(d.y, g + q);
-                W[q] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(w), g + q));
-            }
-            int idx[NB];
-            float x[NB];
-#pragma unroll
-            for (int q = 0; q < NB; q++) {
-                idx[q] = c0; x[q] = 0.0f;
-                if (lane < L[q]) {
-                    // (packed: only the load sits in the predicated block -- a use inside it would put a full
-                    // s_waitcnt behind every load and serialise the eight of them; measured: 42 ms instead of 24)
-                    if constexpr (PK) idx[q] = (int)csr_pk[F[q] + lane];
-                    else {
-                        idx[q] = csr_idx[F[q] + lane];
-                        x[q] = csr_w[F[q] + lane];
-                    }
-                }
-            }
-            if constexpr (PK) {
-#pragma unroll
-                for (int q = 0; q < NB; q++) {
-                    const uint32_t pk = (uint32_t)idx[q];
-                    x[q] = lane < L[q] ? __half2float(__ushort_as_half((unsigned short)(pk >> 16))) : 0.0f;
-                    idx[q] = lane < L[q] ? c0 + (int)(pk & 0xFFFFu) : c0;
-                }
-            }
-            if (A.debug == 1) {
-                float sink = 0.f;
-#pragma unroll
-                for (int q = 0; q < NB; q++) sink += x[q] + (float)idx[q];
-                if (sink == -12345.f) fy_cooc_acc[0] = sink;
-            } else {
-#pragma unroll
-                for (int q = 0; q < NB; q++)
-                    if (lane < L[q]) atomicAdd(&fy_cooc_acc[idx[q] - c0], (double)W[q] * (double)x[q]);   // ds_add_f64
+        for (int q = 0; q < NB; q++) {
+            const int F = __builtin_amdgcn_readlane(d.x, g + q);
+            G.L[q] = __builtin_amdgcn_readlane(d.y, g + q);
+            G.W[q] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(w), g + q));
+            // Unconditional loads, straight-line code: lanes beyond the segment re-read its first entry (same cache line,
+            // no traffic; an empty descriptor reads entry 0).  With the loads inside `if (lane < L)` blocks the compiler's
+            // wait-count pass gave up at the branches and drained ALL outstanding loads (s_waitcnt vmcnt(0)) before the
+            // first use -- measured with a use inside the block: 42 ms instead of 24.
+            const int at = F + (lane < G.L[q] ? lane : 0);
+            G.x[q] = 0.0f;
+            if constexpr (PK) G.idx[q] = (int)csr_pk[at];
+            else {
+                G.idx[q] = csr_idx[at] - c0;
+                G.x[q] = csr_w[at];
             }
         }
+    };
+    auto commit = [&](Group& G) __attribute__((always_inline)) {
+        if constexpr (PK) {
+#pragma unroll
+            for (int q = 0; q < NB; q++) {
+                const uint32_t pk = (uint32_t)G.idx[q];
+                G.x[q] = __half2float(__ushort_as_half((unsigned short)(pk >> 16)));
+                G.idx[q] = (int)(pk & 0xFFFFu);
+            }
+        }
+        if (A.debug == 1) {
+            float sink = 0.f;
+#pragma unroll
+            for (int q = 0; q < NB; q++) sink += G.x[q] + (float)G.idx[q];
+            if (sink == -12345.f) fy_cooc_acc[0] = sink;
+        } else {
+#pragma unroll
+            for (int q = 0; q < NB; q++)
+                if (lane < G.L[q]) atomicAdd(&fy_cooc_acc[G.idx[q]], (double)G.W[q] * (double)G.x[q]);   // ds_add_f64
+        }
+    };
+    int sb = s_begin + wave * 64;
+    if (sb >= s_end) return;
+    int2 d = make_int2(0, 0);
+    float w = 0.0f;
+    if (sb + lane < s_end) { d = A.seg[sb + lane]; w = A.seg_w[sb + lane]; }
+    while (sb < s_end) {   // wave-uniform
+        const int nloc = min(64, s_end - sb);
+        const int sb_next = sb + nwaves * 64;
+        int2 dn = make_int2(0, 0);
+        float wn = 0.0f;
+        if (sb_next + lane < s_end) { dn = A.seg[sb_next + lane]; wn = A.seg_w[sb_next + lane]; }
+        Group GA, GB;
+        issue(GA, d, w, 0);
+        for (int g = 0; g < nloc; g += 2 * NB) {
+            const bool has_b = g + NB < nloc, has_a2 = g + 2 * NB < nloc;
+            if (has_b) issue(GB, d, w, g + NB);
+            commit(GA);
+            if (has_a2) issue(GA, d, w, g + 2 * NB);
+            if (has_b) commit(GB);
+        }
+        d = dn;
+        w = wn;
+        sb = sb_next;
     }
 }
 

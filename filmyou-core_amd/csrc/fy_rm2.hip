@@ -336,6 +336,20 @@ void build_segments(Context* ctx, const int32_t* csc_slot, const float* csc_w, c
     }
 }
 
+// segment range of every (row, chunk) item of a launch (CoocArgs::item_seg)
+__global__ void k_item_segments(CoocArgs A, int2* __restrict__ out) {
+    const int n = A.nrows * A.nch;
+    const int stride = A.row_stride ? A.row_stride : 1;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+        const int lrow = t / A.nch, ch = t % A.nch;
+        const int pair = A.rank_pair[A.pbase + A.row0 + lrow * stride];
+        int e0 = A.pair_start[pair], e1 = A.pair_start[pair + 1];
+        if (A.local_start) { e0 = A.local_start[lrow]; e1 = A.local_start[lrow + 1]; }
+        const int32_t* __restrict__ sp = A.seg_ptr + (int64_t)ch * (A.nq + 1) - A.q0;
+        out[t] = make_int2(sp[e0], sp[e1]);
+    }
+}
+
 // ================================================================ M build: co-rating row kernel + RM2 epilogue
 struct MEpilogue {
     float* __restrict__ M;
@@ -1563,6 +1577,7 @@ static void score_cluster_coop(const CoopShared& X, const Plan& p, hipStream_t l
     {
         DevBuf<int32_t> co_tmp(ctx, (size_t)Uc * (nch + 1));
         SegTable seg;
+        DevBuf<int2> item_seg(ctx, (size_t)std::max<int64_t>(1, (int64_t)nrows * nch));
         build_chunk_offsets(ctx, P.rowptr.get(), P.csr_idx.get(), sbase, Uc, CH, nch, co_tmp.get(), ls);
         std::vector<int32_t> hls((size_t)nrows + 1, 0);
         for (int32_t i = 0; i < nrows; i++) hls[i + 1] = hls[i] + hcnt[r0 + (int64_t)i * W];
@@ -1586,6 +1601,9 @@ static void score_cluster_coop(const CoopShared& X, const Plan& p, hipStream_t l
             const int block = tune.cooc_block ? tune.cooc_block : ((CH * 8 > 48 * 1024) ? 1024 : 256);
             const size_t sp = X.t_cooc->begin(ls);
             const int n_items = nrows * nch;
+            k_item_segments<<<grid_for(n_items), 256, 0, ls>>>(CA, item_seg.get());
+            FY_KERNEL_CHECK();
+            CA.item_seg = item_seg.get();
             const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2048 / block, (160 * 1024) / ((size_t)CH * 8 + 1024)));
             const int grid = std::min(n_items, ctx->num_cus * per_cu);
             FY_HIP(hipMemsetAsync(item_counter.get(), 0, sizeof(int32_t), ls));
@@ -1945,9 +1963,12 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             DevBuf<float> Bmax, amax, UB, tau;
             DevBuf<uint16_t> surv;
             DevBuf<int32_t> n_quads, quad_prefix;
+            DevBuf<int2> item_seg;
         };
         std::vector<Lane> lanes((size_t)NS);
         {
+            size_t is_el = 1;
+            for (auto& p : plans) is_el = std::max(is_el, (size_t)p.Ic * p.nch);
             size_t m_el = 1, s_el = 1, co_el = 1, rb_el = 1, ho_el = 1, ov_el = 1, sl_el = 1, bm_el = 1, ub_el = 1, am_el = 1;
             for (auto& p : plans) {
                 p.B = std::min<int64_t>(std::max<int64_t>(1, (ws / NS) / (p.ldm * 4)), p.b - p.a);
@@ -1989,6 +2010,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 L.surv.alloc(ctx, ub_el);
                 L.n_quads.alloc(ctx, ov_el + 1);
                 L.quad_prefix.alloc(ctx, ov_el + 1);
+                L.item_seg.alloc(ctx, is_el);
             }
         }
         DevBuf<unsigned long long> prune_counters(ctx, 2);   // [0] surviving blocks, [1] log terms evaluated by the three pruned passes
@@ -2056,6 +2078,9 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             const size_t sp = t_cooc.begin(ls);
             {
                 const int n_items = Ic * nch;
+                k_item_segments<<<grid_for(n_items), 256, 0, ls>>>(CA, L.item_seg.get());
+                FY_KERNEL_CHECK();
+                CA.item_seg = L.item_seg.get();
                 const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2048 / block, (160 * 1024) / ((size_t)CH * 8 + 1024)));
                 const int grid = std::min(n_items, ctx->num_cus * per_cu);
                 FY_HIP(hipMemsetAsync(L.any_overflow.get(), 0, sizeof(int32_t), ls));   // reused as the item counter
