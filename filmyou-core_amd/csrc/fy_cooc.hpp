@@ -168,6 +168,20 @@ __device__ __forceinline__ void cooc_accumulate_row(const CoocArgs& A, int row, 
     }
 }
 
+// segment range of every (row, chunk) item of a launch (CoocArgs::item_seg)
+static __global__ void k_item_segments(CoocArgs A, int2* __restrict__ out) {
+    const int n = A.nrows * A.nch;
+    const int stride = A.row_stride ? A.row_stride : 1;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+        const int lrow = t / A.nch, ch = t % A.nch;
+        const int pair = A.rank_pair[A.pbase + A.row0 + lrow * stride];
+        int e0 = A.pair_start[pair], e1 = A.pair_start[pair + 1];
+        if (A.local_start) { e0 = A.local_start[lrow]; e1 = A.local_start[lrow + 1]; }
+        const int32_t* __restrict__ sp = A.seg_ptr + (int64_t)ch * (A.nq + 1) - A.q0;
+        out[t] = make_int2(sp[e0], sp[e1]);
+    }
+}
+
 // segment table of one cluster from its chunk_off table; returns the number of segments (synchronises once)
 struct SegTable {
     DevBuf<int32_t> ptr;   // nch * (nq + 1)

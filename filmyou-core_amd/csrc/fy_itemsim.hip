@@ -73,6 +73,14 @@ struct ISimEpilogue {
     int32_t* __restrict__ out_cnt;     // [rows_mine]
     int32_t* __restrict__ out_other;   // [rows_mine * K]
     float* __restrict__ out_sim;       // [rows_mine * K]
+    // packed row kernel: the accumulators hold sum_v r_vi r_vj (exact in fp64 for fp16-exact ratings); cosine = that times
+    // inv_norm[i] inv_norm[j] (rank order).  nullptr: the weights were divided by the norms beforehand.
+    const double* __restrict__ inv_norm;
+    // per (row, chunk) item: its top K as (order key << 32 | ~raw item id), descending
+    int32_t* __restrict__ part_cnt;    // [rows_mine * nch]
+    uint64_t* __restrict__ part;       // [rows_mine * nch * K]
+    int32_t heavy_rows;                // leading rows of the launch that are split by chunk
+    int32_t n_items;                   // heavy_rows * nch + (rows - heavy_rows)
 };
 
 __device__ __forceinline__ void isim_sort_desc(uint64_t* v, int P2) {
@@ -90,68 +98,228 @@ __device__ __forceinline__ void isim_sort_desc(uint64_t* v, int P2) {
         }
 }
 
-// dynamic LDS: [CH doubles accumulators][ISIM_CAP uint64 candidates]
-__global__ void k_cooc_itemsim(CoocArgs A, ISimEpilogue E) {
-    double* acc = fy_cooc_acc;
-    uint64_t* cand = reinterpret_cast<uint64_t*>(fy_cooc_acc + A.CH);
-    __shared__ uint32_t sh_cnt, sh_tau;
-    const int mine = blockIdx.x;
-    const int row = A.row0 + E.rank + mine * E.world;
+// Cuts the n candidates in LDS down to (at least) the K best without sorting them: two 256-bin histogram levels over the
+// order keys (bits 31..24, then 23..16) locate a 16-bit key prefix T with  #(key >= T) >= K  and  #(key >= T + 1 prefix) < K;
+// everything below T goes.  ~8 barriers instead of the 66 of a 2048-element bitonic sort (rocprof: the sorts were half
+// of the kernel).  Returns the new count through sh_cnt and the new threshold through sh_tau; all threads call it.
+// Ties inside the last prefix all stay, so the result may hold more than K entries -- if it would not fit behind the next
+// streaming step the caller falls back to the exact sort.
+__device__ __forceinline__ void isim_select(uint64_t* cand, int n, int K, uint32_t* hist, uint32_t* sh_cnt, uint32_t* sh_tau,
+                                            uint32_t* sh_aux) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    if (n <= K) {   // block-uniform: nothing to cut
+        return;
+    }
+    uint32_t prefix = 0, above = 0;
+    for (int level = 0; level < 2; level++) {
+        const int shift = level == 0 ? 24 : 16;
+        for (int b = tid; b < 256; b += nt) hist[b] = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += nt) {
+            const uint32_t key = (uint32_t)(cand[i] >> 32);
+            if (level == 0 || (key >> 24) == (prefix >> 24)) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t cum = above;
+            int b = 255;
+            for (; b > 0; b--) {
+                if (cum + hist[b] >= (uint32_t)K) break;
+                cum += hist[b];
+            }
+            sh_aux[0] = prefix | ((uint32_t)b << shift);
+            sh_aux[1] = cum;
+        }
+        __syncthreads();
+        prefix = sh_aux[0];
+        above = sh_aux[1];
+        __syncthreads();
+    }
+    // keep key >= prefix (in place: all reads happen before the first write)
+    uint64_t mine[ISIM_CAP / 256];
+    int have = 0;
+    for (int i = tid; i < n; i += nt) {
+        const uint64_t c = cand[i];
+        if ((uint32_t)(c >> 32) >= prefix && have < ISIM_CAP / 256) mine[have++] = c;
+    }
+    __syncthreads();
+    if (tid == 0) *sh_cnt = 0;
+    __syncthreads();
+    for (int k = 0; k < have; k++) cand[atomicAdd(sh_cnt, 1u)] = mine[k];
+    if (tid == 0) *sh_tau = prefix;
+    __syncthreads();
+}
+
+// buffer (nearly) full: keep the K best (plus ties inside the last key prefix); exact sort when even that does not make room
+__device__ __forceinline__ void isim_cut(uint64_t* cand, int K, uint32_t* hist, uint32_t* sh_cnt, uint32_t* sh_tau, uint32_t* sh_aux) {
     const int tid = threadIdx.x;
-    if (tid == 0) { sh_cnt = 0; sh_tau = 0; }
-    const int self_raw = E.rank_item_raw[row];
-    for (int ch = 0; ch < A.nch; ch++) {
-        for (int t = tid; t < A.CH; t += blockDim.x) acc[t] = 0.0;
+    isim_select(cand, (int)*sh_cnt, K, hist, sh_cnt, sh_tau, sh_aux);
+    if (*sh_cnt + blockDim.x > (uint32_t)ISIM_CAP) {   // massive ties inside one key prefix (block-uniform)
+        const int n = (int)*sh_cnt;
         __syncthreads();
-        cooc_accumulate_row(A, row, ch);
+        for (int i = n + tid; i < ISIM_CAP; i += blockDim.x) cand[i] = 0ull;
         __syncthreads();
-        const int c0 = ch * A.CH;
-        const int ncol = min(A.CH, A.Ic - c0);
-        // stream the finished chunk through the running top-K: keep values >= tau, compact when the buffer fills
-        for (int base = 0; base < ncol; base += blockDim.x) {
-            const int t = base + tid;
-            if (t < ncol) {
-                const float s = (float)acc[t];
-                const int col = c0 + t;
-                bool ok = E.has_threshold ? (s >= E.threshold) : (s > 0.0f);
-                if (E.exclude_self && col == row) ok = false;
-                if (ok) {
-                    const uint32_t key = isim_order_key(s);
-                    if (key >= sh_tau) {
-                        const uint32_t pos = atomicAdd(&sh_cnt, 1u);
-                        cand[pos] = ((uint64_t)key << 32) | (uint32_t)(0x7FFFFFFF - E.rank_item_raw[col]);
-                    }
-                }
-            }
-            __syncthreads();
-            if (sh_cnt + blockDim.x > (uint32_t)ISIM_CAP) {   // block-uniform: the next step could overflow
-                const int n = (int)sh_cnt;
-                for (int i = n + tid; i < ISIM_CAP; i += blockDim.x) cand[i] = 0ull;
-                __syncthreads();
-                isim_sort_desc(cand, ISIM_CAP);
-                if (tid == 0) {
-                    sh_cnt = (uint32_t)min(n, E.K);
-                    if (n >= E.K) sh_tau = (uint32_t)(cand[E.K - 1] >> 32);
-                }
-                __syncthreads();
-            }
+        isim_sort_desc(cand, ISIM_CAP);
+        if (tid == 0) {
+            *sh_cnt = (uint32_t)min(n, K);
+            if (n >= K) *sh_tau = (uint32_t)(cand[K - 1] >> 32);   // inclusive: a later tie with a smaller item id still wins
         }
         __syncthreads();
     }
-    const int n = (int)sh_cnt;
-    int P2 = 1;
-    while (P2 < n) P2 <<= 1;
-    for (int i = n + tid; i < P2; i += blockDim.x) cand[i] = 0ull;
-    __syncthreads();
-    isim_sort_desc(cand, P2);
-    const int keep = min(n, E.K);
-    if (tid == 0) E.out_cnt[mine] = keep;
-    for (int i = tid; i < keep; i += blockDim.x) {
-        const uint64_t c = cand[i];
-        E.out_other[(int64_t)mine * E.K + i] = 0x7FFFFFFF - (int32_t)(uint32_t)c;
-        E.out_sim[(int64_t)mine * E.K + i] = isim_order_unkey((uint32_t)(c >> 32));
+}
+
+// dynamic LDS: [CH doubles accumulators][ISIM_CAP uint64 candidates].  Persistent workgroups pull (row, column chunk) ITEMS
+// from a global counter (heavy rows first) and leave the top K of that chunk; k_isim_merge folds a row's chunks together.
+// Only the heaviest rows are split by chunk (one workgroup per whole row left the heaviest row -- 10^5 raters, 5e7 slice
+// entries -- on a single CU for half of the kernel's run time); a light row is one item and carries its threshold from chunk
+// to chunk (splitting every row cost more in top-K work than it gained: 52 ms against 30).  The pass that streams a finished chunk through the top-K re-zeroes the accumulators it reads.
+template <bool PK>
+__global__ void k_cooc_itemsim(CoocArgs A, ISimEpilogue E, int* __restrict__ next_row) {
+    double* acc = fy_cooc_acc;
+    uint64_t* cand = reinterpret_cast<uint64_t*>(fy_cooc_acc + A.CH);
+    __shared__ uint32_t sh_cnt, sh_tau, sh_aux[2], hist[256];
+    __shared__ int sh_row;
+    const int tid = threadIdx.x;
+    const int stride = A.row_stride ? A.row_stride : 1;
+    for (int t = tid; t < A.CH; t += blockDim.x) acc[t] = 0.0;
+    int next = 0;
+    if (tid == 0) next = atomicAdd(next_row, 1);
+    for (;;) {
+        if (tid == 0) { sh_row = next; sh_cnt = 0; sh_tau = 0; }
+        __syncthreads();
+        const int item = sh_row;
+        if (item >= E.n_items) break;
+        if (tid == 0) next = atomicAdd(next_row, 1);   // the round trip hides behind this item's work
+        // the first heavy_rows rows are split into one item per column chunk, every other row is one item
+        const bool split = item < E.heavy_rows * A.nch;
+        const int mine = split ? item / A.nch : E.heavy_rows + (item - E.heavy_rows * A.nch);
+        const int ch_begin = split ? item - mine * A.nch : 0, ch_end = split ? ch_begin + 1 : A.nch;
+        const int slot = mine * A.nch + ch_begin;     // where this item's list goes
+        const int row = A.row0 + mine * stride;
+        const double scale_row = E.inv_norm ? E.inv_norm[row] : 1.0;
+        for (int ch = ch_begin; ch < ch_end; ch++) {
+            cooc_accumulate_row<PK>(A, row, ch, mine);
+            __syncthreads();
+            const int c0 = ch * A.CH;
+            const int ncol = min(A.CH, A.Ic - c0);
+            // Stream the finished chunk through the running top-K: values >= tau are appended to the candidate buffer, every
+            // accumulator that has been looked at is re-zeroed.  The whole chunk is taken WITHOUT a barrier (one barrier per
+            // 1024 columns was a third of the kernel); a candidate that finds the buffer full leaves its accumulator in place,
+            // the buffer is cut back (isim_select raises tau) and the pass runs again over what is left.  A consumed entry
+            // reads as similarity 0, which only a threshold <= 0 would accept again: that configuration steps with barriers.
+            const bool stepwise = E.has_threshold && !(E.threshold > 0.0f);
+            for (bool again = true; again;) {
+                const uint32_t tau = sh_tau;
+                for (int base = 0; base < ncol; base += blockDim.x) {
+                    const int t = base + tid;
+                    bool want = false;
+                    uint64_t c = 0;
+                    if (t < ncol) {
+                        const double a = acc[t];
+                        const int col = c0 + t;
+                        const float s = E.inv_norm ? (float)(a * scale_row * E.inv_norm[col]) : (float)a;
+                        bool ok = E.has_threshold ? (s >= E.threshold) : (s > 0.0f);
+                        if (E.exclude_self && col == row) ok = false;
+                        const uint32_t key = isim_order_key(s);
+                        want = ok && key >= (stepwise ? sh_tau : tau);
+                        if (want) c = ((uint64_t)key << 32) | (uint32_t)(0x7FFFFFFF - E.rank_item_raw[col]);
+                        else acc[t] = 0.0;
+                    }
+                    // one LDS atomic per wave
+                    const unsigned long long bal = __ballot(want);
+                    if (bal) {
+                        const int lane = tid & 63;
+                        uint32_t at = 0;
+                        if (lane == __ffsll((long long)bal) - 1) at = atomicAdd(&sh_cnt, (uint32_t)__popcll(bal));
+                        at = __shfl(at, __ffsll((long long)bal) - 1, 64);
+                        if (want) {
+                            const uint32_t pos = at + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+                            if (pos < (uint32_t)ISIM_CAP) { cand[pos] = c; acc[t] = 0.0; }
+                        }
+                    }
+                    if (stepwise) {
+                        __syncthreads();
+                        if (sh_cnt + blockDim.x > (uint32_t)ISIM_CAP) isim_cut(cand, E.K, hist, &sh_cnt, &sh_tau, sh_aux);
+                    }
+                }
+                __syncthreads();
+                again = false;
+                if (!stepwise && sh_cnt > (uint32_t)ISIM_CAP) {   // block-uniform: some candidates did not fit
+                    __syncthreads();
+                    if (tid == 0) sh_cnt = (uint32_t)ISIM_CAP;
+                    __syncthreads();
+                    isim_cut(cand, E.K, hist, &sh_cnt, &sh_tau, sh_aux);
+                    again = true;
+                }
+            }
+        }
+        isim_select(cand, (int)sh_cnt, E.K, hist, &sh_cnt, &sh_tau, sh_aux);   // then only ~K entries are left to sort
+        const int n = (int)sh_cnt;
+        int P2 = 1;
+        while (P2 < n) P2 <<= 1;
+        for (int i = n + tid; i < P2; i += blockDim.x) cand[i] = 0ull;
+        __syncthreads();
+        isim_sort_desc(cand, P2);
+        const int keep = min(n, E.K);
+        if (tid == 0) E.part_cnt[slot] = keep;
+        for (int i = tid; i < keep; i += blockDim.x) E.part[(int64_t)slot * E.K + i] = cand[i];
+        __syncthreads();   // everybody is done with sh_cnt / cand before the next item resets them
     }
-    (void)self_raw;
+}
+
+// packed CSR (fy_cooc.hpp): column index relative to its chunk | the raw rating (or 1 for the co-occurrence count) as fp16
+__global__ void k_isim_pack_csr(int64_t nnz, int32_t CH, const int32_t* __restrict__ csr_idx, const float* __restrict__ csr_r, int cosine,
+                                uint32_t* __restrict__ pk) {
+    for (int64_t f = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; f < nnz; f += (int64_t)gridDim.x * blockDim.x)
+        pk[f] = (uint32_t)(csr_idx[f] % CH) | ((uint32_t)__half_as_ushort(__float2half(cosine ? csr_r[f] : 1.0f)) << 16);
+}
+__global__ void k_isim_raw_weights(int64_t nnz, const float* __restrict__ csc_r, int cosine, float* __restrict__ csc_w) {
+    for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < nnz; q += (int64_t)gridDim.x * blockDim.x)
+        csc_w[q] = cosine ? csc_r[q] : 1.0f;
+}
+__global__ void k_isim_inv_norms(int32_t Ic, const int32_t* __restrict__ rank_pair, const double* __restrict__ norm, double* __restrict__ inv) {
+    for (int32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < Ic; r += gridDim.x * blockDim.x) inv[r] = 1.0 / norm[rank_pair[r]];
+}
+
+constexpr int ISIM_HEAVY = 4096;
+__global__ void k_isim_count_heavy(int32_t rows_mine, int32_t rank, int32_t world, const int32_t* __restrict__ rank_pair,
+                                   const int32_t* __restrict__ pair_start, int32_t* __restrict__ n_heavy) {
+    for (int32_t m = blockIdx.x * blockDim.x + threadIdx.x; m < rows_mine; m += gridDim.x * blockDim.x) {
+        const int32_t pr = rank_pair[rank + m * world];
+        if (pair_start[pr + 1] - pair_start[pr] > ISIM_HEAVY) atomicAdd(n_heavy, 1);
+    }
+}
+
+// one workgroup per row: fold the chunks' top-K lists (each sorted, disjoint columns) into the row's top K
+__global__ __launch_bounds__(256) void k_isim_merge(int32_t rows_mine, int32_t nch, int32_t K, const int32_t* __restrict__ part_cnt,
+                                                    const uint64_t* __restrict__ part, int32_t* __restrict__ out_cnt,
+                                                    int32_t* __restrict__ out_other, float* __restrict__ out_sim) {
+    __shared__ uint64_t buf[2 * ISIM_MAX_K];
+    const int tid = threadIdx.x;
+    for (int m = blockIdx.x; m < rows_mine; m += gridDim.x) {
+        int have = 0;
+        for (int ch = 0; ch < nch; ch++) {
+            const int n = part_cnt[(int64_t)m * nch + ch];
+            if (n == 0) continue;    // block-uniform
+            for (int i = tid; i < n; i += blockDim.x) buf[have + i] = part[((int64_t)m * nch + ch) * K + i];
+            const int tot = have + n;
+            if (have == 0) { have = n; __syncthreads(); continue; }   // a single list is already sorted
+            int P2 = 1;
+            while (P2 < tot) P2 <<= 1;
+            for (int i = tot + tid; i < P2; i += blockDim.x) buf[i] = 0ull;
+            __syncthreads();
+            isim_sort_desc(buf, P2);
+            have = min(tot, K);
+        }
+        __syncthreads();
+        if (tid == 0) out_cnt[m] = have;
+        for (int i = tid; i < have; i += blockDim.x) {
+            const uint64_t c = buf[i];
+            out_other[(int64_t)m * K + i] = 0x7FFFFFFF - (int32_t)(uint32_t)c;
+            out_sim[(int64_t)m * K + i] = isim_order_unkey((uint32_t)(c >> 32));
+        }
+        __syncthreads();
+    }
 }
 
 __global__ void k_isim_compact(int32_t rows_mine, int32_t K, int32_t rank, int32_t world, const int32_t* __restrict__ cnt,
@@ -198,14 +366,25 @@ fy_result* itemsim_build(Context* ctx, const fy_itemsim_params* prm, const fy_ra
     }
     const int32_t Ic = P.nP;   // single "cluster": every item is a pair
     const int cosine = prm->similarity == FY_SIMILARITY_COSINE;
-    DevBuf<double> norm(ctx, Ic);
-    DevBuf<float> csc_w(ctx, P.nnz), csr_w(ctx, P.nnz);
+    // packed row kernel (4-byte CSR entries, norms applied in the epilogue) when every rating is fp16-exact
+    const char* pk_env = getenv("FY_COOC_PK");
+    const bool use_pk = P.ratings_fp16_exact && !(pk_env && atoi(pk_env) == 0);
+    DevBuf<double> norm(ctx, Ic), inv_norm(ctx, Ic);
+    DevBuf<float> csc_w(ctx, P.nnz), csr_w(ctx, use_pk ? 1 : (size_t)P.nnz);
+    DevBuf<uint32_t> csr_pk(ctx, use_pk ? (size_t)P.nnz : 1);
     k_item_norms<<<grid_for((int64_t)Ic * 64, 256), 256, 0, st>>>(Ic, P.pair_start.get(), P.csc_r.get(), norm.get());
     FY_KERNEL_CHECK();
-    k_csc_weights<<<grid_for(P.nnz), 256, 0, st>>>(P.nnz, P.csc_pair.get(), P.csc_r.get(), norm.get(), cosine, csc_w.get());
-    FY_KERNEL_CHECK();
-    k_csr_weights<<<grid_for(P.nnz), 256, 0, st>>>(P.nnz, P.csr_idx.get(), P.csr_r.get(), P.rank_pair.get(), norm.get(), cosine, csr_w.get());
-    FY_KERNEL_CHECK();
+    if (use_pk) {
+        k_isim_raw_weights<<<grid_for(P.nnz), 256, 0, st>>>(P.nnz, P.csc_r.get(), cosine, csc_w.get());
+        FY_KERNEL_CHECK();
+        k_isim_inv_norms<<<grid_for(Ic), 256, 0, st>>>(Ic, P.rank_pair.get(), norm.get(), inv_norm.get());
+        FY_KERNEL_CHECK();
+    } else {
+        k_csc_weights<<<grid_for(P.nnz), 256, 0, st>>>(P.nnz, P.csc_pair.get(), P.csc_r.get(), norm.get(), cosine, csc_w.get());
+        FY_KERNEL_CHECK();
+        k_csr_weights<<<grid_for(P.nnz), 256, 0, st>>>(P.nnz, P.csr_idx.get(), P.csr_r.get(), P.rank_pair.get(), norm.get(), cosine, csr_w.get());
+        FY_KERNEL_CHECK();
+    }
 
     const int K = prm->max_similarities_per_item;
     const int max_ch = 16384;   // 128 KiB of fp64 accumulators + 16 KiB candidate buffer <= 160 KiB LDS
@@ -220,17 +399,47 @@ fy_result* itemsim_build(Context* ctx, const fy_itemsim_params* prm, const fy_ra
     if (rows_mine > 0) {
         SegTable segs;
         build_segments(ctx, P.csc_slot.get(), csc_w.get(), chunk_off.get(), 0, 0, (int32_t)P.nnz, nch, segs);
+        if (use_pk) {
+            k_isim_pack_csr<<<grid_for(P.nnz), 256, 0, st>>>(P.nnz, CH, P.csr_idx.get(), P.csr_r.get(), cosine, csr_pk.get());
+            FY_KERNEL_CHECK();
+        }
         CoocArgs CA{P.rank_pair.get(), P.pair_start.get(), segs.ptr.get(), segs.seg.get(), segs.w.get(), P.csr_idx.get(),
-                    csr_w.get(), 0, 0, Ic, CH, nch, 0, Ic, 0, (int32_t)P.nnz, 0};
+                    csr_w.get(), 0, 0, Ic, CH, nch, prm->rank, rows_mine, 0, (int32_t)P.nnz, 0, nullptr, prm->world,
+                    use_pk ? csr_pk.get() : nullptr, nullptr};
+        DevBuf<int2> item_seg(ctx, (size_t)rows_mine * nch);
+        DevBuf<int32_t> part_cnt(ctx, (size_t)rows_mine * nch);
+        part_cnt.zero();
+        // rows are in popularity order: the rows with more than ISIM_HEAVY raters are a prefix
+        DevBuf<int32_t> d_heavy(ctx, 1);
+        d_heavy.zero();
+        k_isim_count_heavy<<<grid_for(rows_mine), 256, 0, st>>>(rows_mine, prm->rank, prm->world, P.rank_pair.get(), P.pair_start.get(), d_heavy.get());
+        FY_KERNEL_CHECK();
+        const int32_t heavy_rows = nch > 1 ? fetch(ctx, d_heavy.get()) : 0;
+        const int64_t n_items = (int64_t)heavy_rows * nch + (rows_mine - heavy_rows);
+        DevBuf<uint64_t> part(ctx, (size_t)rows_mine * nch * K);
+        k_item_segments<<<grid_for((int64_t)rows_mine * nch), 256, 0, st>>>(CA, item_seg.get());
+        FY_KERNEL_CHECK();
+        CA.item_seg = item_seg.get();
         ISimEpilogue IE{P.rank_item_raw.get(), K, prm->exclude_self, prm->has_threshold, (float)prm->threshold, prm->rank,
-                        prm->world, cnt.get(), other.get(), sim.get()};
+                        prm->world, cnt.get(), other.get(), sim.get(), (use_pk && cosine) ? inv_norm.get() : nullptr,
+                        part_cnt.get(), part.get(), heavy_rows, (int32_t)n_items};
         const size_t lds = (size_t)CH * 8 + (size_t)ISIM_CAP * 8;
-        FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cooc_itemsim), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cooc_itemsim<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cooc_itemsim<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const int block = lds > 48 * 1024 ? 1024 : 256;
+        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2048 / block, (160 * 1024) / (lds + 1024)));
+        const int grid = (int)std::min<int64_t>(n_items, (int64_t)ctx->num_cus * per_cu);
+        DevBuf<int32_t> next_row(ctx, 1);
+        next_row.zero();
         const size_t sp = t_cooc.begin();
-        k_cooc_itemsim<<<rows_mine, block, lds, st>>>(CA, IE);
+        if (use_pk) k_cooc_itemsim<true><<<grid, block, lds, st>>>(CA, IE, next_row.get());
+        else k_cooc_itemsim<false><<<grid, block, lds, st>>>(CA, IE, next_row.get());
+        FY_KERNEL_CHECK();
+        k_isim_merge<<<std::min(rows_mine, ctx->num_cus * 8), 256, 0, st>>>(rows_mine, nch, K, part_cnt.get(), part.get(), cnt.get(), other.get(),
+                                                                            sim.get());
         FY_KERNEL_CHECK();
         t_cooc.end(sp);
+        sync(ctx);   // part / item_seg go back to the allocator at the end of this scope
         Rs->st.cooc_launches = 1;
     }
     exclusive_scan_i32(ctx, cnt.get(), off.get(), (size_t)rows_mine + 1);

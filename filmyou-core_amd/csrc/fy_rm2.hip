@@ -336,20 +336,6 @@ void build_segments(Context* ctx, const int32_t* csc_slot, const float* csc_w, c
     }
 }
 
-// segment range of every (row, chunk) item of a launch (CoocArgs::item_seg)
-__global__ void k_item_segments(CoocArgs A, int2* __restrict__ out) {
-    const int n = A.nrows * A.nch;
-    const int stride = A.row_stride ? A.row_stride : 1;
-    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
-        const int lrow = t / A.nch, ch = t % A.nch;
-        const int pair = A.rank_pair[A.pbase + A.row0 + lrow * stride];
-        int e0 = A.pair_start[pair], e1 = A.pair_start[pair + 1];
-        if (A.local_start) { e0 = A.local_start[lrow]; e1 = A.local_start[lrow + 1]; }
-        const int32_t* __restrict__ sp = A.seg_ptr + (int64_t)ch * (A.nq + 1) - A.q0;
-        out[t] = make_int2(sp[e0], sp[e1]);
-    }
-}
-
 // ================================================================ M build: co-rating row kernel + RM2 epilogue
 struct MEpilogue {
     float* __restrict__ M;
