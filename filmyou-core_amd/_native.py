@@ -13,7 +13,7 @@ LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libfilmyou_hip.so")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include", "filmyou.h")
 SOURCES = ["fy_api.hip", "fy_prep.hip", "fy_rm2.hip", "fy_itemsim.hip", "fy_itemcf.hip"]
-HEADERS = ["fy_common.hpp", "fy_prep.hpp", "fy_cooc.hpp", "fy_rm2.hpp"]  # fy_itemcf.hip uses fy_prep.hpp / fy_rm2.hpp
+HEADERS = ["fy_common.hpp", "fy_prep.hpp", "fy_cooc.hpp", "fy_rm2.hpp", "fy_rm2_kernels.hpp", "fy_rm2_coop.hpp"]  # fy_itemcf.hip uses fy_prep.hpp / fy_rm2.hpp
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics", "-Wall",
                "-Wno-unused-result"]
 

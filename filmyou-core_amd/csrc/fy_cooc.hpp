@@ -189,9 +189,7 @@ struct SegTable {
     DevBuf<float> w;
 };
 void build_segments(Context* ctx, const int32_t* csc_slot, const float* csc_w, const int32_t* chunk_off, int32_t slot_base,
-                    int32_t q0, int32_t nq, int32_t nch, SegTable& out, hipStream_t st = nullptr,
-                    const int32_t* csc_pair = nullptr, const int32_t* pair_rank = nullptr, int32_t row0 = 0, int32_t row1 = 0);
-// (csc_pair / pair_rank / [row0, row1): optional filter -- segments only for the CSC entries of these item rows)
+                    int32_t q0, int32_t nq, int32_t nch, SegTable& out, hipStream_t st = nullptr);
 
 // chunk_off table for one cluster: one thread per (slot, boundary)
 void build_chunk_offsets(Context* ctx, const int32_t* rowptr, const int32_t* csr_idx, int32_t slot_base, int32_t n_slots,

@@ -281,12 +281,12 @@ __global__ void k_isim_inv_norms(int32_t Ic, const int32_t* __restrict__ rank_pa
     for (int32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < Ic; r += gridDim.x * blockDim.x) inv[r] = 1.0 / norm[rank_pair[r]];
 }
 
-constexpr int ISIM_HEAVY = 4096;
+constexpr int ISIM_HEAVY = 4096;   // raters above which a row is split by column chunk (test hook: FY_ISIM_HEAVY)
 __global__ void k_isim_count_heavy(int32_t rows_mine, int32_t rank, int32_t world, const int32_t* __restrict__ rank_pair,
-                                   const int32_t* __restrict__ pair_start, int32_t* __restrict__ n_heavy) {
+                                   const int32_t* __restrict__ pair_start, int32_t heavy, int32_t* __restrict__ n_heavy) {
     for (int32_t m = blockIdx.x * blockDim.x + threadIdx.x; m < rows_mine; m += gridDim.x * blockDim.x) {
         const int32_t pr = rank_pair[rank + m * world];
-        if (pair_start[pr + 1] - pair_start[pr] > ISIM_HEAVY) atomicAdd(n_heavy, 1);
+        if (pair_start[pr + 1] - pair_start[pr] > heavy) atomicAdd(n_heavy, 1);
     }
 }
 
@@ -387,7 +387,8 @@ fy_result* itemsim_build(Context* ctx, const fy_itemsim_params* prm, const fy_ra
     }
 
     const int K = prm->max_similarities_per_item;
-    const int max_ch = 16384;   // 128 KiB of fp64 accumulators + 16 KiB candidate buffer <= 160 KiB LDS
+    int max_ch = 16384;   // 128 KiB of fp64 accumulators + 16 KiB candidate buffer <= 160 KiB LDS
+    if (const char* e = getenv("FY_COOC_MAX_CH")) { const int v = atoi(e); if (v >= 64 && v <= 16384) max_ch = v; }   // test hook: force column chunks
     int32_t CH, nch;
     pick_chunks(Ic, max_ch, CH, nch);
     DevBuf<int32_t> chunk_off(ctx, (size_t)P.nU * (nch + 1));
@@ -410,9 +411,11 @@ fy_result* itemsim_build(Context* ctx, const fy_itemsim_params* prm, const fy_ra
         DevBuf<int32_t> part_cnt(ctx, (size_t)rows_mine * nch);
         part_cnt.zero();
         // rows are in popularity order: the rows with more than ISIM_HEAVY raters are a prefix
+        int32_t heavy_raters = ISIM_HEAVY;
+        if (const char* e = getenv("FY_ISIM_HEAVY")) heavy_raters = std::max(0, atoi(e));
         DevBuf<int32_t> d_heavy(ctx, 1);
         d_heavy.zero();
-        k_isim_count_heavy<<<grid_for(rows_mine), 256, 0, st>>>(rows_mine, prm->rank, prm->world, P.rank_pair.get(), P.pair_start.get(), d_heavy.get());
+        k_isim_count_heavy<<<grid_for(rows_mine), 256, 0, st>>>(rows_mine, prm->rank, prm->world, P.rank_pair.get(), P.pair_start.get(), heavy_raters, d_heavy.get());
         FY_KERNEL_CHECK();
         const int32_t heavy_rows = nch > 1 ? fetch(ctx, d_heavy.get()) : 0;
         const int64_t n_items = (int64_t)heavy_rows * nch + (rows_mine - heavy_rows);

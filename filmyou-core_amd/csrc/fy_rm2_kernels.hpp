@@ -1,0 +1,926 @@
+// fy_rm2_kernels.hpp -- device code of the RM2 job's scoring side: the scoring kernel family, top-N, the branch-and-bound
+// helpers and the kernels of the cooperative multi-rank path.  NOT a standalone header: it is one section of fy_rm2.hip's
+// translation unit (included inside `namespace fy`, after the statistics / row-kernel sections), split out for size.
+#pragma once
+
+// ================================================================ scoring kernel (the dominant kernel)
+// Work item = (user, column chunk of 64*VEC items, row block): the wave walks the slice of the user's CSR row that falls
+// into the row block (wave-uniform scalar loads of idx and e) and for every rated item j streams the segment
+// M[j][chunk] (4*VEC bytes per lane, coalesced), adding log2(M[j][i] + a_i * e_uj) to the lane's VEC candidates.
+// No cross-lane traffic at all.
+//
+// Cache blocking (rocprof, round 1: one launch over all rows ran at 41 % L2 hit rate and 7.1 TB/s of fabric traffic,
+// i.e. it was bound by the L2-miss path): the rows are cut into blocks of `rb_rows`, one launch per block, and the grid
+// is chunk-major, so the resident workgroups of a launch touch only the tile M[row block][chunk] (rb_rows * 256 * VEC
+// bytes <= half an XCD L2).  Every tile is fetched from HBM once per XCD and all re-reads are L2 hits; the price is a
+// read-modify-write of the score row per non-empty (user, row block), a few percent of the row traffic.
+struct ScoreArgs {
+    const float* __restrict__ M;
+    int64_t ldm;
+    int32_t Ic;
+    const float* __restrict__ a_rank;      // l * p_i in rank order, offset by pbase
+    const int32_t* __restrict__ rb_off;    // [(slot - slot_base) * (nrb + 1) + rb] first CSR entry with idx >= rb * rb_rows
+    const int32_t* __restrict__ csr_idx;
+    const float* __restrict__ csr_e;
+    const double* __restrict__ pvpi;       // indexed by slot - slot_lo
+    const int32_t* __restrict__ n_out;     // indexed by slot - slot_lo; 0 = user gets no list
+    int32_t slot_lo;                       // first slot of this rank
+    int32_t slot_base;                     // first slot of the cluster (rb_off origin)
+    int32_t slot0;                         // first slot of this batch
+    int32_t n_users;                       // users in the batch
+    float* __restrict__ S;                 // [n_users][ldS]
+    int64_t ldS;
+    int32_t n_slices;
+    int32_t rb;                            // row block of this launch
+    int32_t nrb;                           // row blocks per row
+    int32_t nt_rows;                       // rows with index >= nt_rows are loaded non-temporally (0 = never)
+    int32_t xcd_map;                       // 1: workgroup b works on chunk 8 * (b / 8 / n_slices) + b % 8 (one chunk per XCD at a time)
+    int32_t n_chunks;
+    int32_t no_mask;                       // 1: the columns are not items (bound pass over block maxima): no "already rated" mask;
+                                           // 2: the same, but the (partial) bounds are stored like scores (cooperative ranks)
+    // bound pass only: blocks whose upper bound reaches tau_u are appended to the user's survivor list instead of being stored
+    const float* __restrict__ tau;         // [u]
+    uint16_t* __restrict__ surv;           // [u * ldS + k]
+    int32_t* __restrict__ n_surv;          // [u], zeroed before the launch
+    int32_t seed_blocks;
+    // cooperative ranks: csr_idx holds LOCAL row indices of M (k-th row of the rank); the item it stands for is
+    // k * row_mul + row_add (row_mul == 0: the index is the item itself)
+    int32_t row_mul, row_add;
+};
+
+__device__ __forceinline__ float fy_log2(float x) { return __builtin_amdgcn_logf(x); }   // v_log_f32
+
+template <int VEC> struct VecT;
+template <> struct VecT<1> { using type = float; };
+template <> struct VecT<2> { using type = float2; };
+template <> struct VecT<4> { using type = float4; };
+
+// The read-only arrays are separate `const T* __restrict__` kernel arguments (not struct members): only then does hipcc
+// prove them invariant and fetch the wave-uniform idx / e / offsets with scalar loads (s_load) instead of a vector
+// load + v_readfirstlane in front of every row-segment load.
+struct U3 {
+    uint32_t a, b, c;
+};
+typedef uint32_t fy_u32x3 __attribute__((ext_vector_type(3)));
+typedef float fy_f32x4 __attribute__((ext_vector_type(4)));
+typedef float fy_f32x2 __attribute__((ext_vector_type(2)));
+
+// Row segments of unpopular items are read by few users within an L2 lifetime: loading them with the non-temporal hint
+// keeps them from evicting the popular rows every wave of the XCD re-reads.
+template <class G>
+__device__ __forceinline__ G fy_load_nt(const char* p);
+template <>
+__device__ __forceinline__ U3 fy_load_nt<U3>(const char* p) {
+    const fy_u32x3 v = __builtin_nontemporal_load(reinterpret_cast<const fy_u32x3*>(p));
+    U3 r;
+    r.a = v.x; r.b = v.y; r.c = v.z;
+    return r;
+}
+template <>
+__device__ __forceinline__ float4 fy_load_nt<float4>(const char* p) {
+    const fy_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const fy_f32x4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+template <>
+__device__ __forceinline__ float2 fy_load_nt<float2>(const char* p) {
+    const fy_f32x2 v = __builtin_nontemporal_load(reinterpret_cast<const fy_f32x2*>(p));
+    return make_float2(v.x, v.y);
+}
+template <>
+__device__ __forceinline__ float fy_load_nt<float>(const char* p) {
+    return __builtin_nontemporal_load(reinterpret_cast<const float*>(p));
+}
+// four packed 24-bit values (12 bytes; exponent + 16 mantissa bits, no sign) -> four floats: v_perm_b32 + shift each
+__device__ __forceinline__ void fy_unpack24(const U3& d, float* f) {
+    f[0] = __uint_as_float(__builtin_amdgcn_perm(0u, d.a, 0x0201000cu) >> 1);
+    f[1] = __uint_as_float(__builtin_amdgcn_perm(d.b, d.a, 0x0504030cu) >> 1);
+    f[2] = __uint_as_float(__builtin_amdgcn_perm(d.c, d.b, 0x0403020cu) >> 1);
+    f[3] = __uint_as_float(__builtin_amdgcn_perm(0u, d.c, 0x0302010cu) >> 1);
+}
+
+// Does a block with upper bound `ub` have to be scored exactly for a user whose N-th best seed score is `tau`?
+// tau = +inf: the user emits nothing; tau = -inf: fewer than N finite seed scores, nothing can be excluded (ties at -inf
+// are broken by item id, so even a block of -inf scores may contribute).  The margin covers the rounding of both sums.
+__device__ __forceinline__ bool fy_bound_keeps(float ub, float tau) {
+    if (!(ub == ub) || tau == INFINITY) return false;
+    if (tau == -INFINITY) return true;
+    return ub + (1e-5f * fabsf(ub) + 1e-4f) >= tau;
+}
+
+template <int VEC, bool P24, int SB>
+__global__ __launch_bounds__(256) void k_score(const float* __restrict__ M_, const float* __restrict__ a_rank_,
+                                               const int32_t* __restrict__ rb_off_, const int32_t* __restrict__ csr_idx_,
+                                               const float* __restrict__ csr_e_, const double* __restrict__ pvpi_,
+                                               const int32_t* __restrict__ n_out_, float* __restrict__ S_, ScoreArgs A) {
+    using V = typename VecT<VEC>::type;
+    using G = typename std::conditional<P24, U3, V>::type;   // what one lane loads per row
+    static_assert(!P24 || VEC == 4, "24-bit rows are packed four columns to three dwords");
+    constexpr int CW = 64 * VEC;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int chunk = blockIdx.x / A.n_slices;
+    int slice = blockIdx.x - chunk * A.n_slices;
+    if (A.xcd_map) {   // blocks b and b + 8 share an XCD (round-robin dispatch): give every XCD its own chunk
+        const int t = blockIdx.x >> 3;
+        chunk = (t / A.n_slices) * 8 + (blockIdx.x & 7);
+        slice = t % A.n_slices;
+        if (chunk >= A.n_chunks) return;
+    }
+    const int col0 = chunk * CW;
+    const int col = col0 + lane * VEC;
+    float a[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; v++) a[v] = col + v < A.Ic ? a_rank_[col + v] : 0.0f;
+    // byte address of this lane's part of row 0; the row pitch is ldm * (P24 ? 3 : 4) bytes
+    const char* __restrict__ Mcol = reinterpret_cast<const char*>(M_) + (int64_t)col * (P24 ? 3 : 4);
+    const int64_t pitch = A.ldm * (P24 ? 3 : 4);
+    const double LN2 = 0.69314718055994530942;
+    const float qnan = __builtin_nanf("");
+    const bool first = A.rb == 0;
+    const int stride = A.nrb + 1;
+    const int row_mul = A.row_mul ? A.row_mul : 1;
+    for (int u = slice * 4 + wave; u < A.n_users; u += A.n_slices * 4) {
+        const int slot = A.slot0 + u;
+        if (n_out_[slot - A.slot_lo] == 0) continue;
+        const int32_t* __restrict__ ro = rb_off_ + (int64_t)(slot - A.slot_base) * stride + A.rb;
+        const int beg = ro[0], end = ro[1];
+        if (!first && beg == end) continue;
+        float* __restrict__ dst = S_ + (int64_t)u * A.ldS + col;
+        V old;
+        if (!first) old = *reinterpret_cast<const V*>(dst);      // issued early: its latency hides under the row loads
+        double t[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; v++) t[v] = 0.0;
+        unsigned mask = 0;
+        // batches of 8 rows: all eight segment loads are issued before the first use, also for a short tail
+        // (out-of-range slots re-load the last valid row -- an L1 hit -- and are skipped by a wave-uniform test)
+        for (int k = beg; k < end; k += SB) {
+            G g[SB];
+            float e[SB];
+            int jj[SB];
+#pragma unroll
+            for (int q = 0; q < SB; q++) {
+                const int kk = min(k + q, end - 1);
+                jj[q] = csr_idx_[kk];
+                e[q] = csr_e_[kk];
+                const char* src = Mcol + (int64_t)jj[q] * pitch;
+                if (A.nt_rows > 0 && jj[q] >= A.nt_rows) g[q] = fy_load_nt<G>(src);   // wave-uniform
+                else g[q] = *reinterpret_cast<const G*>(src);
+            }
+            float p[VEC];
+#pragma unroll
+            for (int v = 0; v < VEC; v++) p[v] = 0.f;
+#pragma unroll
+            for (int q = 0; q < SB; q++) {
+                if (k + q < end) {
+                    float gv[VEC];
+                    if constexpr (P24) fy_unpack24(g[q], gv);
+                    else {
+                        const float* gp = reinterpret_cast<const float*>(&g[q]);
+#pragma unroll
+                        for (int v = 0; v < VEC; v++) gv[v] = gp[v];
+                    }
+#pragma unroll
+                    for (int v = 0; v < VEC; v++) p[v] += fy_log2(fmaf(a[v], e[q], gv[v]));
+                    const unsigned d = (unsigned)(jj[q] * row_mul + A.row_add - col0);
+                    if (!A.no_mask && d < (unsigned)CW && (int)(d / VEC) == lane) mask |= 1u << (d % VEC);
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < VEC; v++) t[v] += (double)p[v];
+        }
+        V o;
+        float* ov = reinterpret_cast<float*>(&o);
+        if (first) {
+            const double base = pvpi_[slot - A.slot_lo];
+#pragma unroll
+            for (int v = 0; v < VEC; v++) ov[v] = (float)(base + LN2 * t[v]);
+        } else {
+            const float* oldv = reinterpret_cast<const float*>(&old);
+#pragma unroll
+            for (int v = 0; v < VEC; v++) ov[v] = (float)((double)oldv[v] + LN2 * t[v]);
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; v++)
+            if ((mask >> v) & 1u || col + v >= A.Ic) ov[v] = qnan;
+        if (A.no_mask == 1) {
+            // bound pass: column = candidate block.  Keep the blocks behind the seed whose bound (plus a margin over the
+            // rounding of both sums, each accurate to ~1e-7 relative) reaches tau_u.
+            const float t = A.tau[u];
+            int base = 0;
+            int mine[VEC];
+            unsigned long long bal[VEC];
+#pragma unroll
+            for (int v = 0; v < VEC; v++) {
+                const bool keep = fy_bound_keeps(ov[v], t) && (col + v >= A.seed_blocks);
+                bal[v] = __ballot(keep);
+                mine[v] = keep ? base + __popcll(bal[v] & ((1ull << lane) - 1ull)) : -1;
+                base += __popcll(bal[v]);
+            }
+            if (base > 0) {   // wave-uniform
+                int at = 0;
+                if (lane == 0) at = atomicAdd(&A.n_surv[u], base);
+                at = __builtin_amdgcn_readfirstlane(at);
+#pragma unroll
+                for (int v = 0; v < VEC; v++)
+                    if (mine[v] >= 0) A.surv[(int64_t)u * A.ldS + at + mine[v]] = (uint16_t)(col + v);
+            }
+            continue;
+        }
+        *reinterpret_cast<V*>(dst) = o;
+    }
+}
+
+// ---------------------------------------------------------------- variant with the hottest rows resident in LDS
+// One 1024-thread workgroup per CU keeps the `H` most popular rows of its column chunk (popularity rank = row index) in
+// LDS as fp32 -- 128 rows x 1 KiB -- for its whole life and scores many users against them; those rows carry ~22 % of
+// all row reads of the ML-25M-shaped workload, which then never leave the CU.  The cold remainder of every user's row
+// is streamed from global memory exactly like k_score.  hot_off[(slot - slot_base) * 3 + {0,1,2}] = {row begin,
+// first entry with idx >= H, row end}.
+constexpr int SCORE_HOT_ROWS = 128;
+
+template <bool P24>
+__global__ __launch_bounds__(1024) void k_score_hot(const float* __restrict__ M_, const float* __restrict__ a_rank_,
+                                                    const int32_t* __restrict__ hot_off_, const int32_t* __restrict__ csr_idx_,
+                                                    const float* __restrict__ csr_e_, const double* __restrict__ pvpi_,
+                                                    const int32_t* __restrict__ n_out_, float* __restrict__ S_, ScoreArgs A) {
+    extern __shared__ float4 fy_hot_tile[];   // [H][64] float4
+    using G = typename std::conditional<P24, U3, float4>::type;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwaves = blockDim.x >> 6;
+    const int chunk = blockIdx.x / A.n_slices;
+    const int slice = blockIdx.x - chunk * A.n_slices;
+    const int col0 = chunk * 256;
+    const int col = col0 + lane * 4;
+    const int H = min(SCORE_HOT_ROWS, A.Ic);
+    const char* __restrict__ Mcol = reinterpret_cast<const char*>(M_) + (int64_t)col * (P24 ? 3 : 4);
+    const int64_t pitch = A.ldm * (P24 ? 3 : 4);
+    // stage the hot rows: wave w loads rows w, w + nwaves, ... (one coalesced row segment per instruction)
+    for (int r = wave; r < H; r += nwaves) {
+        const G g = *reinterpret_cast<const G*>(Mcol + (int64_t)r * pitch);
+        float4 f;
+        if constexpr (P24) {
+            float t4[4];
+            fy_unpack24(g, t4);
+            f = make_float4(t4[0], t4[1], t4[2], t4[3]);
+        } else {
+            f = g;
+        }
+        fy_hot_tile[r * 64 + lane] = f;
+    }
+    float a[4];
+#pragma unroll
+    for (int v = 0; v < 4; v++) a[v] = col + v < A.Ic ? a_rank_[col + v] : 0.0f;
+    const double LN2 = 0.69314718055994530942;
+    const float qnan = __builtin_nanf("");
+    __syncthreads();
+    for (int u = slice * nwaves + wave; u < A.n_users; u += A.n_slices * nwaves) {
+        const int slot = A.slot0 + u;
+        if (n_out_[slot - A.slot_lo] == 0) continue;
+        const int32_t* __restrict__ ho = hot_off_ + (int64_t)(slot - A.slot_base) * 3;
+        const int beg = ho[0], hot_end = ho[1], end = ho[2];
+        double t[4] = {0.0, 0.0, 0.0, 0.0};
+        unsigned mask = 0;
+        // hot part: rows from LDS
+        for (int k = beg; k < hot_end; k += 8) {
+            float4 g[8];
+            float e[8];
+            int jj[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int kk = min(k + q, hot_end - 1);
+                jj[q] = csr_idx_[kk];
+                e[q] = csr_e_[kk];
+                g[q] = fy_hot_tile[jj[q] * 64 + lane];
+            }
+            float p[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                if (k + q < hot_end) {
+                    p[0] += fy_log2(fmaf(a[0], e[q], g[q].x));
+                    p[1] += fy_log2(fmaf(a[1], e[q], g[q].y));
+                    p[2] += fy_log2(fmaf(a[2], e[q], g[q].z));
+                    p[3] += fy_log2(fmaf(a[3], e[q], g[q].w));
+                    const unsigned d = (unsigned)(jj[q] - col0);
+                    if (d < 256u && (int)(d >> 2) == lane) mask |= 1u << (d & 3u);
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < 4; v++) t[v] += (double)p[v];
+        }
+        // cold part: rows streamed from global memory, sixteen segment loads in flight per wave (16 waves per CU)
+        constexpr int CB = 16;
+        for (int k = hot_end; k < end; k += CB) {
+            G g[CB];
+            float e[CB];
+            int jj[CB];
+#pragma unroll
+            for (int q = 0; q < CB; q++) {
+                const int kk = min(k + q, end - 1);
+                jj[q] = csr_idx_[kk];
+                e[q] = csr_e_[kk];
+                g[q] = *reinterpret_cast<const G*>(Mcol + (int64_t)jj[q] * pitch);
+            }
+            float p[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < CB; q++) {
+                if (k + q < end) {
+                    float gv[4];
+                    if constexpr (P24) fy_unpack24(g[q], gv);
+                    else { gv[0] = g[q].x; gv[1] = g[q].y; gv[2] = g[q].z; gv[3] = g[q].w; }
+#pragma unroll
+                    for (int v = 0; v < 4; v++) p[v] += fy_log2(fmaf(a[v], e[q], gv[v]));
+                    const unsigned d = (unsigned)(jj[q] - col0);
+                    if (d < 256u && (int)(d >> 2) == lane) mask |= 1u << (d & 3u);
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < 4; v++) t[v] += (double)p[v];
+        }
+        const double base = pvpi_[slot - A.slot_lo];
+        float4 o;
+        o.x = ((mask & 1u) || col + 0 >= A.Ic) ? qnan : (float)(base + LN2 * t[0]);
+        o.y = ((mask & 2u) || col + 1 >= A.Ic) ? qnan : (float)(base + LN2 * t[1]);
+        o.z = ((mask & 4u) || col + 2 >= A.Ic) ? qnan : (float)(base + LN2 * t[2]);
+        o.w = ((mask & 8u) || col + 3 >= A.Ic) ? qnan : (float)(base + LN2 * t[3]);
+        *reinterpret_cast<float4*>(S_ + (int64_t)u * A.ldS + col) = o;
+    }
+}
+
+// ================================================================ top-N (PriorityQueue + poll loop, AbstractRM2Reducer.java:325, 358-369)
+// One workgroup per user.  NaN marks "not a candidate" (rated by the user / padding).  Order: larger score first
+// (IntDouble.compareTo, M/util/IntDouble.java:31-34); ties, unspecified in the reference, by ascending raw item id
+// (at the cut-off of a truncated list: by ascending popularity rank).  Radix select on the order-preserving integer
+// image of the float finds the K-th value in three passes over the row (L2 resident), a fourth pass collects.
+struct TopNArgs {
+    const float* __restrict__ S;
+    int64_t ldS;
+    int32_t Ic;
+    const int32_t* __restrict__ n_out;     // by slot - slot_lo
+    const int32_t* __restrict__ out_off;   // by slot - slot_lo (exclusive prefix of n_out)
+    const int32_t* __restrict__ rank_item_raw;   // offset by pbase
+    const int32_t* __restrict__ slot2du;
+    const int32_t* __restrict__ uid;
+    int32_t slot_lo, slot0, cluster;
+    int32_t* __restrict__ out_user;
+    int32_t* __restrict__ out_item;
+    float* __restrict__ out_score;
+    int32_t* __restrict__ out_cluster;
+    // branch and bound (fy_rm2.hip, "exact pruning"): only the seed columns and the surviving 64-column blocks of a score row
+    // are ever written.  mode 0: the whole row is live.  mode 1 (seed phase): sort the seed columns, publish tau_u and the
+    // list the user gets if no block survives.  mode 2 (merge phase): users with surviving blocks only, seed + survivors.
+    int32_t mode;
+    int32_t seed_cols;
+    const uint16_t* __restrict__ surv;    // [u * ldb + k]: surviving block ids
+    const int32_t* __restrict__ n_quads;  // [u]: surviving blocks of the user
+    int64_t ldb;
+    float* __restrict__ tau;              // [u]
+    // cooperative ranks: the survivors' scores are not in the (seed-wide) row but packed, 256 floats per surviving block,
+    // at entry quad_prefix[u] + k; the user's blocks are in ascending order
+    const float* __restrict__ Ssurv;
+    const int32_t* __restrict__ quad_prefix;
+};
+
+__device__ __forceinline__ uint32_t fy_order_key(float f) {
+    const uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float fy_order_unkey(uint32_t k) {
+    const uint32_t b = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+    return __uint_as_float(b);
+}
+
+constexpr int TOPN_MAX = 2048;
+constexpr int TOPN_BINS = 4096;
+constexpr int TOPN_SAMPLE = 1024;
+constexpr int PRUNE_BLOCK_COLS = 256;   // candidate block of the branch and bound = one column chunk
+
+// descending bitonic sort of P2 (power of two) 64-bit keys in LDS; every thread of the block calls it
+__device__ __forceinline__ void fy_bitonic_desc(uint64_t* v, int P2) {
+    for (int k = 2; k <= P2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < P2; i += blockDim.x) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const uint64_t x = v[i], y = v[l];
+                    const bool desc = (i & k) == 0;
+                    if (desc ? (x < y) : (x > y)) { v[i] = y; v[l] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// Fast path, one pass over the score row.  The columns are in popularity order and RM2 scores grow with the
+// popularity of the candidate, so the K-th best of the first TOPN_SAMPLE columns is a tight LOWER bound tau of the
+// true K-th best: sort the sample in LDS, keep its top K, then stream the rest of the row (16-byte loads) and keep
+// only scores >= tau.  Every member of the true top K is among the kept ones (a member of the overall top K is in the
+// top K of any subset that contains it), so an exact sort of the kept set gives the exact list, ties broken by
+// ascending raw item id.  If more than TOPN_MAX entries survive (massive ties, e.g. a row of -inf) the user is
+// flagged and k_topn_select below redoes it with a radix select.
+__global__ __launch_bounds__(256) void k_topn_fast(TopNArgs A, int32_t* __restrict__ overflow, int32_t* __restrict__ any_overflow,
+                                                   int force_select) {
+    __shared__ uint64_t cand[TOPN_MAX];
+    __shared__ uint32_t sh_count, sh_nvalid;
+    const int u = blockIdx.x;
+    const int slot = A.slot0 + u;
+    const int K = A.n_out[slot - A.slot_lo];
+    if (threadIdx.x == 0) overflow[u] = 0;
+    if (A.mode == 2 && A.n_quads[u] == 0) return;         // the seed phase already wrote this user's final list
+    if (K == 0) {
+        if (A.mode == 1 && threadIdx.x == 0) A.tau[u] = INFINITY;   // nothing to emit: every block may be skipped
+        return;
+    }
+    if (force_select && A.mode != 1) {   // test hook (FY_TOPN_FORCE_SELECT=1): exercise the radix-select path for every user
+        if (threadIdx.x == 0) { overflow[u] = 1; atomicAdd(any_overflow, 1); }
+        return;
+    }
+    const float* __restrict__ row = A.S + (int64_t)u * A.ldS;
+    const int tid = threadIdx.x;
+    const int Ls = min(A.Ic, A.mode ? min(A.seed_cols, TOPN_SAMPLE) : TOPN_SAMPLE);
+    if (tid == 0) sh_nvalid = 0;
+    __syncthreads();
+    int myvalid = 0;
+    int LP2 = 64;                      // sort only as much as the sample needs
+    while (LP2 < Ls) LP2 <<= 1;
+    for (int i = tid; i < LP2; i += blockDim.x) {
+        uint64_t c = 0ull;
+        if (i < Ls) {
+            const float f = row[i];
+            if (f == f) { c = ((uint64_t)fy_order_key(f) << 32) | (uint32_t)(0x7FFFFFFF - A.rank_item_raw[i]); myvalid++; }
+        }
+        cand[i] = c;
+    }
+    if (myvalid) atomicAdd(&sh_nvalid, (uint32_t)myvalid);
+    __syncthreads();
+    fy_bitonic_desc(cand, LP2);
+    const int nvalid = (int)sh_nvalid;
+    const uint32_t tau = nvalid >= K ? (uint32_t)(cand[K - 1] >> 32) : 0u;   // valid keys are > 0
+    const int keep = min(K, nvalid);
+    if (A.mode == 1) {
+        // seed phase: tau for the bound pass, and the list that stands unless a block survives (almost always)
+        if (tid == 0) A.tau[u] = nvalid >= K ? fy_order_unkey(tau) : -INFINITY;
+        const int off1 = A.out_off[slot - A.slot_lo];
+        const int user1 = A.uid[A.slot2du[slot]];
+        for (int i = tid; i < keep; i += blockDim.x) {
+            const uint64_t c = cand[i];
+            A.out_user[off1 + i] = user1;
+            A.out_item[off1 + i] = 0x7FFFFFFF - (int32_t)(uint32_t)c;
+            A.out_score[off1 + i] = fy_order_unkey((uint32_t)(c >> 32));
+            A.out_cluster[off1 + i] = A.cluster;
+        }
+        return;
+    }
+    __syncthreads();
+    if (tid == 0) sh_count = (uint32_t)keep;
+    __syncthreads();
+    // stream the rest of the row (mode 2: only the surviving blocks, 16 float4 each)
+    const int i4_begin = A.mode == 2 ? 0 : (TOPN_SAMPLE >> 2);
+    const int i4_end = A.mode == 2 ? A.n_quads[u] * (PRUNE_BLOCK_COLS / 4) : (A.Ic + 3) >> 2;
+    for (int x = i4_begin + tid; x < i4_end; x += blockDim.x) {
+        int i4 = x;
+        const float* src = row + 4 * (int64_t)x;
+        if (A.mode == 2) {
+            const unsigned blk = A.surv[(int64_t)u * A.ldb + (x >> 6)];
+            i4 = (int)blk * (PRUNE_BLOCK_COLS / 4) + (x & 63);
+            src = A.Ssurv ? A.Ssurv + ((int64_t)(A.quad_prefix[u] + (x >> 6)) * PRUNE_BLOCK_COLS + 4 * (x & 63)) : row + 4 * (int64_t)i4;
+        }
+        const float4 f4 = *reinterpret_cast<const float4*>(src);
+        const float fv[4] = {f4.x, f4.y, f4.z, f4.w};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float f = fv[q];
+            const int i = 4 * i4 + q;
+            if (f == f && i < A.Ic) {
+                const uint32_t key = fy_order_key(f);
+                if (key >= tau) {
+                    const uint32_t pos = atomicAdd(&sh_count, 1u);
+                    if (pos < (uint32_t)TOPN_MAX) cand[pos] = ((uint64_t)key << 32) | (uint32_t)(0x7FFFFFFF - A.rank_item_raw[i]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int n = (int)sh_count;
+    if (n > TOPN_MAX) {   // block-uniform
+        if (tid == 0) { overflow[u] = 1; atomicAdd(any_overflow, 1); }
+        return;
+    }
+    int P2 = 1;
+    while (P2 < n) P2 <<= 1;
+    for (int i = n + tid; i < P2; i += blockDim.x) cand[i] = 0ull;
+    __syncthreads();
+    if (n > keep) fy_bitonic_desc(cand, P2);     // nothing survived beyond the sorted sample head: already in order
+    const int off = A.out_off[slot - A.slot_lo];
+    const int user_raw = A.uid[A.slot2du[slot]];
+    for (int i = tid; i < K; i += blockDim.x) {
+        const uint64_t c = cand[i];
+        A.out_user[off + i] = user_raw;
+        A.out_item[off + i] = 0x7FFFFFFF - (int32_t)(uint32_t)c;
+        A.out_score[off + i] = fy_order_unkey((uint32_t)(c >> 32));
+        A.out_cluster[off + i] = A.cluster;
+    }
+}
+
+
+// Fallback: exact radix select (three histogram passes + collect).  Runs only for users k_topn_fast flagged.
+__global__ __launch_bounds__(256) void k_topn_select(TopNArgs A, const int32_t* __restrict__ overflow,
+                                                     const int32_t* __restrict__ any_overflow) {
+    __shared__ uint32_t hist[TOPN_BINS];
+    __shared__ uint64_t cand[TOPN_MAX];
+    __shared__ uint32_t sh_prefix, sh_need, sh_count, sh_eq_taken;
+    if (*any_overflow == 0) return;
+    const int u = blockIdx.x;
+    if (overflow[u] == 0) return;
+    const int slot = A.slot0 + u;
+    const int K = A.n_out[slot - A.slot_lo];
+    if (K == 0) return;
+    const float* __restrict__ row = A.S + (int64_t)u * A.ldS;
+    const int tid = threadIdx.x;
+    // pruned rows: only the seed columns and the surviving 64-column blocks were ever written
+    __shared__ uint32_t live[2048];
+    __shared__ uint16_t live_pre[2048];   // cooperative ranks: surviving blocks in front of word w (position in the packed scores)
+    if (A.mode) {
+        for (int w = tid; w < 2048; w += blockDim.x) live[w] = 0;
+        __syncthreads();
+        for (int k = tid; k < A.n_quads[u]; k += blockDim.x) {
+            const unsigned blk = A.surv[(int64_t)u * A.ldb + k];
+            atomicOr(&live[blk >> 5], 1u << (blk & 31u));
+        }
+        __syncthreads();
+        if (A.Ssurv && tid == 0) {
+            unsigned run = 0;
+            for (int w = 0; w < 2048; w++) { live_pre[w] = (uint16_t)run; run += __popc(live[w]); }
+        }
+        __syncthreads();
+    }
+    const float* __restrict__ packed = (A.mode && A.Ssurv) ? A.Ssurv + (int64_t)A.quad_prefix[u] * PRUNE_BLOCK_COLS : nullptr;
+    auto rowval = [&](int i) -> float {
+        if (A.mode == 0 || i < A.seed_cols) return row[i];
+        const unsigned blk = (unsigned)i >> 8, w = blk >> 5, bit = blk & 31u;
+        if (!((live[w] >> bit) & 1u)) return __builtin_nanf("");
+        if (!packed) return row[i];
+        const unsigned pos = live_pre[w] + __popc(live[w] & ((1u << bit) - 1u));
+        return packed[(int64_t)pos * PRUNE_BLOCK_COLS + (i & 255)];
+    };
+#define FY_ROWVAL(i) rowval(i)
+
+    // ---- radix select: 12 + 10 + 10 bits, most significant first
+    uint32_t prefix = 0, prefix_mask = 0, need = (uint32_t)K;
+    const int shifts[3] = {20, 10, 0};
+    const int widths[3] = {12, 10, 10};
+    for (int pass = 0; pass < 3; pass++) {
+        const int nb = 1 << widths[pass];
+        for (int b = tid; b < nb; b += blockDim.x) hist[b] = 0;
+        __syncthreads();
+        for (int i = tid; i < A.Ic; i += blockDim.x) {
+            const float f = FY_ROWVAL(i);
+            if (f != f) continue;
+            const uint32_t key = fy_order_key(f);
+            if ((key & prefix_mask) == prefix) atomicAdd(&hist[(key >> shifts[pass]) & (nb - 1)], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t cum = 0;
+            int b = nb - 1;
+            for (; b > 0; b--) {
+                if (cum + hist[b] >= need) break;
+                cum += hist[b];
+            }
+            sh_prefix = prefix | ((uint32_t)b << shifts[pass]);
+            sh_need = need - cum;
+        }
+        __syncthreads();
+        prefix = sh_prefix;
+        need = sh_need;
+        prefix_mask |= (uint32_t)(nb - 1) << shifts[pass];
+        __syncthreads();
+    }
+    const uint32_t T = prefix;      // key of the K-th largest candidate; `need` of the entries equal to T are taken
+    // after the last pass hist[] counts exact keys: how many candidates tie with the K-th value
+    const uint32_t eq_total = hist[T & 1023u];
+    const bool take_all_eq = (eq_total == need);   // block-uniform; the common case (no tie across the cut-off)
+    __syncthreads();
+
+    // ---- collect everything above T (and the ties when all of them fit); order is fixed by the sort below
+    if (tid == 0) { sh_count = 0; sh_eq_taken = 0; }
+    __syncthreads();
+    for (int i = tid; i < A.Ic; i += blockDim.x) {
+        const float f = FY_ROWVAL(i);
+        if (f != f) continue;
+        const uint32_t key = fy_order_key(f);
+        if (key > T || (take_all_eq && key == T)) {
+            const uint32_t pos = atomicAdd(&sh_count, 1u);
+            if (pos < (uint32_t)TOPN_MAX) cand[pos] = ((uint64_t)key << 32) | (uint32_t)(0x7FFFFFFF - A.rank_item_raw[i]);
+        }
+    }
+    __syncthreads();
+    if (!take_all_eq) {
+        // a tie straddles the cut-off: take the first `need` tied entries in index (popularity-rank) order.
+        // Block-uniform loop: every thread reaches every barrier.
+        uint32_t* wave_cnt = hist;   // reuse
+        const int w = tid >> 6, ln = tid & 63, nw = blockDim.x >> 6;
+        for (int base = 0; base < A.Ic; base += blockDim.x) {
+            const int i = base + tid;
+            bool eq = false;
+            if (i < A.Ic) {
+                const float f = FY_ROWVAL(i);
+                eq = (f == f) && fy_order_key(f) == T;
+            }
+            const unsigned long long bal = __ballot(eq);
+            if (ln == 0) wave_cnt[w] = (uint32_t)__popcll(bal);
+            __syncthreads();
+            uint32_t off = sh_eq_taken, all = 0;
+            for (int x = 0; x < nw; x++) {
+                if (x < w) off += wave_cnt[x];
+                all += wave_cnt[x];
+            }
+            off += (uint32_t)__popcll(bal & ((1ull << ln) - 1ull));
+            if (eq && off < need) {
+                const uint32_t pos = atomicAdd(&sh_count, 1u);
+                if (pos < (uint32_t)TOPN_MAX) cand[pos] = ((uint64_t)T << 32) | (uint32_t)(0x7FFFFFFF - A.rank_item_raw[i]);
+            }
+            __syncthreads();
+            if (tid == 0) sh_eq_taken += all;
+            __syncthreads();
+            if (sh_eq_taken >= need) break;   // uniform: read after the barrier
+        }
+        __syncthreads();
+    }
+    const int n = min((int)sh_count, K);     // == K
+    int P2 = 1;
+    while (P2 < n) P2 <<= 1;
+    for (int i = n + tid; i < P2; i += blockDim.x) cand[i] = 0ull;
+    __syncthreads();
+    // ---- bitonic sort, descending on (score key, ~item)
+    for (int k = 2; k <= P2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < P2; i += blockDim.x) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const uint64_t x = cand[i], y = cand[l];
+                    const bool desc = (i & k) == 0;
+                    if (desc ? (x < y) : (x > y)) { cand[i] = y; cand[l] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const int off = A.out_off[slot - A.slot_lo];
+    const int user_raw = A.uid[A.slot2du[slot]];
+    for (int i = tid; i < n; i += blockDim.x) {
+        const uint64_t c = cand[i];
+        A.out_user[off + i] = user_raw;
+        A.out_item[off + i] = 0x7FFFFFFF - (int32_t)(uint32_t)c;
+        A.out_score[off + i] = fy_order_unkey((uint32_t)(c >> 32));   // already the (float) cast of RM2HDFSReducer.java:48
+        A.out_cluster[off + i] = A.cluster;
+    }
+}
+
+// ================================================================ exact pruning of candidate blocks (branch and bound)
+// For a block B of 64 candidate columns,
+//     UB(u, B) = pvpi + sum_{j in rated(u)} ln( max_{i in B} M[j][i] + (max_{i in B} a_i) * e_uj )  >=  score(u, i)  for all i in B,
+// because every term is monotone in M[j][i] and a_i.  Evaluating UB is the scoring kernel itself run on the reduced
+// matrix Bmax[j][B] (1/64 of the columns).  With tau_u = the N-th best EXACT score among the first `seed` (most
+// popular) columns, a block whose UB is below tau_u cannot contribute to the user's top N and is skipped; the exact
+// kernel then runs only on the surviving (user, block) pairs.  RM2 scores fall steeply with candidate popularity, so on
+// MovieLens-shaped data well under 1 % of the tail blocks survive -- the lists are bit-for-bit those of the full pass.
+constexpr int PRUNE_BLOCK = 256;   // = the column chunk of the scoring kernel: a surviving block is one (user, chunk) work item
+
+// block maxima of a = lambda * p
+__global__ void k_block_amax(int32_t Ic, int32_t ldb, const float* __restrict__ a_rank, float* __restrict__ amax) {
+    for (int32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < ldb; b += gridDim.x * blockDim.x) {
+        float m = 0.0f;
+        for (int i = b * PRUNE_BLOCK; i < min(Ic, (b + 1) * PRUNE_BLOCK); i++) m = fmaxf(m, a_rank[i]);
+        amax[b] = m;
+    }
+}
+
+// exact scores of the surviving blocks: one wave = one (user, surviving 256-column block), the scoring kernel's work item
+template <int SB>
+__global__ __launch_bounds__(256) void k_score_blocks(const float* __restrict__ M_, const float* __restrict__ a_rank_,
+                                                      const int32_t* __restrict__ rowptr_, const int32_t* __restrict__ csr_idx_,
+                                                      const float* __restrict__ csr_e_, const double* __restrict__ pvpi_,
+                                                      const int32_t* __restrict__ surv_prefix_, const uint16_t* __restrict__ surv_,
+                                                      float* __restrict__ S_, ScoreArgs A, int64_t ldb,
+                                                      unsigned long long* __restrict__ counters) {
+    const int lane = threadIdx.x & 63;
+    const int wave_in_grid = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    const int n_waves = gridDim.x * (blockDim.x >> 6);
+    const int total = surv_prefix_[A.n_users];
+    const int64_t pitch = A.ldm * 3;
+    const double LN2 = 0.69314718055994530942;
+    const float qnan = __builtin_nanf("");
+    unsigned long long my_terms = 0;
+    if (wave_in_grid == 0 && lane == 0 && total) atomicAdd(&counters[0], (unsigned long long)total);
+    for (int w = wave_in_grid; w < total; w += n_waves) {
+        int lo = 0, hi = A.n_users;                 // last user with surv_prefix <= w
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (surv_prefix_[mid] <= w) lo = mid; else hi = mid;
+        }
+        const int u = lo;
+        const int slot = A.slot0 + u;
+        const int col0 = (int)surv_[(int64_t)u * ldb + (w - surv_prefix_[u])] * PRUNE_BLOCK;
+        const int col = col0 + lane * 4;
+        float a[4];
+#pragma unroll
+        for (int v = 0; v < 4; v++) a[v] = col + v < A.Ic ? a_rank_[col + v] : 0.0f;
+        const char* __restrict__ Mcol = reinterpret_cast<const char*>(M_) + (int64_t)col * 3;
+        const int beg = rowptr_[slot], end = rowptr_[slot + 1];
+        double t[4] = {0.0, 0.0, 0.0, 0.0};
+        unsigned mask = 0;
+        for (int k = beg; k < end; k += SB) {
+            U3 g[SB];
+            float e[SB];
+            int jj[SB];
+#pragma unroll
+            for (int x = 0; x < SB; x++) {
+                const int kk = min(k + x, end - 1);
+                jj[x] = csr_idx_[kk];
+                e[x] = csr_e_[kk];
+                g[x] = *reinterpret_cast<const U3*>(Mcol + (int64_t)jj[x] * pitch);
+            }
+            float p[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int x = 0; x < SB; x++) {
+                if (k + x < end) {
+                    float gv[4];
+                    fy_unpack24(g[x], gv);
+#pragma unroll
+                    for (int v = 0; v < 4; v++) p[v] += fy_log2(fmaf(a[v], e[x], gv[v]));
+                    const unsigned d = (unsigned)(jj[x] - col);
+                    if (d < 4u) mask |= 1u << d;
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < 4; v++) t[v] += (double)p[v];
+        }
+        const double base = pvpi_[slot - A.slot_lo];
+        float4 o;
+        o.x = ((mask & 1u) || col + 0 >= A.Ic) ? qnan : (float)(base + LN2 * t[0]);
+        o.y = ((mask & 2u) || col + 1 >= A.Ic) ? qnan : (float)(base + LN2 * t[1]);
+        o.z = ((mask & 4u) || col + 2 >= A.Ic) ? qnan : (float)(base + LN2 * t[2]);
+        o.w = ((mask & 8u) || col + 3 >= A.Ic) ? qnan : (float)(base + LN2 * t[3]);
+        *reinterpret_cast<float4*>(S_ + (int64_t)u * A.ldS + col) = o;
+        my_terms += (unsigned long long)(end - beg) * 256ull;
+    }
+    if (lane == 0 && my_terms) atomicAdd(&counters[1], my_terms);
+}
+
+// ================================================================ cooperative ranks (fy_collectives): kernels
+// A cooperative rank owns the item rows  me, me + world, me + 2 world, ...  (rows are in popularity order, so every rank
+// gets the same mix of heavy and light rows -- no work model needed).  Its view of the users is a compact CSR that keeps only
+// the rated items falling into its rows, renumbered to the LOCAL row index (idx / world): one wave per user, ballot
+// compaction, order preserved.
+__global__ void k_my_csr_count(int32_t n_slots, int32_t slot_base, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ csr_idx,
+                               int32_t world, int32_t me, int32_t* __restrict__ cnt) {
+    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    for (int32_t v = blockIdx.x * wpb + (threadIdx.x >> 6); v <= n_slots; v += gridDim.x * wpb) {
+        int c = 0;
+        if (v < n_slots)
+            for (int32_t f = rowptr[slot_base + v] + lane; f < rowptr[slot_base + v + 1]; f += 64) c += (csr_idx[f] % world) == me;
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+        if (lane == 0) cnt[v] = c;     // cnt[n_slots] = 0: the exclusive scan's last element is the total
+    }
+}
+__global__ void k_my_csr_fill(int32_t n_slots, int32_t slot_base, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ csr_idx,
+                              const float* __restrict__ csr_e, int32_t world, int32_t me, const int32_t* __restrict__ my_rowptr,
+                              int32_t* __restrict__ my_idx, float* __restrict__ my_e) {
+    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    for (int32_t v = blockIdx.x * wpb + (threadIdx.x >> 6); v < n_slots; v += gridDim.x * wpb) {
+        int at = my_rowptr[v];
+        const int32_t a = rowptr[slot_base + v], b = rowptr[slot_base + v + 1];
+        for (int32_t f0 = a; f0 < b; f0 += 64) {
+            const int32_t f = f0 + lane;
+            const int32_t j = f < b ? csr_idx[f] : -1;
+            const bool mine = j >= 0 && (j % world) == me;
+            const unsigned long long bal = __ballot(mine);
+            if (mine) {
+                const int k = at + __popcll(bal & ((1ull << lane) - 1ull));
+                my_idx[k] = j / world;
+                my_e[k] = csr_e[f];
+            }
+            at += __popcll(bal);
+        }
+    }
+}
+
+// CSC entries (rater slot, weight) of item rows r0, r0 + stride, ... (nrows of them), row by row: the compact CSC a cooperative rank builds its
+// segment table from
+__global__ void k_gather_rows(int32_t r0, int32_t stride, int32_t nrows, const int32_t* __restrict__ rank_pair, const int32_t* __restrict__ pair_start,
+                              const int32_t* __restrict__ local_start, const int32_t* __restrict__ csc_slot,
+                              const float* __restrict__ csc_w, int32_t* __restrict__ my_slot, float* __restrict__ my_w) {
+    const int lane = threadIdx.x & 63;
+    const int wpb = blockDim.x >> 6;
+    for (int32_t i = blockIdx.x * wpb + (threadIdx.x >> 6); i < nrows; i += gridDim.x * wpb) {
+        const int32_t pr = rank_pair[r0 + i * stride];
+        const int32_t q0 = pair_start[pr], n = pair_start[pr + 1] - q0, l0 = local_start[i];
+        for (int32_t k = lane; k < n; k += 64) { my_slot[l0 + k] = csc_slot[q0 + k]; my_w[l0 + k] = csc_w[q0 + k]; }
+    }
+}
+
+// owner of the user: blocks behind the seed whose (summed) bound reaches tau_u, in ascending block order
+__global__ __launch_bounds__(256) void k_bound_select(const float* __restrict__ UB, int64_t ldb, int32_t nblk, int32_t seed_blocks,
+                                                      const float* __restrict__ tau, int32_t n_users, uint16_t* __restrict__ surv,
+                                                      int32_t* __restrict__ n_surv) {
+    const int lane = threadIdx.x & 63;
+    const int wpb = blockDim.x >> 6;
+    for (int u = blockIdx.x * wpb + (threadIdx.x >> 6); u < n_users; u += gridDim.x * wpb) {
+        const float t = tau[u];
+        int count = 0;
+        for (int b0 = 0; b0 < nblk; b0 += 64) {
+            const int b = b0 + lane;
+            const bool keep = b < nblk && b >= seed_blocks && fy_bound_keeps(UB[(int64_t)u * ldb + b], t);
+            const unsigned long long bal = __ballot(keep);
+            if (keep) surv[(int64_t)u * ldb + count + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)b;
+            count += __popcll(bal);
+        }
+        if (lane == 0) n_surv[u] = count;
+    }
+}
+
+// (slot, block) of every surviving block of this rank's users, packed for the all-gather
+__global__ void k_surv_entries(int32_t n_users, int32_t slot0, const int32_t* __restrict__ prefix, const uint16_t* __restrict__ surv,
+                               int64_t ldb, long long* __restrict__ entries) {
+    const int lane = threadIdx.x & 63;
+    const int wpb = blockDim.x >> 6;
+    for (int u = blockIdx.x * wpb + (threadIdx.x >> 6); u < n_users; u += gridDim.x * wpb) {
+        const int a = prefix[u], n = prefix[u + 1] - a;
+        for (int k = lane; k < n; k += 64)
+            entries[a + k] = ((long long)(slot0 + u) << 16) | (long long)surv[(int64_t)u * ldb + k];
+    }
+}
+
+// partial exact scores of the surviving blocks of ALL ranks over this rank's item rows: one wave = one entry,
+// 256 floats at Spart[w * 256]; entry w = k * t_max + i belongs to rank k and exists when i < counts[k]
+template <int SB>
+__global__ __launch_bounds__(256) void k_score_entries(const float* __restrict__ M_, const float* __restrict__ a_rank_,
+                                                       const int32_t* __restrict__ range_off_, const int32_t* __restrict__ csr_idx_,
+                                                       const float* __restrict__ csr_e_, const double* __restrict__ pvpi_,
+                                                       const long long* __restrict__ entries_, const int32_t* __restrict__ counts_,
+                                                       int32_t world, int32_t t_max, int32_t slot_base, int32_t Ic, int64_t ldm,
+                                                       int32_t row_mul, int32_t row_add, float* __restrict__ Spart_,
+                                                       unsigned long long* __restrict__ counters) {
+    const int lane = threadIdx.x & 63;
+    const int wave_in_grid = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    const int n_waves = gridDim.x * (blockDim.x >> 6);
+    const int total = world * t_max;
+    const int64_t pitch = ldm * 3;
+    const double LN2 = 0.69314718055994530942;
+    const float qnan = __builtin_nanf("");
+    unsigned long long my_terms = 0;
+    for (int w = wave_in_grid; w < total; w += n_waves) {
+        const int k = w / t_max;
+        if (w - k * t_max >= counts_[k]) continue;
+        const long long en = entries_[w];
+        const int slot = (int)(en >> 16);
+        const int col0 = (int)(en & 0xFFFF) * PRUNE_BLOCK;
+        const int col = col0 + lane * 4;
+        float a[4];
+#pragma unroll
+        for (int v = 0; v < 4; v++) a[v] = col + v < Ic ? a_rank_[col + v] : 0.0f;
+        const char* __restrict__ Mcol = reinterpret_cast<const char*>(M_) + (int64_t)col * 3;
+        const int beg = range_off_[slot - slot_base], end = range_off_[slot - slot_base + 1];
+        double t[4] = {0.0, 0.0, 0.0, 0.0};
+        unsigned mask = 0;
+        for (int kk0 = beg; kk0 < end; kk0 += SB) {
+            U3 g[SB];
+            float e[SB];
+            int jj[SB];
+#pragma unroll
+            for (int x = 0; x < SB; x++) {
+                const int kk = min(kk0 + x, end - 1);
+                jj[x] = csr_idx_[kk];
+                e[x] = csr_e_[kk];
+                g[x] = *reinterpret_cast<const U3*>(Mcol + (int64_t)jj[x] * pitch);
+            }
+            float p[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int x = 0; x < SB; x++) {
+                if (kk0 + x < end) {
+                    float gv[4];
+                    fy_unpack24(g[x], gv);
+#pragma unroll
+                    for (int v = 0; v < 4; v++) p[v] += fy_log2(fmaf(a[v], e[x], gv[v]));
+                    const unsigned d = (unsigned)(jj[x] * row_mul + row_add - col);
+                    if (d < 4u) mask |= 1u << d;
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < 4; v++) t[v] += (double)p[v];
+        }
+        const double base = pvpi_[slot - slot_base];
+        float4 o;
+        o.x = ((mask & 1u) || col + 0 >= Ic) ? qnan : (float)(base + LN2 * t[0]);
+        o.y = ((mask & 2u) || col + 1 >= Ic) ? qnan : (float)(base + LN2 * t[1]);
+        o.z = ((mask & 4u) || col + 2 >= Ic) ? qnan : (float)(base + LN2 * t[2]);
+        o.w = ((mask & 8u) || col + 3 >= Ic) ? qnan : (float)(base + LN2 * t[3]);
+        *reinterpret_cast<float4*>(Spart_ + (int64_t)w * PRUNE_BLOCK + lane * 4) = o;
+        my_terms += (unsigned long long)(end - beg) * 256ull;
+    }
+    if (lane == 0 && my_terms) atomicAdd(&counters[1], my_terms);
+}
+

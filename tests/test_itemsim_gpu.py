@@ -67,6 +67,20 @@ def test_synthetic(ctx, shape, K):
     check(res.rows(), ref, K)
 
 
+@pytest.mark.parametrize("env", [{"FY_COOC_MAX_CH": "256", "FY_ISIM_HEAVY": "8"},      # column chunks, heavy rows split by chunk + merge
+                                 {"FY_COOC_MAX_CH": "256", "FY_ISIM_HEAVY": "1000000"},  # column chunks, threshold carried along
+                                 {"FY_COOC_PK": "0"}])                                   # 8-byte CSR entries, weights pre-divided
+def test_synthetic_forced_paths(ctx, monkeypatch, env):
+    """the paths that production sizes switch on (several column chunks, split rows) and off (unpacked CSR), on ML-100K shape"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    u, i, s, _ = synth().generate("ml100k")
+    u, i, s = u.numpy(), i.numpy(), s.numpy()
+    res = pkg().RowSimilarityJob(ctx).run((u, i, s), maxSimilaritiesPerRow=30)
+    ref = oracle.itemsim(u, i, s, max_similarities_per_item=1 << 30, n_threads=8)
+    check(res.rows(), ref, 30)
+
+
 def test_item_row_shards_partition_the_result(ctx):
     u, i, s, _ = synth().generate("tiny")
     u, i, s = u.numpy(), i.numpy(), s.numpy()

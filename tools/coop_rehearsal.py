@@ -133,6 +133,19 @@ def main():
             sb = set(zip(single_rows["user"].tolist(), single_rows["item"].tolist()))
             res["pairs_only_in_sharded"] = len(sa - sb)
             res["pairs_only_in_single"] = len(sb - sa)
+            # every such pair must sit AT its user's cut-off: its score equals the other run's last kept score within rounding
+            def cutoffs(r, users):
+                out = {}
+                for uu in users:
+                    m = r["user"] == uu
+                    out[uu] = float(r["score"][m].min())
+                return out
+            users = sorted({p[0] for p in (sa - sb) | (sb - sa)})
+            cs, cm = cutoffs(single_rows, users), cutoffs(rows, users)
+            score_of = lambda r, pr: float(r["score"][(r["user"] == pr[0]) & (r["item"] == pr[1])][0])
+            gaps = [abs(score_of(rows, pr) - cs[pr[0]]) / abs(cs[pr[0]]) for pr in sa - sb] + \
+                   [abs(score_of(single_rows, pr) - cm[pr[0]]) / abs(cm[pr[0]]) for pr in sb - sa]
+            res["max_rel_gap_of_swapped_pairs_to_cutoff"] = max(gaps) if gaps else 0.0
     print(json.dumps(res))
 
 
