@@ -770,6 +770,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             DevBuf<uint16_t> surv;
             DevBuf<int32_t> n_quads, quad_prefix;
             DevBuf<int2> item_seg;
+            DevBuf<float> Ssurv;   // packed scores of the surviving blocks (pruned clusters)
         };
         std::vector<Lane> lanes((size_t)NS);
         {
@@ -778,9 +779,13 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             size_t m_el = 1, s_el = 1, co_el = 1, rb_el = 1, ho_el = 1, ov_el = 1, sl_el = 1, bm_el = 1, ub_el = 1, am_el = 1;
             for (auto& p : plans) {
                 p.B = std::min<int64_t>(std::max<int64_t>(1, (ws / NS) / (p.ldm * 4)), p.b - p.a);
+                // pruned clusters keep only the seed columns of a score row (the survivors' scores are packed, see below):
+                // all users of the rank in one batch
+                const int64_t seed_cols = (int64_t)std::min<int64_t>(ceil_div(p.Ic, 256), tune.seed_chunks) * 256;
+                if (p.prune) p.B = p.b - p.a;
                 if (p.coop) continue;   // allocates for itself
                 m_el = std::max(m_el, (size_t)(p.Ic * p.ldm));
-                s_el = std::max(s_el, (size_t)(p.B * p.ldm));
+                s_el = std::max(s_el, (size_t)(p.B * (p.prune ? seed_cols : p.ldm)));
                 co_el = std::max(co_el, (size_t)p.Uc * (p.nch + 1));
                 rb_el = std::max(rb_el, (size_t)p.Uc * (p.nrb + 1));
                 if (p.use_hot) ho_el = std::max(ho_el, (size_t)p.Uc * 3);
@@ -922,14 +927,15 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 if (p.prune) {
                     const int seed_chunks = std::min(n_chunks, tune.seed_chunks);
                     const int seed_blocks = seed_chunks;
+                    const int64_t SC = (int64_t)seed_chunks * 256;   // pitch of the compact score rows: seed columns only
                     // only the seed columns and the surviving blocks of a score row are ever written or read
                     // (1) exact scores of the seed columns (the most popular candidates)
                     ScoreArgs SA{L.M.get(), ldm, Ic, a_rank.get() + pbase, L.rb_off.get(), P.csr_idx.get(), csr_e.get(), pvpi.get(),
-                                 n_out.get(), lo, sbase, s0, nb, L.S.get(), ldS, n_slices, 0, 1, 0, 0, seed_chunks, 0, nullptr, nullptr, nullptr, 0};
+                                 n_out.get(), lo, sbase, s0, nb, L.S.get(), SC, n_slices, 0, 1, 0, 0, seed_chunks, 0, nullptr, nullptr, nullptr, 0};
                     k_score<4, true, 8><<<seed_chunks * n_slices, 256, 0, ls>>>(SA.M, SA.a_rank, SA.rb_off, SA.csr_idx, SA.csr_e, SA.pvpi, SA.n_out, SA.S, SA);
                     FY_KERNEL_CHECK();
                     // (2) tau_u = N-th best seed score; the sorted seed head is also the user's list unless a block survives
-                    TopNArgs T1{L.S.get(), ldS, Ic, n_out.get(), out_off.get(), P.rank_item_raw.get() + pbase, P.slot2du.get(), P.uid.get(),
+                    TopNArgs T1{L.S.get(), SC, Ic, n_out.get(), out_off.get(), P.rank_item_raw.get() + pbase, P.slot2du.get(), P.uid.get(),
                                 lo, s0, c, R->d_key0.get(), R->d_key1.get(), R->d_value.get(), R->d_aux.get(),
                                 1, seed_chunks * 256, L.surv.get(), L.n_quads.get(), p.ldb, L.tau.get()};
                     k_topn_fast<<<nb, 256, 0, ls>>>(T1, L.overflow.get(), L.any_overflow.get(), 0);
@@ -944,12 +950,18 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                     FY_KERNEL_CHECK();
                     // (4) the bound pass appended the surviving blocks to surv / n_quads itself
                     exclusive_scan_i32(ctx, L.n_quads.get(), L.quad_prefix.get(), (size_t)nb + 1, ls);
-                    // (5) exact scores of the survivors
-                    ScoreArgs SQ{L.M.get(), ldm, Ic, a_rank.get() + pbase, L.rb_off.get(), P.csr_idx.get(), csr_e.get(), pvpi.get(),
-                                 n_out.get(), lo, sbase, s0, nb, L.S.get(), ldS, n_slices, 0, 1, 0, 0, n_chunks, 0, nullptr, nullptr, nullptr, 0};
-                    k_score_blocks<8><<<ctx->num_cus * 8, 256, 0, ls>>>(SQ.M, SQ.a_rank, P.rowptr.get(), SQ.csr_idx, SQ.csr_e, SQ.pvpi,
-                                                                        L.quad_prefix.get(), L.surv.get(), SQ.S, SQ, p.ldb, prune_counters.get());
-                    FY_KERNEL_CHECK();
+                    // (5) exact scores of the survivors, packed: 256 floats per surviving block at entry quad_prefix[u] + k
+                    int32_t n_surv_total = 0;
+                    FY_HIP(hipMemcpyAsync(&n_surv_total, L.quad_prefix.get() + nb, sizeof(int32_t), hipMemcpyDeviceToHost, ls));
+                    FY_HIP(hipStreamSynchronize(ls));   // (everything queued on this lane before has finished: Ssurv may be re-sized)
+                    L.Ssurv.alloc(ctx, (size_t)std::max(1, n_surv_total) * PRUNE_BLOCK);
+                    if (n_surv_total > 0) {
+                        ScoreArgs SQ{L.M.get(), ldm, Ic, a_rank.get() + pbase, L.rb_off.get(), P.csr_idx.get(), csr_e.get(), pvpi.get(),
+                                     n_out.get(), lo, sbase, s0, nb, L.Ssurv.get(), 0, n_slices, 0, 1, 0, 0, n_chunks, 0, nullptr, nullptr, nullptr, 0};
+                        k_score_blocks<8><<<ctx->num_cus * 8, 256, 0, ls>>>(SQ.M, SQ.a_rank, P.rowptr.get(), SQ.csr_idx, SQ.csr_e, SQ.pvpi,
+                                                                            L.quad_prefix.get(), L.surv.get(), SQ.S, SQ, p.ldb, prune_counters.get());
+                        FY_KERNEL_CHECK();
+                    }
                     R->st.score_launches += 3;
                     prune_blocks_total += (int64_t)nb * std::max(0, p.nblk - seed_blocks);
                     {   // log terms of the seed and bound passes of this batch: (ratings of its users) x (columns walked)
@@ -974,10 +986,11 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                     R->st.score_launches++;
                 }
                 t_score.end(ss, ls);
-                TopNArgs TA{L.S.get(), ldS, Ic, n_out.get(), out_off.get(), P.rank_item_raw.get() + pbase, P.slot2du.get(), P.uid.get(),
-                            lo, s0, c, R->d_key0.get(), R->d_key1.get(), R->d_value.get(), R->d_aux.get(),
-                            p.prune ? 2 : 0, p.prune ? std::min(n_chunks, tune.seed_chunks) * 256 : 0, L.surv.get(), L.n_quads.get(), p.ldb,
-                            L.tau.get()};
+                const int32_t seed_cols_p = p.prune ? std::min(n_chunks, tune.seed_chunks) * 256 : 0;
+                TopNArgs TA{L.S.get(), p.prune ? (int64_t)seed_cols_p : ldS, Ic, n_out.get(), out_off.get(), P.rank_item_raw.get() + pbase,
+                            P.slot2du.get(), P.uid.get(), lo, s0, c, R->d_key0.get(), R->d_key1.get(), R->d_value.get(), R->d_aux.get(),
+                            p.prune ? 2 : 0, seed_cols_p, L.surv.get(), L.n_quads.get(), p.ldb, L.tau.get(),
+                            p.prune ? L.Ssurv.get() : nullptr, p.prune ? L.quad_prefix.get() : nullptr};
                 const size_t tt = t_topn.begin(ls);
                 FY_HIP(hipMemsetAsync(L.any_overflow.get(), 0, sizeof(int32_t), ls));
                 k_topn_fast<<<nb, 256, 0, ls>>>(TA, L.overflow.get(), L.any_overflow.get(), tune.force_select);

@@ -764,7 +764,8 @@ __global__ __launch_bounds__(256) void k_score_blocks(const float* __restrict__ 
         o.y = ((mask & 2u) || col + 1 >= A.Ic) ? qnan : (float)(base + LN2 * t[1]);
         o.z = ((mask & 4u) || col + 2 >= A.Ic) ? qnan : (float)(base + LN2 * t[2]);
         o.w = ((mask & 8u) || col + 3 >= A.Ic) ? qnan : (float)(base + LN2 * t[3]);
-        *reinterpret_cast<float4*>(S_ + (int64_t)u * A.ldS + col) = o;
+        // packed: entry w holds the block's 256 scores (the top-N kernels find them through quad_prefix)
+        *reinterpret_cast<float4*>(S_ + (int64_t)w * PRUNE_BLOCK + lane * 4) = o;
         my_terms += (unsigned long long)(end - beg) * 256ull;
     }
     if (lane == 0 && my_terms) atomicAdd(&counters[1], my_terms);
