@@ -477,7 +477,8 @@ struct ScoreTune {
     int lanes = 4;                     // HIP streams the clusters of one job are spread over
     int prune = 1;                     // branch and bound over 64-column candidate blocks
     int prune_min_items = 8192;
-    int seed_chunks = 2;               // 256-column chunks scored exactly before the bound pass (the most popular candidates)
+    int seed_chunks = 0;               // 256-column chunks scored exactly before the bound pass (the most popular candidates);
+                                       // 0 = from the list length: ~5 N columns (N = 50: one chunk, N = 100: two), at most four
     int cooc_debug = 0;                // timing experiments only
     int cooc_block = 0;                // test hook: force the row kernel's workgroup size
     int cooc_max_ch = 16384;           // LDS accumulators of the row kernel (test hook: smaller forces column chunks)
@@ -504,7 +505,7 @@ static ScoreTune score_tune() {
     if (const char* e = getenv("FY_COOP_FORCE")) t.coop_force = atoi(e) != 0;
     if (const char* e = getenv("FY_COOC_PK")) t.cooc_pk = atoi(e) != 0;
     if (const char* e = getenv("FY_PRUNE_MIN_ITEMS")) t.prune_min_items = atoi(e);
-    if (const char* e = getenv("FY_SEED_CHUNKS")) { int v = atoi(e); if (v >= 1 && v <= 4) t.seed_chunks = v; }
+    if (const char* e = getenv("FY_SEED_CHUNKS")) { int v = atoi(e); if (v >= 0 && v <= 4) t.seed_chunks = v; }
     if (const char* e = getenv("FY_WORKSPACE_GB")) { long v = atol(e); if (v >= 1) t.workspace_default = (int64_t)v << 30; }
     if (const char* e = getenv("FY_LANES")) { int v = atoi(e); if (v >= 1 && v <= 8) t.lanes = v; }
     if (const char* e = getenv("FY_COOC_DEBUG")) t.cooc_debug = atoi(e);
@@ -625,7 +626,10 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
     }
     const int32_t nU = P.nU, nP = P.nP, nI = P.nI, K = P.K;
     const double lambda = prm.lambda;
-    const ScoreTune tune = score_tune();
+    ScoreTune tune = score_tune();
+    // tau_u is the N-th best of the seed scores: a seed of only a few N columns gives a weak threshold and many survivors
+    // (Netflix shape, N = 100: 2.7 % of the blocks survive a 256-column seed, 0.1 % a 512-column one)
+    if (tune.seed_chunks == 0) tune.seed_chunks = (int)std::min<int64_t>(4, std::max<int64_t>(1, ceil_div(5 * (int64_t)prm.number_of_recommendations, 256)));
     const bool pack24_allowed = tune.pack24 && tune.vec == 4;
     int64_t coop_pair_contribs = 0;   // cooperative clusters: ordered off-diagonal co-rating pairs of this rank's matrix rows
     bool any_coop = false;
@@ -958,7 +962,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                     if (n_surv_total > 0) {
                         ScoreArgs SQ{L.M.get(), ldm, Ic, a_rank.get() + pbase, L.rb_off.get(), P.csr_idx.get(), csr_e.get(), pvpi.get(),
                                      n_out.get(), lo, sbase, s0, nb, L.Ssurv.get(), 0, n_slices, 0, 1, 0, 0, n_chunks, 0, nullptr, nullptr, nullptr, 0};
-                        k_score_blocks<8><<<ctx->num_cus * 8, 256, 0, ls>>>(SQ.M, SQ.a_rank, P.rowptr.get(), SQ.csr_idx, SQ.csr_e, SQ.pvpi,
+                        k_score_blocks<8><<<std::min(n_surv_total, ctx->num_cus * 16), 256, 0, ls>>>(SQ.M, SQ.a_rank, P.rowptr.get(), SQ.csr_idx, SQ.csr_e, SQ.pvpi,
                                                                             L.quad_prefix.get(), L.surv.get(), SQ.S, SQ, p.ldb, prune_counters.get());
                         FY_KERNEL_CHECK();
                     }

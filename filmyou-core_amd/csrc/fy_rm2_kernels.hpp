@@ -698,7 +698,9 @@ __global__ void k_block_amax(int32_t Ic, int32_t ldb, const float* __restrict__ 
     }
 }
 
-// exact scores of the surviving blocks: one wave = one (user, surviving 256-column block), the scoring kernel's work item
+// One WORKGROUP = one (user, surviving block): its four waves split the user's rated items into quarters and their partial
+// log-sums are added in wave order (fixed, so the result is reproducible).  Survivors belong to the heaviest users -- a
+// single wave walked thousands of rows in dependent batches of 8 and the pass ended on a handful of such waves.
 template <int SB>
 __global__ __launch_bounds__(256) void k_score_blocks(const float* __restrict__ M_, const float* __restrict__ a_rank_,
                                                       const int32_t* __restrict__ rowptr_, const int32_t* __restrict__ csr_idx_,
@@ -706,16 +708,17 @@ __global__ __launch_bounds__(256) void k_score_blocks(const float* __restrict__ 
                                                       const int32_t* __restrict__ surv_prefix_, const uint16_t* __restrict__ surv_,
                                                       float* __restrict__ S_, ScoreArgs A, int64_t ldb,
                                                       unsigned long long* __restrict__ counters) {
+    __shared__ double sh_t[3][64][4];
+    __shared__ unsigned sh_mask[3][64];
     const int lane = threadIdx.x & 63;
-    const int wave_in_grid = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
-    const int n_waves = gridDim.x * (blockDim.x >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int total = surv_prefix_[A.n_users];
     const int64_t pitch = A.ldm * 3;
     const double LN2 = 0.69314718055994530942;
     const float qnan = __builtin_nanf("");
     unsigned long long my_terms = 0;
-    if (wave_in_grid == 0 && lane == 0 && total) atomicAdd(&counters[0], (unsigned long long)total);
-    for (int w = wave_in_grid; w < total; w += n_waves) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && total) atomicAdd(&counters[0], (unsigned long long)total);
+    for (int w = blockIdx.x; w < total; w += gridDim.x) {
         int lo = 0, hi = A.n_users;                 // last user with surv_prefix <= w
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
@@ -729,7 +732,9 @@ __global__ __launch_bounds__(256) void k_score_blocks(const float* __restrict__ 
 #pragma unroll
         for (int v = 0; v < 4; v++) a[v] = col + v < A.Ic ? a_rank_[col + v] : 0.0f;
         const char* __restrict__ Mcol = reinterpret_cast<const char*>(M_) + (int64_t)col * 3;
-        const int beg = rowptr_[slot], end = rowptr_[slot + 1];
+        const int row_beg = rowptr_[slot], row_end = rowptr_[slot + 1];
+        const int quarter = (((row_end - row_beg + 3) >> 2) + SB - 1) / SB * SB;   // whole batches per wave
+        const int beg = min(row_end, row_beg + wave * quarter), end = min(row_end, beg + quarter);
         double t[4] = {0.0, 0.0, 0.0, 0.0};
         unsigned mask = 0;
         for (int k = beg; k < end; k += SB) {
@@ -758,17 +763,31 @@ __global__ __launch_bounds__(256) void k_score_blocks(const float* __restrict__ 
 #pragma unroll
             for (int v = 0; v < 4; v++) t[v] += (double)p[v];
         }
-        const double base = pvpi_[slot - A.slot_lo];
-        float4 o;
-        o.x = ((mask & 1u) || col + 0 >= A.Ic) ? qnan : (float)(base + LN2 * t[0]);
-        o.y = ((mask & 2u) || col + 1 >= A.Ic) ? qnan : (float)(base + LN2 * t[1]);
-        o.z = ((mask & 4u) || col + 2 >= A.Ic) ? qnan : (float)(base + LN2 * t[2]);
-        o.w = ((mask & 8u) || col + 3 >= A.Ic) ? qnan : (float)(base + LN2 * t[3]);
-        // packed: entry w holds the block's 256 scores (the top-N kernels find them through quad_prefix)
-        *reinterpret_cast<float4*>(S_ + (int64_t)w * PRUNE_BLOCK + lane * 4) = o;
-        my_terms += (unsigned long long)(end - beg) * 256ull;
+        if (wave > 0) {
+#pragma unroll
+            for (int v = 0; v < 4; v++) sh_t[wave - 1][lane][v] = t[v];
+            sh_mask[wave - 1][lane] = mask;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            for (int x = 0; x < 3; x++) {
+#pragma unroll
+                for (int v = 0; v < 4; v++) t[v] += sh_t[x][lane][v];
+                mask |= sh_mask[x][lane];
+            }
+            const double base = pvpi_[slot - A.slot_lo];
+            float4 o;
+            o.x = ((mask & 1u) || col + 0 >= A.Ic) ? qnan : (float)(base + LN2 * t[0]);
+            o.y = ((mask & 2u) || col + 1 >= A.Ic) ? qnan : (float)(base + LN2 * t[1]);
+            o.z = ((mask & 4u) || col + 2 >= A.Ic) ? qnan : (float)(base + LN2 * t[2]);
+            o.w = ((mask & 8u) || col + 3 >= A.Ic) ? qnan : (float)(base + LN2 * t[3]);
+            // packed: entry w holds the block's 256 scores (the top-N kernels find them through quad_prefix)
+            *reinterpret_cast<float4*>(S_ + (int64_t)w * PRUNE_BLOCK + lane * 4) = o;
+            my_terms += (unsigned long long)(row_end - row_beg) * 256ull;
+        }
+        __syncthreads();   // sh_t is free again
     }
-    if (lane == 0 && my_terms) atomicAdd(&counters[1], my_terms);
+    if (wave == 0 && lane == 0 && my_terms) atomicAdd(&counters[1], my_terms);
 }
 
 // ================================================================ cooperative ranks (fy_collectives): kernels
