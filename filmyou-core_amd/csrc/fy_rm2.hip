@@ -481,7 +481,8 @@ struct ScoreTune {
                                        // 0 = from the list length: ~5 N columns (N = 50: one chunk, N = 100: two), at most four
     int cooc_debug = 0;                // timing experiments only
     int cooc_block = 0;                // test hook: force the row kernel's workgroup size
-    int cooc_max_ch = 16384;           // LDS accumulators of the row kernel (test hook: smaller forces column chunks)
+    int cooc_max_ch = 19968;           // LDS accumulators of the row kernel: 156 KiB of fp64 of the 160 KiB LDS (ML-25M shape: three
+                                       // column chunks instead of four, 19.7 -> 17.8 ms; test hook: smaller forces more chunks)
     int hot_lds = 0;                   // k_score_hot: the 128 most popular rows of a chunk stay in LDS (slower: 16 waves/CU)
     int hot_min_items = 2048;
     int64_t tile_bytes = (int64_t)1 << 40;   // M[row block][chunk] tile; default: one row block (sweep r1)
@@ -510,7 +511,7 @@ static ScoreTune score_tune() {
     if (const char* e = getenv("FY_LANES")) { int v = atoi(e); if (v >= 1 && v <= 8) t.lanes = v; }
     if (const char* e = getenv("FY_COOC_DEBUG")) t.cooc_debug = atoi(e);
     if (const char* e = getenv("FY_COOC_BLOCK")) { int v = atoi(e); if (v == 256 || v == 512 || v == 1024) t.cooc_block = v; }
-    if (const char* e = getenv("FY_COOC_MAX_CH")) { int v = atoi(e); if (v >= 64 && v <= 16384) t.cooc_max_ch = v; }
+    if (const char* e = getenv("FY_COOC_MAX_CH")) { int v = atoi(e); if (v >= 64 && v <= 20224) t.cooc_max_ch = v; }
     if (const char* e = getenv("FY_HOT_MIN_ITEMS")) t.hot_min_items = atoi(e);
     if (const char* e = getenv("FY_TOPN_FORCE_SELECT")) t.force_select = atoi(e) != 0;
     if (const char* e = getenv("FY_SCORE_TILE_KB")) { long v = atol(e); if (v >= 16) t.tile_bytes = (int64_t)v << 10; }
@@ -712,7 +713,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
         FY_FAIL(FY_ERR_UNSUPPORTED, "min(numberOfRecommendations, items per cluster) = %d exceeds the top-N kernel limit %d", eff_top, TOPN_MAX);
     if (n_recs > 0 && max_Ic > 0) {
         const int64_t ws = prm.workspace_bytes > 0 ? prm.workspace_bytes : tune.workspace_default;
-        const int max_ch_lds = tune.cooc_max_ch;   // fp64 accumulators: 128 KiB of the 160 KiB LDS
+        const int max_ch_lds = tune.cooc_max_ch;   // fp64 accumulators in LDS
         FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cooc_rm2<false>), hipFuncAttributeMaxDynamicSharedMemorySize, max_ch_lds * 8));
         FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cooc_rm2<true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_ch_lds * 8));
         FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_score_hot<true>), hipFuncAttributeMaxDynamicSharedMemorySize, SCORE_HOT_ROWS * 1024));
