@@ -248,7 +248,7 @@ def main():
         out["pcie_inclusive"] = {"value": n_rows / dt, "unit": "recs/s", "ms": 1e3 * dt,
                                  "note": "host COO -> HBM -> job -> rows back in host memory, one run"}
     if rank == 0 and world == 1 and not a.no_cpu:
-        n_cpu = a.cpu_users or {"ml25m": 180, "netflix": 150, "ml1m": 600, "ml100k": 943}.get(a.shape, 200)
+        n_cpu = a.cpu_users or {"ml25m": 270, "netflix": 200, "ml1m": 800, "ml100k": 943}.get(a.shape, 200)
         out["cpu_baseline"] = cpu_baseline(S, a.shape, facts, a.lam, top_n, n_cpu)
     elif rank == 0:
         out["cpu_baseline"] = None
