@@ -62,6 +62,8 @@ __device__ __forceinline__ float isim_order_unkey(uint32_t k) {
 
 constexpr int ISIM_CAP = 2048;      // candidate buffer (LDS)
 constexpr int ISIM_MAX_K = 1024;
+constexpr int ISIM_SAMPLE = 256;       // columns sampled for the first threshold guess of a row
+constexpr int ISIM_SAMPLE_RANK = 5;    // ... whose 5th largest is the guess (expected: ~5 * columns / 256 values above it)
 
 struct ISimEpilogue {
     const int32_t* __restrict__ rank_item_raw;
@@ -81,6 +83,7 @@ struct ISimEpilogue {
     uint64_t* __restrict__ part;       // [rows_mine * nch * K]
     int32_t heavy_rows;                // leading rows of the launch that are split by chunk
     int32_t n_items;                   // heavy_rows * nch + (rows - heavy_rows)
+    int32_t cap;                       // candidate buffer entries in LDS (power of two, >= 2 K, <= ISIM_CAP)
 };
 
 __device__ __forceinline__ void isim_sort_desc(uint64_t* v, int P2) {
@@ -151,15 +154,15 @@ __device__ __forceinline__ void isim_select(uint64_t* cand, int n, int K, uint32
 }
 
 // buffer (nearly) full: keep the K best (plus ties inside the last key prefix); exact sort when even that does not make room
-__device__ __forceinline__ void isim_cut(uint64_t* cand, int K, uint32_t* hist, uint32_t* sh_cnt, uint32_t* sh_tau, uint32_t* sh_aux) {
+__device__ __forceinline__ void isim_cut(uint64_t* cand, int K, int cap, uint32_t* hist, uint32_t* sh_cnt, uint32_t* sh_tau, uint32_t* sh_aux) {
     const int tid = threadIdx.x;
     isim_select(cand, (int)*sh_cnt, K, hist, sh_cnt, sh_tau, sh_aux);
-    if (*sh_cnt + blockDim.x > (uint32_t)ISIM_CAP) {   // massive ties inside one key prefix (block-uniform)
+    if (*sh_cnt + min((uint32_t)blockDim.x, (uint32_t)cap / 2) > (uint32_t)cap) {   // massive ties inside one key prefix (block-uniform)
         const int n = (int)*sh_cnt;
         __syncthreads();
-        for (int i = n + tid; i < ISIM_CAP; i += blockDim.x) cand[i] = 0ull;
+        for (int i = n + tid; i < cap; i += blockDim.x) cand[i] = 0ull;
         __syncthreads();
-        isim_sort_desc(cand, ISIM_CAP);
+        isim_sort_desc(cand, cap);
         if (tid == 0) {
             *sh_cnt = (uint32_t)min(n, K);
             if (n >= K) *sh_tau = (uint32_t)(cand[K - 1] >> 32);   // inclusive: a later tie with a smaller item id still wins
@@ -208,6 +211,62 @@ __global__ void k_cooc_itemsim(CoocArgs A, ISimEpilogue E, int* __restrict__ nex
             // the buffer is cut back (isim_select raises tau) and the pass runs again over what is left.  A consumed entry
             // reads as similarity 0, which only a threshold <= 0 would accept again: that configuration steps with barriers.
             const bool stepwise = E.has_threshold && !(E.threshold > 0.0f);
+            if (!stepwise && sh_tau == 0 && ncol >= 4 * ISIM_SAMPLE) {
+                // No threshold yet: thousands of non-zero similarities would flood the candidate buffer and be cut back in
+                // several rounds.  Guess one from a sample instead: the ISIM_SAMPLE_RANK-th largest of ISIM_SAMPLE columns
+                // spread over the chunk (wave 0, shuffles only), count how many columns reach it (one sweep, no writes) and
+                // adopt it if at least K do -- then it is a valid lower bound of the K-th best and the append pass below
+                // takes a few hundred candidates in one go.  A bad guess changes nothing: the old path runs.
+                if (tid < 64) {
+                    uint32_t k4[ISIM_SAMPLE / 64];
+#pragma unroll
+                    for (int x = 0; x < ISIM_SAMPLE / 64; x++) {
+                        const int t = (int)(((int64_t)(tid * (ISIM_SAMPLE / 64) + x) * ncol) / ISIM_SAMPLE);
+                        const int col = c0 + t;
+                        const double a = acc[t];
+                        const float sv = E.inv_norm ? (float)(a * scale_row * E.inv_norm[col]) : (float)a;
+                        bool ok = E.has_threshold ? (sv >= E.threshold) : (sv > 0.0f);
+                        if (E.exclude_self && col == row) ok = false;
+                        k4[x] = ok ? isim_order_key(sv) : 0u;
+                    }
+                    uint32_t best = 0;
+                    for (int r = 0; r < ISIM_SAMPLE_RANK; r++) {
+                        uint32_t m = 0;
+#pragma unroll
+                        for (int x = 0; x < ISIM_SAMPLE / 64; x++) m = max(m, k4[x]);
+                        uint32_t wm = m;
+                        for (int o = 32; o > 0; o >>= 1) wm = max(wm, (uint32_t)__shfl_xor((int)wm, o, 64));
+                        best = wm;
+                        // remove one occurrence of the maximum (the first lane that holds it)
+                        const unsigned long long holders = __ballot(m == wm && wm != 0);
+                        if (holders && tid == __ffsll((long long)holders) - 1) {
+                            bool done = false;
+#pragma unroll
+                            for (int x = 0; x < ISIM_SAMPLE / 64; x++)
+                                if (!done && k4[x] == wm) { k4[x] = 0; done = true; }
+                        }
+                    }
+                    if (tid == 0) { sh_aux[0] = best; sh_aux[1] = 0; }
+                }
+                __syncthreads();
+                const uint32_t guess = sh_aux[0];
+                if (guess != 0) {   // block-uniform
+                    int mine_cnt = 0;
+                    for (int t = tid; t < ncol; t += blockDim.x) {
+                        const int col = c0 + t;
+                        const double a = acc[t];
+                        const float sv = E.inv_norm ? (float)(a * scale_row * E.inv_norm[col]) : (float)a;
+                        bool ok = E.has_threshold ? (sv >= E.threshold) : (sv > 0.0f);
+                        if (E.exclude_self && col == row) ok = false;
+                        mine_cnt += ok && isim_order_key(sv) >= guess;
+                    }
+                    for (int o = 32; o > 0; o >>= 1) mine_cnt += __shfl_down(mine_cnt, o, 64);
+                    if ((tid & 63) == 0 && mine_cnt) atomicAdd(&sh_aux[1], (uint32_t)mine_cnt);
+                    __syncthreads();
+                    if (tid == 0 && sh_aux[1] >= (uint32_t)E.K) sh_tau = guess;
+                }
+                __syncthreads();
+            }
             for (bool again = true; again;) {
                 const uint32_t tau = sh_tau;
                 for (int base = 0; base < ncol; base += blockDim.x) {
@@ -234,21 +293,21 @@ __global__ void k_cooc_itemsim(CoocArgs A, ISimEpilogue E, int* __restrict__ nex
                         at = __shfl(at, __ffsll((long long)bal) - 1, 64);
                         if (want) {
                             const uint32_t pos = at + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-                            if (pos < (uint32_t)ISIM_CAP) { cand[pos] = c; acc[t] = 0.0; }
+                            if (pos < (uint32_t)E.cap) { cand[pos] = c; acc[t] = 0.0; }
                         }
                     }
                     if (stepwise) {
                         __syncthreads();
-                        if (sh_cnt + blockDim.x > (uint32_t)ISIM_CAP) isim_cut(cand, E.K, hist, &sh_cnt, &sh_tau, sh_aux);
+                        if (sh_cnt + blockDim.x > (uint32_t)E.cap) isim_cut(cand, E.K, E.cap, hist, &sh_cnt, &sh_tau, sh_aux);
                     }
                 }
                 __syncthreads();
                 again = false;
-                if (!stepwise && sh_cnt > (uint32_t)ISIM_CAP) {   // block-uniform: some candidates did not fit
+                if (!stepwise && sh_cnt > (uint32_t)E.cap) {   // block-uniform: some candidates did not fit
                     __syncthreads();
-                    if (tid == 0) sh_cnt = (uint32_t)ISIM_CAP;
+                    if (tid == 0) sh_cnt = (uint32_t)E.cap;
                     __syncthreads();
-                    isim_cut(cand, E.K, hist, &sh_cnt, &sh_tau, sh_aux);
+                    isim_cut(cand, E.K, E.cap, hist, &sh_cnt, &sh_tau, sh_aux);
                     again = true;
                 }
             }
@@ -387,8 +446,11 @@ fy_result* itemsim_build(Context* ctx, const fy_itemsim_params* prm, const fy_ra
     }
 
     const int K = prm->max_similarities_per_item;
-    int max_ch = 16384;   // 128 KiB of fp64 accumulators + 16 KiB candidate buffer <= 160 KiB LDS
-    if (const char* e = getenv("FY_COOC_MAX_CH")) { const int v = atoi(e); if (v >= 64 && v <= 16384) max_ch = v; }   // test hook: force column chunks
+    // LDS = fp64 accumulators + candidate buffer <= 160 KiB.  (A 512-entry buffer would allow three column chunks instead of
+    // four at ML-25M shape, but the extra cuts cost more than the shorter walk gains: 28.5 against 27.2 ms.)
+    const int cap = ISIM_CAP;
+    int max_ch = ((160 * 1024 - cap * 8 - 2048) / 8) / 256 * 256;
+    if (const char* e = getenv("FY_COOC_MAX_CH")) { const int v = atoi(e); if (v >= 64 && v <= max_ch) max_ch = v; }   // test hook: force column chunks
     int32_t CH, nch;
     pick_chunks(Ic, max_ch, CH, nch);
     DevBuf<int32_t> chunk_off(ctx, (size_t)P.nU * (nch + 1));
@@ -425,8 +487,8 @@ fy_result* itemsim_build(Context* ctx, const fy_itemsim_params* prm, const fy_ra
         CA.item_seg = item_seg.get();
         ISimEpilogue IE{P.rank_item_raw.get(), K, prm->exclude_self, prm->has_threshold, (float)prm->threshold, prm->rank,
                         prm->world, cnt.get(), other.get(), sim.get(), (use_pk && cosine) ? inv_norm.get() : nullptr,
-                        part_cnt.get(), part.get(), heavy_rows, (int32_t)n_items};
-        const size_t lds = (size_t)CH * 8 + (size_t)ISIM_CAP * 8;
+                        part_cnt.get(), part.get(), heavy_rows, (int32_t)n_items, cap};
+        const size_t lds = (size_t)CH * 8 + (size_t)cap * 8;
         FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cooc_itemsim<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cooc_itemsim<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const int block = lds > 48 * 1024 ? 1024 : 256;
