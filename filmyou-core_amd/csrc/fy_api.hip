@@ -221,6 +221,15 @@ int fy_itemsim_run(const fy_itemsim_params* p, int64_t nnz, const int32_t* user,
     return rc;
 }
 
+int fy_cluster_assign(fy_context* c, int32_t n_rows, int32_t k, const double* H, int location, int32_t first_user,
+                      int32_t cluster_offset, int32_t n_clusters, int32_t* user_out, int32_t* cluster_out, int32_t* count_inout) {
+    if (!c) { set_error("context is NULL"); return FY_ERR_INVALID_ARGUMENT; }
+    FY_TRY
+    FY_HIP(hipSetDevice(c->c.device));
+    fy::cluster_assign(&c->c, n_rows, k, H, location, first_user, cluster_offset, n_clusters, user_out, cluster_out, count_inout);
+    FY_CATCH
+}
+
 int fy_itemcf_recommend(fy_context* c, const fy_itemcf_params* p, const fy_ratings* r, fy_result* sims, fy_result** out) {
     if (!out) { set_error("out is NULL"); return FY_ERR_INVALID_ARGUMENT; }
     *out = nullptr;

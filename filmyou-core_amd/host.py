@@ -466,3 +466,56 @@ class RowSimilarityJob:
         finally:
             if own_ratings:
                 r.close()
+
+
+class ClusterAssignmentJob:
+    """Cluster assignment in front of the RM2 job (M/nmf/clustering/ClusterAssignmentJob.java:60-135 + CountClustersJob):
+    every user goes to the cluster of the largest entry of its row of H (FindClusterMapper.java:37-45), or -- sub-clustering,
+    FindSubClusterMapper.java:46-76 -- to  parent * ceil(numberOfUsers / numberOfClusters) + argmax  of its row of that
+    parent cluster's H.  ``run`` returns ``(users, clusters, counts)``: the reference's `clustering` and `clusteringCount`
+    files as arrays, i.e. the ``clustering=(users, clusters), clustering_count=counts`` arguments of ``RM2Job.run``."""
+
+    def __init__(self, context):
+        self._ctx = context
+        self._lib = _native.load()
+
+    def _assign(self, H, first_user, offset, counts):
+        import numpy as np
+        device = hasattr(H, "is_cuda") and H.is_cuda
+        if device:
+            import torch
+            assert H.dtype == torch.float64 and H.is_contiguous() and H.dim() == 2
+            torch.cuda.current_stream(H.device).synchronize()
+            n, k, ptr = int(H.shape[0]), int(H.shape[1]), H.data_ptr()
+        else:
+            H = np.ascontiguousarray(H, dtype=np.float64)
+            if H.ndim != 2:
+                raise ValueError("H must be a (users x clusters) matrix")
+            n, k, ptr = H.shape[0], H.shape[1], H.ctypes.data
+        users, clusters = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        _check(self._lib.fy_cluster_assign(self._ctx._h, n, k, ptr, 1 if device else 0, int(first_user),
+                                           int(offset), len(counts), users.ctypes.data, clusters.ctypes.data,
+                                           counts.ctypes.data if len(counts) else None))
+        return users, clusters
+
+    def run(self, H, first_user=1, number_of_clusters=None):
+        """H: (users x numberOfClusters) float64, numpy or a CUDA torch tensor.  first_user: id of row 0 (the reference's H
+        files are keyed from 1)."""
+        import numpy as np
+        k = int(H.shape[1]) if number_of_clusters is None else int(number_of_clusters)
+        counts = np.zeros(k, np.int32)
+        users, clusters = self._assign(H, first_user, 0, counts)
+        return users, clusters, counts
+
+    def run_sub(self, parts, number_of_users, number_of_clusters):
+        """Sub-clustering: parts = [(parent_cluster, H_parent, first_user), ...] (one H per `cluster<c>` directory of the
+        reference); the total number of clusters becomes numberOfClusters * ceil(numberOfUsers / numberOfClusters)."""
+        import numpy as np
+        n_sub = -(-int(number_of_users) // int(number_of_clusters))
+        counts = np.zeros(n_sub * int(number_of_clusters), np.int32)
+        us, cs = [], []
+        for parent, H, first_user in parts:
+            u, c = self._assign(H, first_user, int(parent) * n_sub, counts)
+            us.append(u)
+            cs.append(c)
+        return np.concatenate(us), np.concatenate(cs), counts

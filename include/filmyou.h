@@ -159,6 +159,20 @@ typedef struct {
 } fy_itemcf_params;
 int fy_itemcf_recommend(fy_context*, const fy_itemcf_params*, const fy_ratings*, fy_result* similarities, fy_result** out);
 
+/* ------------------------------------------------------------------ cluster assignment (the stage in front of the RM2 job)
+ * Replaces ClusterAssignmentJob's map-only jobs and CountClustersJob (M/nmf/clustering/ClusterAssignmentJob.java:60-135,
+ * FindClusterMapper.java:37-45, FindSubClusterMapper.java:46-76, CountReducer.java:31-45): for every row j of H (n_rows x k
+ * doubles, row-major; the factor matrix the NMF/PPC stage leaves behind)
+ *     user[j] = first_user + j          (the SequenceFile key of DataInitialization.createDoubleMatrix / the H files)
+ *     cluster[j] = cluster_offset + first index of the largest value of the row   (Vector.maxValueIndex(); -1 + no offset if
+ *                  no value exceeds -infinity)
+ * Sub-clustering calls it once per parent cluster c with cluster_offset = c * ceil(numberOfUsers / numberOfClusters).
+ * count_inout (host, n_clusters ints, may be NULL) is INCREMENTED per routed user = the `clusteringCount` file; a cluster id
+ * outside [0, n_clusters) then fails with FY_ERR_CLUSTER_RANGE.  H: FY_HOST or FY_DEVICE; user_out / cluster_out: host arrays of
+ * n_rows ints -- exactly the (map_user, map_cluster, cluster_count) arguments of fy_rm2_prepare / fy_rm2_run. */
+int fy_cluster_assign(fy_context*, int32_t n_rows, int32_t k, const double* H, int location, int32_t first_user,
+                      int32_t cluster_offset, int32_t n_clusters, int32_t* user_out, int32_t* cluster_out, int32_t* count_inout);
+
 /* ------------------------------------------------------------------ results
  * Rows as the reference writes them: RM2 (user, item, (float) relevance, cluster) -- RM2HDFSReducer.java:48 /
  * RM2CassandraReducer.java:49-63 -- grouped by user, best first; item-sim (item, other item, similarity) grouped by

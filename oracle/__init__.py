@@ -16,7 +16,7 @@ _lib = None
 
 def build(force=False):
     """Compile liboracle.so with gcc (seconds).  Safe to call repeatedly."""
-    srcs = [os.path.join(_HERE, f) for f in ("rm2_oracle.c", "itemsim_oracle.c", "itemcf_oracle.c", "oracle.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("rm2_oracle.c", "itemsim_oracle.c", "itemcf_oracle.c", "cluster_oracle.c", "oracle.h", "Makefile")]
     stale = force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
     if stale:
         subprocess.run(["make", "-C", _HERE, "-s"] + (["-B"] if force else []), check=True)
@@ -70,6 +70,10 @@ def _load():
         f = getattr(L, "icfo_" + name)
         f.argtypes = [vp]
         f.restype = rt
+    L.clo_assign.argtypes = [C.c_int32, C.c_int32, vp, C.c_int32, C.c_int32, vp, vp]
+    L.clo_assign.restype = C.c_int
+    L.clo_count.argtypes = [i64, vp, C.c_int32, vp]
+    L.clo_count.restype = C.c_int
     _lib = L
     return L
 
@@ -166,3 +170,19 @@ def itemcf(user, item, score, sim_item, sim_other, sim_value, *, num_recommendat
                 "score": _arr(L.icfo_score(h), n, np.float32)}
     finally:
         L.icfo_free(h)
+
+
+def cluster_assign(H, first_user=1, cluster_offset=0, n_clusters=None):
+    """Cluster-assignment oracle: (users, clusters[, counts]) from the rows of H (see cluster_oracle.c)."""
+    L = _load()
+    H = np.ascontiguousarray(H, dtype=np.float64)
+    n, k = H.shape
+    user, cluster = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    if L.clo_assign(n, k, H.ctypes.data, int(first_user), int(cluster_offset), user.ctypes.data, cluster.ctypes.data) != 0:
+        raise RuntimeError("cluster oracle failed")
+    if n_clusters is None:
+        return user, cluster
+    count = np.zeros(int(n_clusters), np.int32)
+    if L.clo_count(n, cluster.ctypes.data, int(n_clusters), count.ctypes.data) != 0:
+        raise RuntimeError("cluster id outside [0, n_clusters)")
+    return user, cluster, count

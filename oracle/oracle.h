@@ -84,7 +84,13 @@ const int32_t* icfo_user(const icfo_result*);
 const int32_t* icfo_item(const icfo_result*);
 const float* icfo_score(const icfo_result*);
 
+/* ---- cluster assignment (cluster_oracle.c): FindClusterMapper / FindSubClusterMapper / CountReducer */
+int clo_assign(int32_t n_rows, int32_t k, const double* H /* row-major n_rows x k */, int32_t first_user, int32_t cluster_offset,
+               int32_t* user, int32_t* cluster);
+int clo_count(int64_t n, const int32_t* cluster, int32_t n_clusters, int32_t* count);
+
 #ifdef __cplusplus
 }
 #endif
+
 #endif

@@ -13,6 +13,10 @@ Source of every array (data values only, no code is copied):
   * T/RMTestData.java:408-410  userSum,  :415-421 itemSum,  :426 totalSum,  :431-464 itemColl
   * T/ClusteringTestData.java:90-93  clustering (cluster of user u at [u-1]), clusteringCount
   * T/RMTestData2.java:25-60   the 3x5 toy (A, userSum, itemSum, totalSum, itemColl, clustering)
+  * T/ClusteringTestData.java:28-93   H (30 users x 5 clusters) -> clustering, clusteringCount   (cluster assignment stage,
+    asserted by T/../nmf/clustering/TestClusterAssignment.java:43-69)
+  * T/SubClusteringTestData.java:25-100  H0 (users 1..17), H1 (users 18..30), numberOfSubClusters -> clustering
+    (sub-cluster assignment, TestClusterAssignment.java:71-103)
 Parameters of the reference integration test that produced `recommendations`
 (T/../rm/TestHDFSRM2.java:39-75 with T/../util/HadoopIntegrationTest.java:81-100):
   lambda=0.5, clusterSplit=5, splitSize=3, numberOfRecommendations=1000, tolerance 1e-4 absolute.
@@ -74,6 +78,30 @@ def main():
     assert len(out["clustering"]) == 30 and sum(out["clusteringCount"]) == 30
     with open(os.path.join(HERE, "rm_test_data.json"), "w") as f:
         json.dump(out, f, separators=(",", ":"))
+
+    sub = open(T + "SubClusteringTestData.java").read()
+
+    def java_array2(text, name):   # `H1 = { ... }` is written without `new double[][]`
+        m = re.search(r"\b%s\s*=\s*(?:new\s+\w+\s*(?:\[\s*\])+\s*)?(\{.*?\})\s*;" % re.escape(name), text, re.S)
+        lit = re.sub(r"(\d)\.(?=[\s,}])", r"\1.0", m.group(1)).replace("{", "[").replace("}", "]")
+        return json.loads(lit)
+
+    clus = {
+        "_source": attribution + "ClusteringTestData.java + SubClusteringTestData.java",
+        "numberOfUsers": int(java_scalar(cl, "numberOfUsers")),
+        "numberOfClusters": int(java_scalar(cl, "numberOfClusters")),
+        "H": java_array(cl, "H"),
+        "clustering": java_array(cl, "clustering"),
+        "clusteringCount": java_array(cl, "clusteringCount"),
+        "sub": {"numberOfUsers": int(java_scalar(sub, "numberOfUsers")), "numberOfClusters": int(java_scalar(sub, "numberOfClusters")),
+                "numberOfSubClusters": int(java_scalar(sub, "numberOfSubClusters")),
+                "H0": java_array2(sub, "H0"), "H0_first_user": 1, "H1": java_array2(sub, "H1"), "H1_first_user": 18,
+                "clustering": java_array2(sub, "clustering")},
+    }
+    assert len(clus["H"]) == 30 and len(clus["H"][0]) == 5
+    assert len(clus["sub"]["H0"]) + len(clus["sub"]["H1"]) == 30
+    with open(os.path.join(HERE, "clustering_test_data.json"), "w") as f:
+        json.dump(clus, f, separators=(",", ":"))
 
     toy = {
         "_source": attribution + "RMTestData2.java",

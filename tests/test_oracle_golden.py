@@ -143,3 +143,21 @@ def test_cluster_count_mismatch_is_an_error(rm_golden):
     cc[0] += 1
     with pytest.raises(RuntimeError, match="clusteringCount"):
         run_golden(rm_golden, cluster_count=cc)
+
+
+def test_cluster_assignment_oracle_reproduces_the_reference_vectors():
+    """ClusteringTestData.H -> clustering / clusteringCount and SubClusteringTestData.H0/H1 -> clustering
+    (T/nmf/clustering/TestClusterAssignment.java:43-103)"""
+    import json
+    import os
+    import oracle
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "clustering_test_data.json")) as f:
+        g = json.load(f)
+    u, c, cnt = oracle.cluster_assign(np.array(g["H"]), first_user=1, n_clusters=g["numberOfClusters"])
+    assert u.tolist() == list(range(1, 31)) and c.tolist() == g["clustering"] and cnt.tolist() == g["clusteringCount"]
+    s = g["sub"]
+    n_sub = -(-s["numberOfUsers"] // s["numberOfClusters"])            # FindSubClusterMapper.setup: ceil(30 / 2) = 15
+    u0, c0 = oracle.cluster_assign(np.array(s["H0"]), first_user=s["H0_first_user"], cluster_offset=0 * n_sub)
+    u1, c1 = oracle.cluster_assign(np.array(s["H1"]), first_user=s["H1_first_user"], cluster_offset=1 * n_sub)
+    assert np.r_[u0, u1].tolist() == list(range(1, 31))
+    assert np.r_[c0, c1].tolist() == s["clustering"]
