@@ -12,8 +12,8 @@ All compute happens in libfilmyou_hip.so (hand-written HIP for gfx950); there is
 """
 from . import _native
 from ._native import build, LIB_PATH
-from .host import (BaselineRecommenderJob, ClusterAssignmentJob, Configuration, Context, FilmYouError, ItemRecommendations, ItemSimilarities, PreparedRM2, Ratings, Recommendations, RM2Job,
+from .host import (BaselineRecommenderJob, ClusterAssignmentJob, Configuration, Context, FilmYouError, ItemRecommendations, ItemSimilarities, NMFDriver, PreparedRM2, Ratings, Recommendations, RM2Job,
                    RowSimilarityJob, SIMILARITY_COSINE, SIMILARITY_COOCCURRENCE)
 
-__all__ = ["build", "BaselineRecommenderJob", "ClusterAssignmentJob", "ItemRecommendations", "LIB_PATH", "Configuration", "Context", "FilmYouError", "ItemSimilarities", "PreparedRM2", "Ratings",
+__all__ = ["build", "BaselineRecommenderJob", "ClusterAssignmentJob", "ItemRecommendations", "NMFDriver", "LIB_PATH", "Configuration", "Context", "FilmYouError", "ItemSimilarities", "PreparedRM2", "Ratings",
            "Recommendations", "RM2Job", "RowSimilarityJob", "SIMILARITY_COSINE", "SIMILARITY_COOCCURRENCE", "_native"]

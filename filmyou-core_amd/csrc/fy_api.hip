@@ -230,6 +230,15 @@ int fy_cluster_assign(fy_context* c, int32_t n_rows, int32_t k, const double* H,
     FY_CATCH
 }
 
+int fy_nmf_factorize(fy_context* c, const fy_nmf_params* p, const fy_ratings* r, double* H, double* W, fy_stats* st) {
+    if (!c || !r) { set_error("context or ratings is NULL"); return FY_ERR_INVALID_ARGUMENT; }
+    if (r->ctx != &c->c) { set_error("ratings belong to another context"); return FY_ERR_INVALID_ARGUMENT; }
+    FY_TRY
+    FY_HIP(hipSetDevice(c->c.device));
+    fy::nmf_factorize(&c->c, p, r, H, W, st);
+    FY_CATCH
+}
+
 int fy_itemcf_recommend(fy_context* c, const fy_itemcf_params* p, const fy_ratings* r, fy_result* sims, fy_result** out) {
     if (!out) { set_error("out is NULL"); return FY_ERR_INVALID_ARGUMENT; }
     *out = nullptr;

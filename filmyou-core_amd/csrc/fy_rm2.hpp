@@ -33,6 +33,7 @@ void rm2_job_destroy(fy_rm2_job*);
 fy_result* itemsim_build(Context*, const fy_itemsim_params*, const fy_ratings*);
 void cluster_assign(Context*, int32_t n_rows, int32_t k, const double* H, int location, int32_t first_user, int32_t cluster_offset,
                     int32_t n_clusters, int32_t* user_out, int32_t* cluster_out, int32_t* count_inout);
+void nmf_factorize(Context*, const fy_nmf_params*, const fy_ratings*, double* H, double* W, fy_stats* st);
 fy_result* itemcf_recommend(Context*, const fy_itemcf_params*, const fy_ratings*, fy_result* similarities);
 
 // top-N over rows of a dense score matrix (NaN = not a candidate): k_topn_fast + k_topn_select of fy_rm2.hip.

@@ -519,3 +519,42 @@ class ClusterAssignmentJob:
             us.append(u)
             cs.append(c)
         return np.concatenate(us), np.concatenate(cs), counts
+
+
+class NMFDriver:
+    """NMF (``ppc=False``, M/nmf/NMFDriver.java) or PPC (``ppc=True``, M/nmf/ppc/PPCDriver.java) factorisation of the rating
+    matrix: ``run`` performs numberOfIterations multiplicative updates of (H, W) (M/nmf/AbstractNMFDriver.java:118-146) on the
+    GPU in fp64 and returns the new ``(H, W)``.  H is (numberOfUsers x numberOfClusters), W (numberOfItems x numberOfClusters);
+    row r belongs to id r + 1.  Configuration keys: numberOfUsers, numberOfItems, numberOfClusters, numberOfIterations,
+    normalizationFrequency (PPC; Java's ``iteration % f``; 0 = never)."""
+
+    def __init__(self, conf, context, ppc=False):
+        self._conf, self._ctx, self._ppc = conf, context, bool(ppc)
+        self._lib = _native.load()
+        self.stats = None
+
+    def run(self, ratings, H, W):
+        import numpy as np
+        conf = self._conf
+        H = np.array(H, dtype=np.float64, order="C")
+        W = np.array(W, dtype=np.float64, order="C")
+        n_users = conf.getInt("numberOfUsers", H.shape[0])
+        n_items = conf.getInt("numberOfItems", W.shape[0])
+        k = conf.getInt("numberOfClusters", H.shape[1])
+        if H.shape != (n_users, k) or W.shape != (n_items, k):
+            raise ValueError("H must be numberOfUsers x numberOfClusters and W numberOfItems x numberOfClusters")
+        p = _native.NMFParams(n_users, n_items, k, conf.getInt("numberOfIterations", 1), 1 if self._ppc else 0,
+                              conf.getInt("normalizationFrequency", -1))
+        own = not isinstance(ratings, Ratings)
+        r = Ratings(self._ctx, *ratings) if own else ratings
+        try:
+            st = _native.Stats()
+            try:
+                _check(self._lib.fy_nmf_factorize(self._ctx._h, C.byref(p), r._h, H.ctypes.data, W.ctypes.data, C.byref(st)))
+            except FilmYouError as e:
+                raise RuntimeError("%s failed!: %s" % ("PPC" if self._ppc else "NMF", e.message)) from e
+            self.stats = st.as_dict()
+        finally:
+            if own:
+                r.close()
+        return H, W

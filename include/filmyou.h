@@ -213,6 +213,26 @@ typedef struct {
 } fy_stats;
 int fy_result_stats(fy_result*, fy_stats* out);
 
+/* ------------------------------------------------------------------ NMF / PPC factorisation (produces the H of fy_cluster_assign)
+ * Replaces NMFDriver / PPCDriver (M/nmf/AbstractNMFDriver.java:88-150): numberOfIterations rounds of the multiplicative
+ * updates, each computing H2 and W2 from the same old (H, W) -- ComputeHJob + HComputationReducer.java:57-75 (or
+ * PPCComputeHJob + PPCHComputationReducer.java:61-96) and ComputeWJob + WComputationMapper.java:100-118 -- in fp64 with
+ * eps = 1e-12 (MatrixComputationJob.java:41).  Only ratings with score > 0 enter (VectorByItemHDFSMapper.java:37-40).
+ * H: number_of_users x k, W: number_of_items x k doubles, row-major, HOST memory, updated in place; row r belongs to id
+ * r + 1 (the H / W files are keyed from 1, DataInitialization.createMatrix).  A user (item) in [1, n] without a kept rating
+ * fails like the reference's NoSuchElementException ("User %d has not rated any item" / "Item %d has not been rated by
+ * anybody"); an id outside the ranges fails too (the reference would hit a null vector). */
+typedef struct {
+    int32_t number_of_users;           /* "numberOfUsers" */
+    int32_t number_of_items;           /* "numberOfItems" */
+    int32_t number_of_clusters;        /* "numberOfClusters" = k (<= 256) */
+    int32_t number_of_iterations;      /* "numberOfIterations" */
+    int32_t ppc;                       /* 0 = NMFDriver, 1 = PPCDriver */
+    int32_t normalization_frequency;   /* PPC: the rows of H are L1-normalised when iteration % f == 0 (Java's %, so the
+                                          reference's unset key, -1, normalises every iteration); 0 = never */
+} fy_nmf_params;
+int fy_nmf_factorize(fy_context*, const fy_nmf_params*, const fy_ratings*, double* H_inout, double* W_inout, fy_stats* stats_or_null);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,7 +16,7 @@ _lib = None
 
 def build(force=False):
     """Compile liboracle.so with gcc (seconds).  Safe to call repeatedly."""
-    srcs = [os.path.join(_HERE, f) for f in ("rm2_oracle.c", "itemsim_oracle.c", "itemcf_oracle.c", "cluster_oracle.c", "oracle.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("rm2_oracle.c", "itemsim_oracle.c", "itemcf_oracle.c", "cluster_oracle.c", "nmf_oracle.c", "oracle.h", "Makefile")]
     stale = force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
     if stale:
         subprocess.run(["make", "-C", _HERE, "-s"] + (["-B"] if force else []), check=True)
@@ -70,6 +70,8 @@ def _load():
         f = getattr(L, "icfo_" + name)
         f.argtypes = [vp]
         f.restype = rt
+    L.nmfo_run.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, i64, vp, vp, vp, vp, vp]
+    L.nmfo_run.restype = C.c_int
     L.clo_assign.argtypes = [C.c_int32, C.c_int32, vp, C.c_int32, C.c_int32, vp, vp]
     L.clo_assign.restype = C.c_int
     L.clo_count.argtypes = [i64, vp, C.c_int32, vp]
@@ -186,3 +188,17 @@ def cluster_assign(H, first_user=1, cluster_offset=0, n_clusters=None):
     if L.clo_count(n, cluster.ctypes.data, int(n_clusters), count.ctypes.data) != 0:
         raise RuntimeError("cluster id outside [0, n_clusters)")
     return user, cluster, count
+
+
+def nmf(user, item, score, H, W, *, iterations, ppc=False, normalization_frequency=0):
+    """NMF / PPC factorisation oracle (nmf_oracle.c): returns the updated (H, W) copies.  ids are 1-based."""
+    L = _load()
+    user, item = _i32(user), _i32(item)
+    score = np.ascontiguousarray(score, dtype=np.float32)
+    H = np.array(H, dtype=np.float64, order="C")
+    W = np.array(W, dtype=np.float64, order="C")
+    rc = L.nmfo_run(H.shape[0], W.shape[0], H.shape[1], int(iterations), int(bool(ppc)), int(normalization_frequency), len(user),
+                    user.ctypes.data, item.ctypes.data, score.ctypes.data, H.ctypes.data, W.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("nmf oracle failed (%d)" % rc)
+    return H, W

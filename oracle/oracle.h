@@ -89,6 +89,10 @@ int clo_assign(int32_t n_rows, int32_t k, const double* H /* row-major n_rows x 
                int32_t* user, int32_t* cluster);
 int clo_count(int64_t n, const int32_t* cluster, int32_t n_clusters, int32_t* count);
 
+/* ---- NMF / PPC factorisation (nmf_oracle.c).  Returns 0, -2 id out of range, -3 a user without ratings, -4 an item without */
+int nmfo_run(int32_t n_users, int32_t n_items, int32_t k, int32_t iterations, int32_t ppc, int32_t norm_freq, int64_t nnz,
+             const int32_t* user, const int32_t* item, const float* score, double* H, double* W);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,6 +15,8 @@ Source of every array (data values only, no code is copied):
   * T/RMTestData2.java:25-60   the 3x5 toy (A, userSum, itemSum, totalSum, itemColl, clustering)
   * T/ClusteringTestData.java:28-93   H (30 users x 5 clusters) -> clustering, clusteringCount   (cluster assignment stage,
     asserted by T/../nmf/clustering/TestClusterAssignment.java:43-69)
+  * T/NMFTestData.java / T/PPCTestData.java   A (100 items x 30 users), W_init, H_init -> W_one, H_one (1 iteration), W_ten, H_ten
+    (10 iterations); PPC's 5 x 7 toy Ap, h0p, w0p -> w1p, h1p
   * T/SubClusteringTestData.java:25-100  H0 (users 1..17), H1 (users 18..30), numberOfSubClusters -> clustering
     (sub-cluster assignment, TestClusterAssignment.java:71-103)
 Parameters of the reference integration test that produced `recommendations`
@@ -37,6 +39,7 @@ def java_array(text, name):
     if not m:
         raise KeyError(name)
     lit = m.group(1)
+    lit = re.sub(r"(\d)[dD](?=[\s,}])", r"\1", lit)    # "2.585d" -> "2.585"
     lit = re.sub(r"(\d)\.(?=[\s,}])", r"\1.0", lit)  # "238." -> "238.0"
     lit = lit.replace("{", "[").replace("}", "]")
     return json.loads(lit)
@@ -102,6 +105,17 @@ def main():
     assert len(clus["sub"]["H0"]) + len(clus["sub"]["H1"]) == 30
     with open(os.path.join(HERE, "clustering_test_data.json"), "w") as f:
         json.dump(clus, f, separators=(",", ":"))
+
+    nmf, ppc = open(T + "NMFTestData.java").read(), open(T + "PPCTestData.java").read()
+    fact = {
+        "_source": attribution + "NMFTestData.java + PPCTestData.java (asserted by T/../nmf/NMFHDFSDriverTest.java:36-70, "
+                   "T/../nmf/ppc/PPCHDFSDriverTest.java, T/../nmf/hcomputation/*, T/../nmf/wcomputation/* with accuracy 1e-4)",
+        "nmf": {k: java_array(nmf, k) for k in ("A", "W_init", "H_init", "W_one", "H_one", "W_ten", "H_ten")},
+        "ppc": {k: java_array(ppc, k) for k in ("Ap", "h0p", "w0p", "w1p", "h1p", "A", "W_init", "H_init", "W_one", "H_one", "W_ten", "H_ten")},
+    }
+    assert len(fact["nmf"]["A"]) == 100 and len(fact["nmf"]["H_ten"]) == 30 and len(fact["nmf"]["W_ten"][0]) == 10
+    with open(os.path.join(HERE, "factorization_test_data.json"), "w") as f:
+        json.dump(fact, f, separators=(",", ":"))
 
     toy = {
         "_source": attribution + "RMTestData2.java",

@@ -161,3 +161,27 @@ def test_cluster_assignment_oracle_reproduces_the_reference_vectors():
     u1, c1 = oracle.cluster_assign(np.array(s["H1"]), first_user=s["H1_first_user"], cluster_offset=1 * n_sub)
     assert np.r_[u0, u1].tolist() == list(range(1, 31))
     assert np.r_[c0, c1].tolist() == s["clustering"]
+
+
+@pytest.mark.parametrize("name,ppc", [("nmf", False), ("ppc", True)])
+def test_factorisation_oracle_reproduces_the_reference_vectors(name, ppc):
+    """NMFTestData / PPCTestData: W_init, H_init -> W_one, H_one (1 iteration) and W_ten, H_ten (10 iterations);
+    asserted by the reference with accuracy 1e-4 (NMFHDFSDriverTest.java:36-70, PPCHDFSDriverTest.java)"""
+    import json
+    import os
+    import oracle
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "factorization_test_data.json")) as f:
+        d = json.load(f)[name]
+    A = np.array(d["A"])
+    i, u = np.nonzero(A > 0)
+    coo = ((u + 1).astype(np.int32), (i + 1).astype(np.int32), A[i, u].astype(np.float32))
+    for iterations, suffix in ((1, "one"), (10, "ten")):
+        H, W = oracle.nmf(*coo, d["H_init"], d["W_init"], iterations=iterations, ppc=ppc, normalization_frequency=12)
+        assert np.abs(H - np.array(d["H_" + suffix])).max() < 1e-10
+        assert np.abs(W - np.array(d["W_" + suffix])).max() < 1e-10
+    if ppc:   # the 5 x 7 toy (PPCTestData.Ap / h0p / w0p -> h1p); Ap is stored as FloatWritable scores
+        Ap = np.array(d["Ap"])
+        i, u = np.nonzero(Ap > 0)
+        H, _ = oracle.nmf((u + 1).astype(np.int32), (i + 1).astype(np.int32), Ap[i, u].astype(np.float32), d["h0p"], d["w0p"],
+                          iterations=1, ppc=True)
+        assert np.abs(H - np.array(d["h1p"])).max() < 1e-7
