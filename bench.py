@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--lam", type=float, default=0.1)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-itemsim", action="store_true", help="skip the item-item similarity leg")
+    ap.add_argument("--no-factorization", action="store_true", help="skip the PPC factorisation + cluster assignment leg")
     ap.add_argument("--cpu-users", type=int, default=0, help="users in the CPU sample cluster (0 = auto)")
     return ap.parse_args()
 
@@ -235,6 +236,47 @@ def main():
             out["itemsim"]["roofline"]["frac"] = out["itemsim"]["roofline"]["achieved"] / HBM_PEAK_GBS
         except RuntimeError as e:
             out["itemsim"] = {"error": str(e)}
+
+    # ---- the stage in front of the hot path: PPC factorisation (k = 50) + cluster assignment on the same
+    # ratings.  Algorithmic bytes per iteration: both SpMMs read 12 B per rating and gather one k-row of the dense factor
+    # (8 k B) per rating; the updates stream H, W, X once.
+    if world == 1 and not a.no_factorization:
+        try:
+            kf, iters = 50, 4
+            rng = np.random.Generator(np.random.PCG64(11))
+            H0 = rng.random((facts["n_users"], kf)) + 0.01
+            W0 = rng.random((facts["n_items"], kf)) + 0.01
+            fconf = P.Configuration()
+            for kk, vv in (("numberOfUsers", facts["n_users"]), ("numberOfItems", facts["n_items"]), ("numberOfClusters", kf),
+                           ("numberOfIterations", iters), ("normalizationFrequency", 12)):
+                fconf.setInt(kk, vv)
+            drv = P.NMFDriver(fconf, ctx, ppc=True)
+            drv.run(ratings, H0, W0)
+            fence()
+            t0 = time.perf_counter()
+            Hn, _ = drv.run(ratings, H0, W0)
+            fence()
+            dt_f = time.perf_counter() - t0
+            Hd = torch.from_numpy(Hn).to(dev)
+            job_c = P.ClusterAssignmentJob(ctx)
+            job_c.run(Hd, first_user=1)
+            fence()
+            t0 = time.perf_counter()
+            _, _, counts = job_c.run(Hd, first_user=1)
+            fence()
+            dt_c = time.perf_counter() - t0
+            gpu_ms = drv.stats["ms_total"] - drv.stats["ms_prepare"]
+            bytes_it = 2.0 * facts["nnz"] * (12 + 8 * kf) + 3.0 * 8 * kf * (facts["n_users"] + facts["n_items"])
+            out["factorization"] = {"what": "PPC, k = %d, %d iterations (host H/W in and out) + cluster assignment" % (kf, iters),
+                                    "seconds": dt_f, "ms_per_iteration_gpu": gpu_ms / iters, "ms_prepare": drv.stats["ms_prepare"],
+                                    "roofline": {"bound": "hbm", "achieved": bytes_it / (gpu_ms / iters * 1e-3) / 1e9,
+                                                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                 "frac": bytes_it / (gpu_ms / iters * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                 "note": "ms_per_iteration_gpu still contains the H/W transfers of the call"},
+                                    "cluster_assign_ms": 1e3 * dt_c, "users_per_s_cluster_assign": facts["n_users"] / dt_c,
+                                    "largest_cluster": int(counts.max())}
+        except RuntimeError as e:
+            out["factorization"] = {"error": str(e)}
 
     if world == 1:
         # the boundary also takes host buffers (fy_ratings_create FY_HOST + result download): PCIe-inclusive rate, reported

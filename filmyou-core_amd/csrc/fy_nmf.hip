@@ -68,28 +68,65 @@ __global__ void k_nmf_check_rows(int32_t n_rows, const int32_t* __restrict__ row
         if (rowptr[r + 1] == rowptr[r]) atomicMin(first_empty, r);
 }
 
-// X[r][:] = sum over the row's ratings a * B[col][:]   (one wave per row, lanes over the k columns; entries in index order)
-__global__ void k_nmf_spmm(int32_t n_rows, int32_t k, const int32_t* __restrict__ rowptr, const uint64_t* __restrict__ keys,
-                           const float* __restrict__ val, const double* __restrict__ B, double* __restrict__ X) {
+// SpMM  X[r][:] = sum over the row's ratings a * B[col][:]  in two deterministic stages: a row is cut into chunks of at most
+// NMF_CHUNK entries (the most popular item of ML-25M shape has ~10^5 raters: one wave walking it alone took 50 ms), one
+// wave per chunk writes a partial k-vector (lanes over the k columns, four entries in flight), then the row's partials are
+// added in chunk order.
+constexpr int NMF_CHUNK = 512;
+__global__ void k_nmf_chunk_counts(int32_t n_rows, const int32_t* __restrict__ rowptr, int32_t* __restrict__ cnt) {
+    for (int32_t r = blockIdx.x * blockDim.x + threadIdx.x; r <= n_rows; r += gridDim.x * blockDim.x)
+        cnt[r] = r < n_rows ? (rowptr[r + 1] - rowptr[r] + NMF_CHUNK - 1) / NMF_CHUNK : 0;
+}
+__global__ void k_nmf_chunk_rows(int32_t n_rows, const int32_t* __restrict__ chunkptr, int32_t* __restrict__ chunk_row) {
+    for (int32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += gridDim.x * blockDim.x)
+        for (int32_t c = chunkptr[r]; c < chunkptr[r + 1]; c++) chunk_row[c] = r;
+}
+__global__ void k_nmf_spmm_chunks(int32_t n_chunks, int32_t k, const int32_t* __restrict__ chunk_row, const int32_t* __restrict__ chunkptr,
+                                  const int32_t* __restrict__ rowptr, const uint64_t* __restrict__ keys, const float* __restrict__ val,
+                                  const double* __restrict__ B, double* __restrict__ part) {
     const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
-    for (int32_t r = blockIdx.x * wpb + (threadIdx.x >> 6); r < n_rows; r += gridDim.x * wpb) {
+    for (int32_t ch = blockIdx.x * wpb + (threadIdx.x >> 6); ch < n_chunks; ch += gridDim.x * wpb) {
+        const int32_t r = chunk_row[ch];
+        const int32_t f0 = rowptr[r] + (ch - chunkptr[r]) * NMF_CHUNK, f1 = min(rowptr[r + 1], f0 + NMF_CHUNK);
         double acc[NMF_MAX_K / 64];
 #pragma unroll
         for (int x = 0; x < NMF_MAX_K / 64; x++) acc[x] = 0.0;
-        for (int32_t f = rowptr[r]; f < rowptr[r + 1]; f++) {
-            const double a = (double)val[f];
-            const double* __restrict__ b = B + (int64_t)(uint32_t)keys[f] * k;
+        for (int32_t f = f0; f < f1; f += 4) {
+            double a[4];
+            const double* b[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int32_t ff = min(f + u, f1 - 1);
+                a[u] = f + u < f1 ? (double)val[ff] : 0.0;
+                b[u] = B + (int64_t)(uint32_t)keys[ff] * k;
+            }
 #pragma unroll
             for (int x = 0; x < NMF_MAX_K / 64; x++) {
                 const int c = lane + 64 * x;
-                if (c < k) acc[x] += a * b[c];
+                if (c < k) {
+                    const double v0 = b[0][c], v1 = b[1][c], v2 = b[2][c], v3 = b[3][c];
+                    acc[x] += a[0] * v0;      // entry order, like the sequential sum (a tail slot re-reads the last entry:
+                    if (f + 1 < f1) acc[x] += a[1] * v1;      // skipped, so that 0 * inf cannot leak in)
+                    if (f + 2 < f1) acc[x] += a[2] * v2;
+                    if (f + 3 < f1) acc[x] += a[3] * v3;
+                }
             }
         }
 #pragma unroll
         for (int x = 0; x < NMF_MAX_K / 64; x++) {
             const int c = lane + 64 * x;
-            if (c < k) X[(int64_t)r * k + c] = acc[x];
+            if (c < k) part[(int64_t)ch * k + c] = acc[x];
         }
+    }
+}
+__global__ void k_nmf_spmm_reduce(int32_t n_rows, int32_t k, const int32_t* __restrict__ chunkptr, const double* __restrict__ part,
+                                  double* __restrict__ X) {
+    const int64_t total = (int64_t)n_rows * k;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t r = (int32_t)(t / k), c = (int32_t)(t % k);
+        double s = 0.0;
+        for (int32_t ch = chunkptr[r]; ch < chunkptr[r + 1]; ch++) s += part[(int64_t)ch * k + c];
+        X[t] = s;
     }
 }
 
@@ -117,9 +154,18 @@ __device__ __forceinline__ double fy_clampinf(double v) { return isinf(v) ? (v >
 // out[r][c] = m_c * x_c / (y_c + eps),  y = C m.   mode 0: HComputationReducer; 1: PPCHComputationReducer (+ optional L1
 // normalisation); 2: WComputationMapper (infinities clamped)
 __global__ void k_nmf_update(int32_t n_rows, int32_t k, const double* __restrict__ M, const double* __restrict__ X,
-                             const double* __restrict__ C, int mode, int normalize, double* __restrict__ out) {
+                             const double* __restrict__ C_, int mode, int normalize, double* __restrict__ out) {
     const double eps = 1e-12;   // MatrixComputationJob.java:41
     const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    // the k x k matrix in LDS (k <= 64: 32 KiB), padded rows against bank conflicts; larger k reads it through L2
+    __shared__ double shC[64 * 65];
+    const bool in_lds = k <= 64;
+    if (in_lds) {
+        for (int e = threadIdx.x; e < k * k; e += blockDim.x) shC[(e / k) * 65 + (e % k)] = C_[e];
+        __syncthreads();
+    }
+    const double* __restrict__ C = in_lds ? shC : C_;
+    const int ldc = in_lds ? 65 : k;
     for (int32_t r = blockIdx.x * wpb + (threadIdx.x >> 6); r < n_rows; r += gridDim.x * wpb) {
         const double* __restrict__ m = M + (int64_t)r * k;
         double y[NMF_MAX_K / 64], x[NMF_MAX_K / 64], mv[NMF_MAX_K / 64];
@@ -130,7 +176,7 @@ __global__ void k_nmf_update(int32_t n_rows, int32_t k, const double* __restrict
             y[q] = 0.0; x[q] = 0.0; mv[q] = 0.0;
             if (c < k) {
                 double s = 0.0;
-                for (int a = 0; a < k; a++) s += C[(int64_t)c * k + a] * m[a];
+                for (int a = 0; a < k; a++) s += C[(int64_t)c * ldc + a] * m[a];
                 y[q] = s;
                 x[q] = X[(int64_t)r * k + c];
                 mv[q] = m[c];
@@ -210,10 +256,27 @@ void nmf_factorize(Context* ctx, const fy_nmf_params* prm, const fy_ratings* R, 
     // HComputationReducer.java:50-53 / WComputationMapper.java:93-96
     if (he[0] < nU) FY_FAIL(FY_ERR_INVALID_ARGUMENT, "User %d has not rated any item", he[0] + 1);
     if (he[1] < nI) FY_FAIL(FY_ERR_INVALID_ARGUMENT, "Item %d has not been rated by anybody", he[1] + 1);
+    // chunk tables of both SpMMs (fixed across the iterations)
+    struct Chunks { DevBuf<int32_t> ptr, row; int32_t n = 0; };
+    auto make_chunks = [&](int32_t n_rows, const int32_t* rowptr, Chunks& ck) {
+        DevBuf<int32_t> cnt(ctx, (size_t)n_rows + 1);
+        ck.ptr.alloc(ctx, (size_t)n_rows + 1);
+        k_nmf_chunk_counts<<<grid_for((int64_t)n_rows + 1), 256, 0, s>>>(n_rows, rowptr, cnt.get());
+        FY_KERNEL_CHECK();
+        exclusive_scan_i32(ctx, cnt.get(), ck.ptr.get(), (size_t)n_rows + 1);
+        ck.n = fetch(ctx, ck.ptr.get() + n_rows);
+        ck.row.alloc(ctx, (size_t)std::max(1, ck.n));
+        k_nmf_chunk_rows<<<grid_for(n_rows), 256, 0, s>>>(n_rows, ck.ptr.get(), ck.row.get());
+        FY_KERNEL_CHECK();
+    };
+    Chunks cu, ci;
+    make_chunks(nU, uptr.get(), cu);
+    make_chunks(nI, iptr.get(), ci);
     t_prep.end(sp_prep);
 
     DevBuf<double> H(ctx, (size_t)nU * k), W(ctx, (size_t)nI * k), H2(ctx, (size_t)nU * k), W2(ctx, (size_t)nI * k);
     DevBuf<double> XH(ctx, (size_t)nU * k), XW(ctx, (size_t)nI * k), C(ctx, (size_t)k * k), part(ctx, (size_t)NMF_GRAM_BLOCKS * k * k);
+    DevBuf<double> spart(ctx, (size_t)std::max(cu.n, ci.n) * k + 1);
     h2d(ctx, H.get(), H_host, (size_t)nU * k);
     h2d(ctx, W.get(), W_host, (size_t)nI * k);
     double* h = H.get();
@@ -223,7 +286,9 @@ void nmf_factorize(Context* ctx, const fy_nmf_params* prm, const fy_ratings* R, 
     const int f = prm->normalization_frequency;
     for (int32_t it = 1; it <= prm->number_of_iterations; it++) {
         // H2 from (H, W)
-        k_nmf_spmm<<<grid_for((int64_t)nU * 64, 256), 256, 0, s>>>(nU, k, uptr.get(), ku_s.get(), vu.get(), w, XH.get());
+        k_nmf_spmm_chunks<<<grid_for((int64_t)cu.n * 64, 256), 256, 0, s>>>(cu.n, k, cu.row.get(), cu.ptr.get(), uptr.get(), ku_s.get(), vu.get(), w, spart.get());
+        FY_KERNEL_CHECK();
+        k_nmf_spmm_reduce<<<grid_for((int64_t)nU * k), 256, 0, s>>>(nU, k, cu.ptr.get(), spart.get(), XH.get());
         FY_KERNEL_CHECK();
         k_nmf_gram_partial<<<NMF_GRAM_BLOCKS, 256, 0, s>>>(nI, k, w, part.get());
         FY_KERNEL_CHECK();
@@ -233,7 +298,9 @@ void nmf_factorize(Context* ctx, const fy_nmf_params* prm, const fy_ratings* R, 
         k_nmf_update<<<grid_for((int64_t)nU * 64, 256), 256, 0, s>>>(nU, k, h, XH.get(), C.get(), prm->ppc ? 1 : 0, normalize, h2);
         FY_KERNEL_CHECK();
         // W2 from the same (H, W)
-        k_nmf_spmm<<<grid_for((int64_t)nI * 64, 256), 256, 0, s>>>(nI, k, iptr.get(), ki_s.get(), vi.get(), h, XW.get());
+        k_nmf_spmm_chunks<<<grid_for((int64_t)ci.n * 64, 256), 256, 0, s>>>(ci.n, k, ci.row.get(), ci.ptr.get(), iptr.get(), ki_s.get(), vi.get(), h, spart.get());
+        FY_KERNEL_CHECK();
+        k_nmf_spmm_reduce<<<grid_for((int64_t)nI * k), 256, 0, s>>>(nI, k, ci.ptr.get(), spart.get(), XW.get());
         FY_KERNEL_CHECK();
         k_nmf_gram_partial<<<NMF_GRAM_BLOCKS, 256, 0, s>>>(nU, k, h, part.get());
         FY_KERNEL_CHECK();
