@@ -223,7 +223,7 @@ __global__ void k_cluster_item_keys(int64_t n, const uint64_t* __restrict__ ukey
 
 __global__ void k_scatter_pairs(int64_t n, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ head,
                                 const uint32_t* __restrict__ pr1, int32_t* __restrict__ pair_cluster,
-                                int32_t* __restrict__ pair_item, int32_t* __restrict__ pair_start, int32_t* __restrict__ pcount, int ib) {
+                                int32_t* __restrict__ pair_item, int32_t* __restrict__ pair_start, int ib) {
     const uint64_t mask = ((uint64_t)1 << ib) - 1;
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x)
         if (head[t]) {
@@ -232,16 +232,24 @@ __global__ void k_scatter_pairs(int64_t n, const uint64_t* __restrict__ keys, co
             pair_cluster[p] = c;
             pair_item[p] = (int32_t)(uint32_t)(keys[t] & mask);
             pair_start[p] = (int32_t)t;
-            // one atomic per wave when all its heads sit in one cluster (always, with a single cluster)
-            const unsigned long long act = __ballot(1);
-            const int c0 = __shfl(c, __ffsll((long long)act) - 1, 64);
-            const unsigned long long same = __ballot(c == c0);
-            if (same == act) {
-                if ((int)(threadIdx.x & 63) == __ffsll((long long)act) - 1) atomicAdd(&pcount[c0], (int)__popcll(act));
-            } else {
-                atomicAdd(&pcount[c], 1);
-            }
         }
+}
+
+// pairs are cluster-major: pairs of cluster c = [first pair with cluster >= c, first pair with cluster >= c + 1).  (Counting
+// them with one atomic per pair -- 59 k atomics on ONE address for a single cluster -- took 0.6 ms.)
+__global__ void k_cluster_pair_counts(int32_t K, int32_t nP, const int32_t* __restrict__ pair_cluster, int32_t* __restrict__ pcount) {
+    for (int32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < K; c += gridDim.x * blockDim.x) {
+        int32_t b[2];
+        for (int x = 0; x < 2; x++) {
+            int32_t lo = 0, hi = nP;
+            while (lo < hi) {
+                const int32_t mid = (lo + hi) >> 1;
+                if (pair_cluster[mid] < c + x) lo = mid + 1; else hi = mid;
+            }
+            b[x] = lo;
+        }
+        pcount[c] = b[1] - b[0];
+    }
 }
 
 __global__ void k_item_keys_of_pairs(int32_t nP, const int32_t* __restrict__ pair_item, uint64_t* __restrict__ keys,
@@ -464,9 +472,10 @@ void build_structure(Context* ctx, const fy_ratings* R, int32_t K, int64_t n_map
     P.pair_cluster.alloc(ctx, nP);
     P.pair_start.alloc(ctx, (size_t)nP + 1);
     DevBuf<int32_t> pair_item(ctx, nP), pcount(ctx, (size_t)K);
-    pcount.zero();
     k_scatter_pairs<<<grid_for(nnz), 256, 0, st>>>(nnz, k3b.get(), head.get(), pr1.get(), P.pair_cluster.get(),
-                                                    pair_item.get(), P.pair_start.get(), pcount.get(), ib);
+                                                    pair_item.get(), P.pair_start.get(), ib);
+    FY_KERNEL_CHECK();
+    k_cluster_pair_counts<<<grid_for(K), 256, 0, st>>>(K, nP, P.pair_cluster.get(), pcount.get());
     FY_KERNEL_CHECK();
     const int32_t last_pair = (int32_t)nnz;   // must outlive the copy (synchronised just below)
     h2d(ctx, P.pair_start.get() + nP, &last_pair, 1);

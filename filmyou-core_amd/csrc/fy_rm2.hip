@@ -281,21 +281,52 @@ __global__ void k_seg_counts(const int32_t* __restrict__ csc_slot, const int32_t
     }
 }
 
+// One wave fills the segments of 64 consecutive CSC entries of one chunk cooperatively: the group's segments are
+// contiguous in the table (exclusive prefix `ptr`), lane l writes segment base + l, base + l + 64, ... after finding its
+// owner among the 64 entries with a binary search over shuffled prefix values -- every store of the 3 GB table is
+// coalesced (one thread per entry writing its own run of segments reached 1.1 TB/s).
 __global__ void k_seg_fill(const int32_t* __restrict__ csc_slot, const float* __restrict__ csc_w, const int32_t* __restrict__ chunk_off,
                            int32_t slot_base, int32_t q0, int32_t nq, int32_t nch, const int32_t* __restrict__ ptr,
                            int2* __restrict__ seg, float* __restrict__ seg_w) {
-    for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
-        const int32_t* co = chunk_off + (int64_t)(csc_slot[q0 + q] - slot_base) * (nch + 1);
-        const float w = csc_w[q0 + q];
-        int32_t f0 = co[0];
-        for (int32_t ch = 0; ch < nch; ch++) {
-            const int32_t f1 = co[ch + 1];
-            int32_t k = ptr[(int64_t)ch * (nq + 1) + q];
-            for (int32_t f = f0; f < f1; f += 64, k++) {
-                seg[k] = make_int2(f, min(64, f1 - f));
-                seg_w[k] = w;
+    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    const int64_t n_groups = ((int64_t)nq + 63) >> 6;
+    const int64_t total_work = n_groups * nch;
+    for (int64_t gw = blockIdx.x * (int64_t)wpb + (threadIdx.x >> 6); gw < total_work; gw += (int64_t)gridDim.x * wpb) {
+        const int32_t ch = (int32_t)(gw / n_groups);
+        const int64_t g = gw - (int64_t)ch * n_groups;
+        const int64_t q = g * 64 + lane;
+        int32_t f0 = 0, len = 0, start = 0;
+        float w = 0.0f;
+        const int32_t* __restrict__ pp = ptr + (int64_t)ch * (nq + 1);
+        if (q < nq) {
+            const int32_t* co = chunk_off + (int64_t)(csc_slot[q0 + q] - slot_base) * (nch + 1) + ch;
+            f0 = co[0];
+            len = co[1] - f0;
+            w = csc_w[q0 + q];
+            start = pp[q];
+        }
+        const int32_t base = __shfl(start, 0, 64);
+        const int64_t q_end = min((int64_t)nq, g * 64 + 64);
+        const int32_t total = pp[q_end] - base;             // segments of the whole group
+        if (q >= nq) start = base + total;                    // inactive lanes sit behind the last segment
+        const int32_t rel = start - base;
+        for (int32_t kk = 0; kk < total; kk += 64) {         // wave-uniform trip count: the shuffles need every lane alive
+            const int32_t k = kk + lane;
+            int lo = 0, hi = 63;                              // largest lane j with rel_j <= k (rel is non-decreasing)
+#pragma unroll
+            for (int it = 0; it < 6; it++) {
+                const int mid = (lo + hi + 1) >> 1;
+                const int32_t rm = __shfl(rel, mid, 64);
+                if (rm <= k) lo = mid; else hi = mid - 1;
             }
-            f0 = f1;
+            // entries with zero segments share their rel with the next entry: the owner is the LAST lane with rel <= k
+            const int32_t off = k - __shfl(rel, lo, 64);
+            const int32_t of0 = __shfl(f0, lo, 64), olen = __shfl(len, lo, 64);
+            const float ow = __shfl(w, lo, 64);
+            if (k < total) {
+                seg[base + k] = make_int2(of0 + 64 * off, min(64, olen - 64 * off));
+                seg_w[base + k] = ow;
+            }
         }
     }
 }
@@ -315,7 +346,7 @@ void build_segments(Context* ctx, const int32_t* csc_slot, const float* csc_w, c
     out.seg.alloc(ctx, (size_t)total);
     out.w.alloc(ctx, (size_t)total);
     if ((int64_t)nch * nq > 0) {
-        k_seg_fill<<<grid_for((int64_t)nq), 256, 0, st>>>(csc_slot, csc_w, chunk_off, slot_base, q0, nq, nch, out.ptr.get(),
+        k_seg_fill<<<grid_for((((int64_t)nq + 63) >> 6) * nch * 64, 256, 256 * 64), 256, 0, st>>>(csc_slot, csc_w, chunk_off, slot_base, q0, nq, nch, out.ptr.get(),
                                                                  out.seg.get(), out.w.get());
         FY_KERNEL_CHECK();
     }
