@@ -517,6 +517,7 @@ struct ScoreTune {
     int hot_lds = 0;                   // k_score_hot: the 128 most popular rows of a chunk stay in LDS (slower: 16 waves/CU)
     int hot_min_items = 2048;
     int64_t tile_bytes = (int64_t)1 << 40;   // M[row block][chunk] tile; default: one row block (sweep r1)
+    int seed_forced = 0;               // FY_SEED_CHUNKS given: prune whatever the list length (tests)
     int coop = 1;                      // cooperative scoring of clusters that span all ranks (needs fy_collectives)
     int coop_force = 0;                // test hook: cooperative path also with world == 1 (identity collectives)
     int cooc_pk = 1;                   // packed 4-byte CSR entries for the row kernel when the ratings are fp16-exact
@@ -537,7 +538,7 @@ static ScoreTune score_tune() {
     if (const char* e = getenv("FY_COOP_FORCE")) t.coop_force = atoi(e) != 0;
     if (const char* e = getenv("FY_COOC_PK")) t.cooc_pk = atoi(e) != 0;
     if (const char* e = getenv("FY_PRUNE_MIN_ITEMS")) t.prune_min_items = atoi(e);
-    if (const char* e = getenv("FY_SEED_CHUNKS")) { int v = atoi(e); if (v >= 0 && v <= 4) t.seed_chunks = v; }
+    if (const char* e = getenv("FY_SEED_CHUNKS")) { int v = atoi(e); if (v >= 0 && v <= 4) { t.seed_chunks = v; t.seed_forced = v > 0; } }
     if (const char* e = getenv("FY_WORKSPACE_GB")) { long v = atol(e); if (v >= 1) t.workspace_default = (int64_t)v << 30; }
     if (const char* e = getenv("FY_LANES")) { int v = atoi(e); if (v >= 1 && v <= 8) t.lanes = v; }
     if (const char* e = getenv("FY_COOC_DEBUG")) t.cooc_debug = atoi(e);
@@ -697,7 +698,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
         if (nonempty == 1) {   // one neighbourhood: it is scored cooperatively when it is big enough for the branch and bound
             const int32_t Ic1 = P.pcstart[c1 + 1] - P.pcstart[c1];
             J->count_balanced = Ic1 >= tune.pack24_min_items && Ic1 >= tune.prune_min_items && ceil_div(Ic1, PRUNE_BLOCK) < 0xFFFF &&
-                                P.nU >= prm.world;
+                                P.nU >= prm.world && (tune.seed_forced || 5 * (int64_t)prm.number_of_recommendations <= 4 * 256);
         }
     }
     int32_t own_lo, own_hi;
@@ -781,7 +782,10 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             // branch-and-bound over 256-column blocks: only where the matrix is big enough for the bound pass to pay
             p.nblk = (int32_t)ceil_div(p.Ic, PRUNE_BLOCK);
             p.ldb = round_up(p.nblk, 256);
-            p.prune = tune.prune && p.pack24 && p.nrb == 1 && !p.use_hot && p.Ic >= tune.prune_min_items && p.nblk < 0xFFFF;
+            // (the threshold is the N-th best of at most 1024 seed scores: for lists longer than ~200 items it is too weak --
+            // N = 1000 at ML-25M shape: 77 % of the blocks survive and the three passes cost twice the plain one)
+            p.prune = tune.prune && p.pack24 && p.nrb == 1 && !p.use_hot && p.Ic >= tune.prune_min_items && p.nblk < 0xFFFF &&
+                      (tune.seed_forced || 5 * (int64_t)prm.number_of_recommendations <= 4 * 256);
             if (J->count_balanced && !p.prune) FY_FAIL(FY_ERR_STATE, "internal: count-balanced ownership without a cooperative cluster");
             // all ranks hold users of this cluster and can talk to each other: score it together, every rank with its
             // share of the matrix rows (score_cluster_coop)
