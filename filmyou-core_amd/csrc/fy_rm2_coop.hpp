@@ -159,7 +159,7 @@ static void score_cluster_coop(const CoopShared& X, const Plan& p, hipStream_t l
     FY_KERNEL_CHECK();
     if (me != 0) FY_HIP(hipMemsetAsync(pv_all.get(), 0, (size_t)Uc * sizeof(double), ls));   // pvpi enters the sum once
 
-    const size_t ss = X.t_score->begin(ls);
+    size_t ss = X.t_score->begin(ls);   // the spans of ms_score cover this rank's kernels, not the waits inside the collectives
     auto slices_for = [&](int32_t nb) { return (int)std::max<int64_t>(1, std::min<int64_t>(tune.max_slices, ceil_div(nb, 4 * tune.users_per_wave))); };
     // ---- (1) partial seed scores of every user, owner by owner; (2) reduce-scatter; (3) tau + the speculative lists
     for (int k = 0; k < W; k++) {
@@ -173,7 +173,9 @@ static void score_cluster_coop(const CoopShared& X, const Plan& p, hipStream_t l
         FY_KERNEL_CHECK();
         R->st.score_launches++;
     }
+    X.t_score->end(ss, ls);
     coll_reduce_scatter(J, seed_send.get(), seed.get(), (int64_t)Umax * SC, ls);
+    ss = X.t_score->begin(ls);
     if (n_mine > 0) {
         TopNArgs T1{seed.get(), SC, Ic, X.n_out, X.out_off, P.rank_item_raw.get() + pbase, P.slot2du.get(), P.uid.get(),
                     X.lo, my_a, p.c, R->d_key0.get(), R->d_key1.get(), R->d_value.get(), R->d_aux.get(),
@@ -193,7 +195,9 @@ static void score_cluster_coop(const CoopShared& X, const Plan& p, hipStream_t l
         FY_KERNEL_CHECK();
         R->st.score_launches++;
     }
+    X.t_score->end(ss, ls);
     coll_reduce_scatter(J, ub_send.get(), UBsum.get(), (int64_t)Umax * ldb, ls);
+    ss = X.t_score->begin(ls);
     FY_HIP(hipMemsetAsync(n_quads.get(), 0, ((size_t)Umax + 1) * sizeof(int32_t), ls));
     if (n_mine > 0) {
         k_bound_select<<<grid_for((int64_t)n_mine * 64, 256), 256, 0, ls>>>(UBsum.get(), ldb, p.nblk, seed_blocks, tau.get(), n_mine,
@@ -204,7 +208,9 @@ static void score_cluster_coop(const CoopShared& X, const Plan& p, hipStream_t l
     // ---- (6) everybody learns everybody's survivors
     DevBuf<int32_t> my_count(ctx, 1);
     FY_HIP(hipMemcpyAsync(my_count.get(), quad_prefix.get() + n_mine, sizeof(int32_t), hipMemcpyDeviceToDevice, ls));
+    X.t_score->end(ss, ls);
     coll_all_gather(J, my_count.get(), counts.get(), sizeof(int32_t), ls);
+    ss = X.t_score->begin(ls);
     std::vector<int32_t> hcounts((size_t)W);
     FY_HIP(hipMemcpyAsync(hcounts.data(), counts.get(), (size_t)W * sizeof(int32_t), hipMemcpyDeviceToHost, ls));
     FY_HIP(hipStreamSynchronize(ls));
@@ -220,14 +226,18 @@ static void score_cluster_coop(const CoopShared& X, const Plan& p, hipStream_t l
             k_surv_entries<<<grid_for((int64_t)n_mine * 64, 256), 256, 0, ls>>>(n_mine, my_a, quad_prefix.get(), surv.get(), ldb, entries.get());
             FY_KERNEL_CHECK();
         }
+        X.t_score->end(ss, ls);
         coll_all_gather(J, entries.get(), entries_all.get(), (int64_t)t_max * (int64_t)sizeof(long long), ls);
+        ss = X.t_score->begin(ls);
         // ---- (7) partial exact scores of all survivors over my rows, reduce-scatter to the owners
         k_score_entries<8><<<ctx->num_cus * 8, 256, 0, ls>>>(Mshift, X.a_rank + pbase, my_rowptr.get(), my_idx.get(), my_e.get(), pv_all.get(),
                                                              entries_all.get(), counts.get(), W, t_max, sbase, Ic, ldm, W, me, Spart.get(),
                                                              X.prune_counters);
         FY_KERNEL_CHECK();
         R->st.score_launches++;
+        X.t_score->end(ss, ls);
         coll_reduce_scatter(J, Spart.get(), Ssurv.get(), (int64_t)t_max * PRUNE_BLOCK, ls);
+        ss = X.t_score->begin(ls);
         FY_HIP(hipStreamSynchronize(ls));   // entries / Spart are released here
     }
     X.t_score->end(ss, ls);
