@@ -361,7 +361,7 @@ struct MEpilogue {
     double w2;    // (1-l)^2
     double w1;    // l (1-l)
     int pack24;   // 3 bytes per element: 8 exponent + 16 mantissa bits of the (non-negative) fp32, rounded to nearest
-    float* __restrict__ Bmax;   // optional [row][ldb]: maximum of the (rounded) row over every 64-column block
+    float* __restrict__ Bmax;   // optional [row][ldb]: maximum of the (rounded) row over every 256-column block
     int64_t ldb;
     int local_rows;   // 1: M / Bmax hold only this launch's rows, k-th row of the launch at index k (cooperative ranks)
 };
@@ -506,7 +506,7 @@ struct ScoreTune {
     int users_per_wave = 16;           // users a wave of the scoring kernel walks for one column chunk
     int64_t workspace_default = (int64_t)16 << 30;   // score scratch per batch of users
     int lanes = 4;                     // HIP streams the clusters of one job are spread over
-    int prune = 1;                     // branch and bound over 64-column candidate blocks
+    int prune = 1;                     // branch and bound over 256-column candidate blocks
     int prune_min_items = 8192;
     int seed_chunks = 0;               // 256-column chunks scored exactly before the bound pass (the most popular candidates);
                                        // 0 = from the list length: ~5 N columns (N = 50: one chunk, N = 100: two), at most four
@@ -980,7 +980,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                                 1, seed_chunks * 256, L.surv.get(), L.n_quads.get(), p.ldb, L.tau.get()};
                     k_topn_fast<<<nb, 256, 0, ls>>>(T1, L.overflow.get(), L.any_overflow.get(), 0);
                     FY_KERNEL_CHECK();
-                    // (3) upper bounds of all 64-column blocks: the scoring kernel on the block-maximum matrix
+                    // (3) upper bounds of all 256-column blocks: the scoring kernel on the block-maximum matrix
                     const int bchunks = (int)(p.ldb / 256);
                     FY_HIP(hipMemsetAsync(L.n_quads.get(), 0, ((size_t)nb + 1) * sizeof(int32_t), ls));
                     ScoreArgs SB_{L.Bmax.get(), p.ldb, p.nblk, L.amax.get(), L.rb_off.get(), P.csr_idx.get(), csr_e.get(), pvpi.get(),

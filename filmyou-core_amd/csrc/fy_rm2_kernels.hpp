@@ -367,7 +367,7 @@ struct TopNArgs {
     int32_t* __restrict__ out_item;
     float* __restrict__ out_score;
     int32_t* __restrict__ out_cluster;
-    // branch and bound (fy_rm2.hip, "exact pruning"): only the seed columns and the surviving 64-column blocks of a score row
+    // branch and bound (fy_rm2.hip, "exact pruning"): only the seed columns and the surviving 256-column blocks of a score row
     // are ever written.  mode 0: the whole row is live.  mode 1 (seed phase): sort the seed columns, publish tau_u and the
     // list the user gets if no block survives.  mode 2 (merge phase): users with surviving blocks only, seed + survivors.
     int32_t mode;
@@ -539,7 +539,7 @@ __global__ __launch_bounds__(256) void k_topn_select(TopNArgs A, const int32_t* 
     if (K == 0) return;
     const float* __restrict__ row = A.S + (int64_t)u * A.ldS;
     const int tid = threadIdx.x;
-    // pruned rows: only the seed columns and the surviving 64-column blocks were ever written
+    // pruned rows: only the seed columns and the surviving 256-column blocks were ever written
     __shared__ uint32_t live[2048];
     __shared__ uint16_t live_pre[2048];   // cooperative ranks: surviving blocks in front of word w (position in the packed scores)
     if (A.mode) {
@@ -680,10 +680,10 @@ __global__ __launch_bounds__(256) void k_topn_select(TopNArgs A, const int32_t* 
 }
 
 // ================================================================ exact pruning of candidate blocks (branch and bound)
-// For a block B of 64 candidate columns,
+// For a block B of 256 candidate columns,
 //     UB(u, B) = pvpi + sum_{j in rated(u)} ln( max_{i in B} M[j][i] + (max_{i in B} a_i) * e_uj )  >=  score(u, i)  for all i in B,
 // because every term is monotone in M[j][i] and a_i.  Evaluating UB is the scoring kernel itself run on the reduced
-// matrix Bmax[j][B] (1/64 of the columns).  With tau_u = the N-th best EXACT score among the first `seed` (most
+// matrix Bmax[j][B] (1/256 of the columns).  With tau_u = the N-th best EXACT score among the first `seed` (most
 // popular) columns, a block whose UB is below tau_u cannot contribute to the user's top N and is skipped; the exact
 // kernel then runs only on the surviving (user, block) pairs.  RM2 scores fall steeply with candidate popularity, so on
 // MovieLens-shaped data well under 1 % of the tail blocks survive -- the lists are bit-for-bit those of the full pass.

@@ -207,7 +207,7 @@ typedef struct {
     double ms_total;
     int64_t score_launches;    /* launches of the scoring kernels */
     int64_t cooc_launches;
-    int64_t blocks_total;        /* RM2 branch and bound: (user, 64-column block) pairs behind the seed columns ... */
+    int64_t blocks_total;        /* RM2 branch and bound: (user, 256-column block) pairs behind the seed columns ... */
     int64_t blocks_survived;     /* ... and how many of them had to be scored exactly */
     int64_t log_terms_evaluated; /* log terms actually evaluated (seed + bound + survivor passes); 0 = no pruning: log_terms */
 } fy_stats;
