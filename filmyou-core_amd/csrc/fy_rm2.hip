@@ -361,7 +361,8 @@ struct MEpilogue {
     double w2;    // (1-l)^2
     double w1;    // l (1-l)
     int pack24;   // 3 bytes per element: 8 exponent + 16 mantissa bits of the (non-negative) fp32, rounded to nearest
-    float* __restrict__ Bmax;   // optional [row][ldb]: maximum of the (rounded) row over every 256-column block
+    float* __restrict__ Bmax;   // optional [row][ldb] in the 24-bit packed format (3 bytes per entry): maximum of the (rounded) row
+                                // over every 256-column block
     int64_t ldb;
     int local_rows;   // 1: M / Bmax hold only this launch's rows, k-th row of the launch at index k (cooperative ranks)
 };
@@ -422,7 +423,16 @@ __global__ void k_cooc_rm2(CoocArgs A, MEpilogue E, int n_items, int* __restrict
                     for (int q = 0; q < 4; q++) m = fmaxf(m, __uint_as_float((v[q] << 8) >> 1));
 #pragma unroll
                     for (int o = 1; o < 64; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-                    if ((threadIdx.x & 63) == 0) E.Bmax[(int64_t)mrow * E.ldb + (c4 >> 6)] = m;
+                    if ((threadIdx.x & 63) == 0) {
+                        // the maximum of 24-bit values is itself one: Bmax is stored in the same packed format (3 bytes per
+                        // block, byte stores: the four blocks of a packed group belong to different waves or chunks), so
+                        // the bound pass streams 768 instead of 1024 bytes per rated item
+                        const uint32_t pv = (__float_as_uint(m) << 1) >> 8;
+                        uint8_t* bp = reinterpret_cast<uint8_t*>(E.Bmax) + ((int64_t)mrow * E.ldb + (c4 >> 6)) * 3;
+                        bp[0] = (uint8_t)pv;
+                        bp[1] = (uint8_t)(pv >> 8);
+                        bp[2] = (uint8_t)(pv >> 16);
+                    }
                 }
             }
         } else {
@@ -921,7 +931,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             MEpilogue ME{L.M.get(), ldm, p_rank.get() + pbase, b_rank.get() + pbase, (1.0 - lambda) * (1.0 - lambda), lambda * (1.0 - lambda),
                          pack24 ? 1 : 0, p.prune ? L.Bmax.get() : nullptr, p.ldb};
             if (p.prune) {
-                FY_HIP(hipMemsetAsync(L.Bmax.get(), 0, (size_t)Ic * p.ldb * sizeof(float), ls));
+                FY_HIP(hipMemsetAsync(L.Bmax.get(), 0, (size_t)Ic * p.ldb * 3, ls));
                 k_block_amax<<<grid_for(p.ldb), 256, 0, ls>>>(Ic, (int32_t)p.ldb, a_rank.get() + pbase, L.amax.get());
                 FY_KERNEL_CHECK();
             }
@@ -969,10 +979,22 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                     const int seed_blocks = seed_chunks;
                     const int64_t SC = (int64_t)seed_chunks * 256;   // pitch of the compact score rows: seed columns only
                     // only the seed columns and the surviving blocks of a score row are ever written or read
-                    // (1) exact scores of the seed columns (the most popular candidates)
+                    // (1) + (3) ONE launch: exact scores of the seed columns (the most popular candidates) and the upper bounds
+                    // of all 256-column blocks (the same kernel on the block-maximum matrix); the grid's tail -- the waves
+                    // that walk the heaviest users -- is paid once instead of twice (tune.fuse_bound = 0: two launches)
+                    const int bchunks = (int)(p.ldb / 256);
                     ScoreArgs SA{L.M.get(), ldm, Ic, a_rank.get() + pbase, L.rb_off.get(), P.csr_idx.get(), csr_e.get(), pvpi.get(),
                                  n_out.get(), lo, sbase, s0, nb, L.S.get(), SC, n_slices, 0, 1, 0, 0, seed_chunks, 0, nullptr, nullptr, nullptr, 0};
-                    k_score<4, true, 8><<<seed_chunks * n_slices, 256, 0, ls>>>(SA.M, SA.a_rank, SA.rb_off, SA.csr_idx, SA.csr_e, SA.pvpi, SA.n_out, SA.S, SA);
+                    SA.chunks1 = seed_chunks;
+                    SA.M2 = L.Bmax.get();
+                    SA.ldm2 = p.ldb;
+                    SA.Ic2 = p.nblk;
+                    SA.a2 = L.amax.get();
+                    SA.S2 = L.UB.get();
+                    SA.ldS2 = p.ldb;
+                    SA.no_mask2 = 2;
+                    SA.n_chunks = seed_chunks + bchunks;
+                    k_score<4, true, 8><<<(seed_chunks + bchunks) * n_slices, 256, 0, ls>>>(SA.M, SA.a_rank, SA.rb_off, SA.csr_idx, SA.csr_e, SA.pvpi, SA.n_out, SA.S, SA);
                     FY_KERNEL_CHECK();
                     // (2) tau_u = N-th best seed score; the sorted seed head is also the user's list unless a block survives
                     TopNArgs T1{L.S.get(), SC, Ic, n_out.get(), out_off.get(), P.rank_item_raw.get() + pbase, P.slot2du.get(), P.uid.get(),
@@ -980,15 +1002,11 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                                 1, seed_chunks * 256, L.surv.get(), L.n_quads.get(), p.ldb, L.tau.get()};
                     k_topn_fast<<<nb, 256, 0, ls>>>(T1, L.overflow.get(), L.any_overflow.get(), 0);
                     FY_KERNEL_CHECK();
-                    // (3) upper bounds of all 256-column blocks: the scoring kernel on the block-maximum matrix
-                    const int bchunks = (int)(p.ldb / 256);
+                    // (4) the blocks whose bound reaches tau_u, in ascending order
                     FY_HIP(hipMemsetAsync(L.n_quads.get(), 0, ((size_t)nb + 1) * sizeof(int32_t), ls));
-                    ScoreArgs SB_{L.Bmax.get(), p.ldb, p.nblk, L.amax.get(), L.rb_off.get(), P.csr_idx.get(), csr_e.get(), pvpi.get(),
-                                  n_out.get(), lo, sbase, s0, nb, L.UB.get(), p.ldb, n_slices, 0, 1, 0, 0, bchunks, 1,
-                                  L.tau.get(), L.surv.get(), L.n_quads.get(), seed_blocks};
-                    k_score<4, false, 8><<<bchunks * n_slices, 256, 0, ls>>>(SB_.M, SB_.a_rank, SB_.rb_off, SB_.csr_idx, SB_.csr_e, SB_.pvpi, SB_.n_out, SB_.S, SB_);
+                    k_bound_select<<<grid_for((int64_t)nb * 64, 256), 256, 0, ls>>>(L.UB.get(), p.ldb, p.nblk, seed_blocks, L.tau.get(), nb,
+                                                                                   L.surv.get(), L.n_quads.get());
                     FY_KERNEL_CHECK();
-                    // (4) the bound pass appended the surviving blocks to surv / n_quads itself
                     exclusive_scan_i32(ctx, L.n_quads.get(), L.quad_prefix.get(), (size_t)nb + 1, ls);
                     // (5) exact scores of the survivors, packed: 256 floats per surviving block at entry quad_prefix[u] + k
                     int32_t n_surv_total = 0;

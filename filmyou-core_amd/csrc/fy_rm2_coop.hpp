@@ -119,7 +119,7 @@ static void score_cluster_coop(const CoopShared& X, const Plan& p, hipStream_t l
             FY_KERNEL_CHECK();
         }
         build_segments(ctx, my_slot.get(), my_w.get(), co_tmp.get(), sbase, 0, (int32_t)my_ratings, nch, seg, ls);
-        FY_HIP(hipMemsetAsync(Bloc.get(), 0, (size_t)std::max<int64_t>(1, (int64_t)nrows * ldb) * sizeof(float), ls));
+        FY_HIP(hipMemsetAsync(Bloc.get(), 0, (size_t)std::max<int64_t>(1, (int64_t)nrows * ldb) * 3, ls));
         k_block_amax<<<grid_for(ldb), 256, 0, ls>>>(Ic, (int32_t)ldb, X.a_rank + pbase, amax.get());
         FY_KERNEL_CHECK();
         if (nrows > 0) {
@@ -191,7 +191,7 @@ static void score_cluster_coop(const CoopShared& X, const Plan& p, hipStream_t l
         ScoreArgs SB_{Bshift, ldb, p.nblk, amax.get(), my_rowptr.get(), my_idx.get(), my_e.get(), pv_all.get(), n_out_all.get(),
                       sbase, sbase, ua[k], nk, ub_send.get() + (int64_t)k * Umax * ldb, ldb, ns, 0, 0, 0, 0, bchunks, 2,
                       nullptr, nullptr, nullptr, seed_blocks, W, me};
-        k_score<4, false, 8><<<bchunks * ns, 256, 0, ls>>>(SB_.M, SB_.a_rank, SB_.rb_off, SB_.csr_idx, SB_.csr_e, SB_.pvpi, SB_.n_out, SB_.S, SB_);
+        k_score<4, true, 8><<<bchunks * ns, 256, 0, ls>>>(SB_.M, SB_.a_rank, SB_.rb_off, SB_.csr_idx, SB_.csr_e, SB_.pvpi, SB_.n_out, SB_.S, SB_);
         FY_KERNEL_CHECK();
         R->st.score_launches++;
     }

@@ -46,6 +46,15 @@ struct ScoreArgs {
     // cooperative ranks: csr_idx holds LOCAL row indices of M (k-th row of the rank); the item it stands for is
     // k * row_mul + row_add (row_mul == 0: the index is the item itself)
     int32_t row_mul, row_add;
+    // fused launch: chunks [chunks1, n) of the grid work on a second matrix (the block maxima), results stored like scores
+    int32_t chunks1;                       // 0 = single matrix
+    const float* __restrict__ M2;
+    int64_t ldm2;
+    int32_t Ic2;
+    const float* __restrict__ a2;
+    float* __restrict__ S2;
+    int64_t ldS2;
+    int32_t no_mask2;
 };
 
 __device__ __forceinline__ float fy_log2(float x) { return __builtin_amdgcn_logf(x); }   // v_log_f32
@@ -126,14 +135,22 @@ __global__ __launch_bounds__(256) void k_score(const float* __restrict__ M_, con
         slice = t % A.n_slices;
         if (chunk >= A.n_chunks) return;
     }
+    // fused seed + bound launch (one grid, one tail): the chunks behind the first `chunks1` belong to a second matrix
+    const bool second = A.chunks1 > 0 && chunk >= A.chunks1;
+    if (second) chunk -= A.chunks1;
+    const float* __restrict__ Msel = second ? A.M2 : M_;
+    const float* __restrict__ asel = second ? A.a2 : a_rank_;
+    float* __restrict__ Ssel = second ? A.S2 : S_;
+    const int64_t ldm_sel = second ? A.ldm2 : A.ldm, ldS_sel = second ? A.ldS2 : A.ldS;
+    const int Ic_sel = second ? A.Ic2 : A.Ic, no_mask = second ? A.no_mask2 : A.no_mask;
     const int col0 = chunk * CW;
     const int col = col0 + lane * VEC;
     float a[VEC];
 #pragma unroll
-    for (int v = 0; v < VEC; v++) a[v] = col + v < A.Ic ? a_rank_[col + v] : 0.0f;
+    for (int v = 0; v < VEC; v++) a[v] = col + v < Ic_sel ? asel[col + v] : 0.0f;
     // byte address of this lane's part of row 0; the row pitch is ldm * (P24 ? 3 : 4) bytes
-    const char* __restrict__ Mcol = reinterpret_cast<const char*>(M_) + (int64_t)col * (P24 ? 3 : 4);
-    const int64_t pitch = A.ldm * (P24 ? 3 : 4);
+    const char* __restrict__ Mcol = reinterpret_cast<const char*>(Msel) + (int64_t)col * (P24 ? 3 : 4);
+    const int64_t pitch = ldm_sel * (P24 ? 3 : 4);
     const double LN2 = 0.69314718055994530942;
     const float qnan = __builtin_nanf("");
     const bool first = A.rb == 0;
@@ -145,7 +162,7 @@ __global__ __launch_bounds__(256) void k_score(const float* __restrict__ M_, con
         const int32_t* __restrict__ ro = rb_off_ + (int64_t)(slot - A.slot_base) * stride + A.rb;
         const int beg = ro[0], end = ro[1];
         if (!first && beg == end) continue;
-        float* __restrict__ dst = S_ + (int64_t)u * A.ldS + col;
+        float* __restrict__ dst = Ssel + (int64_t)u * ldS_sel + col;
         V old;
         if (!first) old = *reinterpret_cast<const V*>(dst);      // issued early: its latency hides under the row loads
         double t[VEC];
@@ -183,7 +200,7 @@ __global__ __launch_bounds__(256) void k_score(const float* __restrict__ M_, con
 #pragma unroll
                     for (int v = 0; v < VEC; v++) p[v] += fy_log2(fmaf(a[v], e[q], gv[v]));
                     const unsigned d = (unsigned)(jj[q] * row_mul + A.row_add - col0);
-                    if (!A.no_mask && d < (unsigned)CW && (int)(d / VEC) == lane) mask |= 1u << (d % VEC);
+                    if (!no_mask && d < (unsigned)CW && (int)(d / VEC) == lane) mask |= 1u << (d % VEC);
                 }
             }
 #pragma unroll
@@ -202,8 +219,8 @@ __global__ __launch_bounds__(256) void k_score(const float* __restrict__ M_, con
         }
 #pragma unroll
         for (int v = 0; v < VEC; v++)
-            if ((mask >> v) & 1u || col + v >= A.Ic) ov[v] = qnan;
-        if (A.no_mask == 1) {
+            if ((mask >> v) & 1u || col + v >= Ic_sel) ov[v] = qnan;
+        if (no_mask == 1) {
             // bound pass: column = candidate block.  Keep the blocks behind the seed whose bound (plus a margin over the
             // rounding of both sums, each accurate to ~1e-7 relative) reaches tau_u.
             const float t = A.tau[u];
