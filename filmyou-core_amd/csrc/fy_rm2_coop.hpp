@@ -161,20 +161,30 @@ static void score_cluster_coop(const CoopShared& X, const Plan& p, hipStream_t l
 
     size_t ss = X.t_score->begin(ls);   // the spans of ms_score cover this rank's kernels, not the waits inside the collectives
     auto slices_for = [&](int32_t nb) { return (int)std::max<int64_t>(1, std::min<int64_t>(tune.max_slices, ceil_div(nb, 4 * tune.users_per_wave))); };
-    // ---- (1) partial seed scores of every user, owner by owner; (2) reduce-scatter; (3) tau + the speculative lists
+    // ---- (1) partial seed scores AND partial block bounds of every user in one launch per owner (one grid tail, see
+    // rm2_score); (2) two reduce-scatters; (3) tau + the speculative lists; (5) the owner keeps the blocks that reach tau
     for (int k = 0; k < W; k++) {
         const int32_t nk = ub[k] - ua[k];
         if (nk <= 0) continue;
         const int ns = slices_for(nk);
         ScoreArgs SA{Mshift, ldm, Ic, X.a_rank + pbase, my_rowptr.get(), my_idx.get(), my_e.get(), pv_all.get(), n_out_all.get(),
-                     sbase, sbase, ua[k], nk, seed_send.get() + (int64_t)k * Umax * SC, SC, ns, 0, 0, 0, 0, seed_chunks, 0,
+                     sbase, sbase, ua[k], nk, seed_send.get() + (int64_t)k * Umax * SC, SC, ns, 0, 0, 0, 0, seed_chunks + bchunks, 0,
                      nullptr, nullptr, nullptr, 0, W, me};
-        k_score<4, true, 8><<<seed_chunks * ns, 256, 0, ls>>>(SA.M, SA.a_rank, SA.rb_off, SA.csr_idx, SA.csr_e, SA.pvpi, SA.n_out, SA.S, SA);
+        SA.chunks1 = seed_chunks;
+        SA.M2 = Bshift;
+        SA.ldm2 = ldb;
+        SA.Ic2 = p.nblk;
+        SA.a2 = amax.get();
+        SA.S2 = ub_send.get() + (int64_t)k * Umax * ldb;
+        SA.ldS2 = ldb;
+        SA.no_mask2 = 2;
+        k_score<4, true, 8><<<(seed_chunks + bchunks) * ns, 256, 0, ls>>>(SA.M, SA.a_rank, SA.rb_off, SA.csr_idx, SA.csr_e, SA.pvpi, SA.n_out, SA.S, SA);
         FY_KERNEL_CHECK();
-        R->st.score_launches++;
+        R->st.score_launches += 2;
     }
     X.t_score->end(ss, ls);
     coll_reduce_scatter(J, seed_send.get(), seed.get(), (int64_t)Umax * SC, ls);
+    coll_reduce_scatter(J, ub_send.get(), UBsum.get(), (int64_t)Umax * ldb, ls);
     ss = X.t_score->begin(ls);
     if (n_mine > 0) {
         TopNArgs T1{seed.get(), SC, Ic, X.n_out, X.out_off, P.rank_item_raw.get() + pbase, P.slot2du.get(), P.uid.get(),
@@ -183,21 +193,6 @@ static void score_cluster_coop(const CoopShared& X, const Plan& p, hipStream_t l
         k_topn_fast<<<n_mine, 256, 0, ls>>>(T1, overflow.get(), any_overflow.get(), 0);
         FY_KERNEL_CHECK();
     }
-    // ---- (4) partial block bounds, reduce-scatter, (5) the owner keeps the blocks that reach tau
-    for (int k = 0; k < W; k++) {
-        const int32_t nk = ub[k] - ua[k];
-        if (nk <= 0) continue;
-        const int ns = slices_for(nk);
-        ScoreArgs SB_{Bshift, ldb, p.nblk, amax.get(), my_rowptr.get(), my_idx.get(), my_e.get(), pv_all.get(), n_out_all.get(),
-                      sbase, sbase, ua[k], nk, ub_send.get() + (int64_t)k * Umax * ldb, ldb, ns, 0, 0, 0, 0, bchunks, 2,
-                      nullptr, nullptr, nullptr, seed_blocks, W, me};
-        k_score<4, true, 8><<<bchunks * ns, 256, 0, ls>>>(SB_.M, SB_.a_rank, SB_.rb_off, SB_.csr_idx, SB_.csr_e, SB_.pvpi, SB_.n_out, SB_.S, SB_);
-        FY_KERNEL_CHECK();
-        R->st.score_launches++;
-    }
-    X.t_score->end(ss, ls);
-    coll_reduce_scatter(J, ub_send.get(), UBsum.get(), (int64_t)Umax * ldb, ls);
-    ss = X.t_score->begin(ls);
     FY_HIP(hipMemsetAsync(n_quads.get(), 0, ((size_t)Umax + 1) * sizeof(int32_t), ls));
     if (n_mine > 0) {
         k_bound_select<<<grid_for((int64_t)n_mine * 64, 256), 256, 0, ls>>>(UBsum.get(), ldb, p.nblk, seed_blocks, tau.get(), n_mine,
