@@ -1020,7 +1020,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                                                                             L.quad_prefix.get(), L.surv.get(), SQ.S, SQ, p.ldb, prune_counters.get());
                         FY_KERNEL_CHECK();
                     }
-                    R->st.score_launches += 3;
+                    R->st.score_launches += 2;   // the fused seed + bound launch and the survivor pass
                     prune_blocks_total += (int64_t)nb * std::max(0, p.nblk - seed_blocks);
                     {   // log terms of the seed and bound passes of this batch: (ratings of its users) x (columns walked)
                         int32_t r2[2];
