@@ -2,6 +2,7 @@
 #include <memory>
 #include <new>
 
+#include "fy_prep.hpp"
 #include "fy_rm2.hpp"
 
 namespace fy {
@@ -107,6 +108,7 @@ int fy_ratings_create(fy_context* c, int64_t nnz, const int32_t* user, const int
         FY_HIP(hipMemcpyAsync(r->item.get(), item, (size_t)nnz * 4, k, c->c.stream));
         FY_HIP(hipMemcpyAsync(r->score.get(), score, (size_t)nnz * 4, k, c->c.stream));
         FY_HIP(hipStreamSynchronize(c->c.stream));   // the caller may free its arrays when this returns
+        fy::ratings_id_bounds(&c->c, r.get());
     }
     *out = r.release();
     FY_CATCH

@@ -198,4 +198,7 @@ struct fy_ratings {
     int64_t nnz = 0;
     fy::DevBuf<int32_t> user, item;
     fy::DevBuf<float> score;
+    // largest user / item id over ALL entries (-1: none >= 0), found once when the ratings are put into HBM: the jobs pack
+    // their sort keys into the bits these ids need
+    int32_t max_user = -1, max_item = -1;
 };

@@ -85,7 +85,7 @@ __global__ void k_max_ids(int64_t n, const int32_t* __restrict__ user, const int
     int32_t mu = -1, mi = -1;
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
         const float s = score[t];
-        if (keep_nonpositive ? (s == s) : (s > 0.0f)) { mu = max(mu, user[t]); mi = max(mi, item[t]); }
+        if (keep_nonpositive == 2 || (keep_nonpositive ? (s == s) : (s > 0.0f))) { mu = max(mu, user[t]); mi = max(mi, item[t]); }   // 2: every entry
     }
     for (int o = 32; o > 0; o >>= 1) {
         mu = max(mu, __shfl_down(mu, o, 64));
@@ -333,6 +333,20 @@ __global__ void k_gather_i32(int32_t n, const int32_t* __restrict__ src, const i
 }
 
 // ---------------------------------------------------------------- build
+void ratings_id_bounds(Context* ctx, fy_ratings* R) {
+    R->max_user = R->max_item = -1;
+    if (R->nnz == 0) return;
+    DevBuf<int32_t> max_ids(ctx, 2);
+    FY_HIP(hipMemsetAsync(max_ids.get(), 0xFF, 2 * sizeof(int32_t), ctx->stream));   // -1
+    k_max_ids<<<grid_for(R->nnz), 256, 0, ctx->stream>>>(R->nnz, R->user.get(), R->item.get(), R->score.get(), 2, max_ids.get());
+    FY_KERNEL_CHECK();
+    int32_t h[2];
+    d2h(ctx, h, max_ids.get(), 2);
+    sync(ctx);
+    R->max_user = h[0];
+    R->max_item = h[1];
+}
+
 void build_structure(Context* ctx, const fy_ratings* R, int32_t K, int64_t n_map, const int32_t* map_user,
                      const int32_t* map_cluster, const int32_t* cluster_count, bool keep_nonpositive, Prepared& P) {
     P.ctx = ctx;
@@ -352,13 +366,8 @@ void build_structure(Context* ctx, const fy_ratings* R, int32_t K, int64_t n_map
     auto bits_for = [](uint64_t v) { int b = 0; while (v) { b++; v >>= 1; } return b; };   // bits that hold every value <= v
     int ib = 1;   // bits of the item field of the sort keys
     if (n_in) {
-        DevBuf<int32_t> max_ids(ctx, 2);
-        FY_HIP(hipMemsetAsync(max_ids.get(), 0xFF, 2 * sizeof(int32_t), st));   // -1
-        k_max_ids<<<grid_for(n_in), 256, 0, st>>>(n_in, R->user.get(), R->item.get(), R->score.get(), keep_nonpositive ? 1 : 0, max_ids.get());
-        FY_KERNEL_CHECK();
-        int32_t hmax[2];
-        d2h(ctx, hmax, max_ids.get(), 2);
-        sync(ctx);
+        // (the id bounds were found when the ratings entered HBM, fy_ratings_create: a property of the container like nnz)
+        const int32_t hmax[2] = {R->max_user, R->max_item};
         const uint32_t drop_user = (uint32_t)(hmax[0] + 1);
         ib = std::max(1, bits_for((uint64_t)std::max(0, hmax[1])));
         const int ub = std::max(1, bits_for(drop_user));

@@ -50,6 +50,9 @@ struct Prepared {
 void build_structure(Context* ctx, const fy_ratings* R, int32_t n_clusters, int64_t n_map, const int32_t* map_user,
                      const int32_t* map_cluster, const int32_t* cluster_count, bool keep_nonpositive, Prepared& P);
 
+// fills R->max_user / R->max_item (one pass over the COO; called by fy_ratings_create)
+void ratings_id_bounds(Context* ctx, fy_ratings* R);
+
 // slot range [lo, hi) of `rank` out of `world`, cut on the work prefix (identical on every rank)
 void rank_slot_range(const Prepared& P, int rank, int world, int32_t& lo, int32_t& hi);
 
