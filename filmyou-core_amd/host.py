@@ -502,6 +502,8 @@ class ClusterAssignmentJob:
         """H: (users x numberOfClusters) float64, numpy or a CUDA torch tensor.  first_user: id of row 0 (the reference's H
         files are keyed from 1)."""
         import numpy as np
+        if len(H.shape) != 2:
+            raise ValueError("H must be a (users x clusters) matrix")
         k = int(H.shape[1]) if number_of_clusters is None else int(number_of_clusters)
         counts = np.zeros(k, np.int32)
         users, clusters = self._assign(H, first_user, 0, counts)
