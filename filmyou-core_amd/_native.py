@@ -19,7 +19,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
 
 # every symbol include/filmyou.h declares (tests check the library exports exactly these)
 SYMBOLS = [
-    "fy_abi_version", "fy_last_error", "fy_context_create", "fy_context_destroy", "fy_context_synchronize",
+    "fy_abi_version", "fy_last_error", "fy_context_create", "fy_context_destroy", "fy_context_synchronize", "fy_context_inject_alloc_failure",
     "fy_context_stream", "fy_ratings_create", "fy_ratings_destroy", "fy_ratings_nnz", "fy_rm2_prepare",
     "fy_rm2_partial_stats", "fy_rm2_set_global_stats", "fy_rm2_set_collectives", "fy_rm2_score", "fy_rm2_job_destroy", "fy_rm2_run",
     "fy_itemsim_build", "fy_itemsim_run", "fy_itemcf_recommend", "fy_cluster_assign", "fy_nmf_factorize", "fy_result_size", "fy_result_key0", "fy_result_key1", "fy_result_value",
@@ -106,7 +106,7 @@ class Stats(C.Structure):
                 ("ms_prepare", C.c_double), ("ms_cooc", C.c_double), ("ms_score", C.c_double),
                 ("ms_topn", C.c_double), ("ms_total", C.c_double), ("score_launches", C.c_int64),
                 ("cooc_launches", C.c_int64), ("blocks_total", C.c_int64), ("blocks_survived", C.c_int64),
-                ("log_terms_evaluated", C.c_int64)]
+                ("log_terms_evaluated", C.c_int64), ("prune_fallbacks", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -140,6 +140,7 @@ def load():
     L.fy_context_destroy.argtypes = [vp]
     L.fy_context_destroy.restype = None
     L.fy_context_synchronize.argtypes = [vp]
+    L.fy_context_inject_alloc_failure.argtypes = [vp, i64]
     L.fy_context_stream.argtypes = [vp]
     L.fy_context_stream.restype = vp
     L.fy_ratings_create.argtypes = [vp, i64, vp, vp, vp, C.c_int, pvp]

@@ -68,6 +68,7 @@ void fy_context_destroy(fy_context* c) {
     if (!c) return;
     (void)hipSetDevice(c->c.device);
     if (c->c.stream) {
+        for (hipStream_t x : c->c.aux) (void)hipStreamSynchronize(x);   // lanes of a multi-cluster job (a failed job may have left work there)
         (void)hipStreamSynchronize(c->c.stream);
         c->c.trim();
         for (auto& kv : c->c.capacity) (void)hipFree(kv.first);   // blocks still held by live objects: caller error, reclaimed anyway
@@ -76,6 +77,12 @@ void fy_context_destroy(fy_context* c) {
         (void)hipStreamDestroy(c->c.stream);
     }
     delete c;
+}
+
+int fy_context_inject_alloc_failure(fy_context* c, int64_t nth) {
+    if (!c || nth < 0) { set_error("context is NULL or nth < 0"); return FY_ERR_INVALID_ARGUMENT; }
+    c->c.fail_alloc_in = nth;
+    return FY_OK;
 }
 
 int fy_context_synchronize(fy_context* c) {

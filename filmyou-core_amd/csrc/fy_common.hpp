@@ -55,9 +55,14 @@ struct Context {
     std::vector<hipStream_t> aux;               // extra streams ("lanes") a multi-cluster job overlaps its clusters on
     std::multimap<size_t, void*> free_blocks;   // capacity -> block
     std::map<void*, size_t> capacity;            // every block ever handed out
+    int64_t fail_alloc_in = 0;                   // fault injection (fy_context_inject_alloc_failure): the n-th request from now fails
 
     void* alloc(size_t bytes) {
         const size_t want = (bytes + 255) & ~size_t(255);
+        if (fail_alloc_in > 0 && --fail_alloc_in == 0) {
+            set_error("HBM allocation of %zu bytes failed: injected fault", want);
+            throw Failure{FY_ERR_OUT_OF_MEMORY};
+        }
         auto it = free_blocks.lower_bound(want);
         if (it != free_blocks.end() && it->first <= want + want / 4 + (1u << 20)) {
             void* p = it->second;

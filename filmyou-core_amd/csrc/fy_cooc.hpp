@@ -38,7 +38,6 @@ struct CoocArgs {
     int32_t nrows;      // rows in this launch
     int32_t q0;         // first CSC entry of the cluster
     int32_t nq;         // CSC entries of the cluster
-    int32_t debug;      // timing experiments only (wrong results): 1 = no LDS atomics
     // optional (cooperative ranks): the segment table covers only the CSC entries of rows [row0, row0 + nrows), renumbered
     // row by row; local_start[k] = first local entry of the launch's k-th row (then q0 = 0, nq = local entries)
     const int32_t* __restrict__ local_start;
@@ -96,7 +95,7 @@ __device__ __forceinline__ void cooc_accumulate_row(const CoocArgs& A, int row, 
     // slice loads, then NB LDS atomics.  Software-pipelined by hand (the compiler keeps the order it is given): the loads
     // of group g + 1 are issued BEFORE the atomics of group g, and the descriptors of the wave's next batch before the
     // first group of this one -- the kernel is bound by round trips to L2 / Infinity Cache per wave, not by bytes or by the
-    // LDS atomics (FY_COOC_DEBUG=1, no atomics: 19.6 of 20.9 ms).
+    // LDS atomics (a round-1 timing build without the atomics: 19.6 of 20.9 ms).
     struct Group {
         int L[NB];
         float W[NB];
@@ -131,16 +130,9 @@ __device__ __forceinline__ void cooc_accumulate_row(const CoocArgs& A, int row, 
                 G.idx[q] = (int)(pk & 0xFFFFu);
             }
         }
-        if (A.debug == 1) {
-            float sink = 0.f;
 #pragma unroll
-            for (int q = 0; q < NB; q++) sink += G.x[q] + (float)G.idx[q];
-            if (sink == -12345.f) fy_cooc_acc[0] = sink;
-        } else {
-#pragma unroll
-            for (int q = 0; q < NB; q++)
-                if (lane < G.L[q]) atomicAdd(&fy_cooc_acc[G.idx[q]], (double)G.W[q] * (double)G.x[q]);   // ds_add_f64
-        }
+        for (int q = 0; q < NB; q++)
+            if (lane < G.L[q]) atomicAdd(&fy_cooc_acc[G.idx[q]], (double)G.W[q] * (double)G.x[q]);   // ds_add_f64
     };
     int sb = s_begin + wave * 64;
     if (sb >= s_end) return;

@@ -390,9 +390,8 @@ __global__ void k_cooc_rm2(CoocArgs A, MEpilogue E, int n_items, int* __restrict
         const int row = A.row0 + lrow * (A.row_stride ? A.row_stride : 1);
         const int mrow = E.local_rows ? lrow : row;
         const int ch = item % A.nch;
-        if (A.debug != 3) cooc_accumulate_row<PK>(A, row, ch, lrow);
+        cooc_accumulate_row<PK>(A, row, ch, lrow);
         __syncthreads();
-        if (A.debug == 4) continue;   // timing experiment: no epilogue (block-uniform)
         const int c0 = ch * A.CH;
         // the last chunk also writes the padding columns [Ic, ldm) so the scoring kernel may load whole 256-wide chunks
         const int c1 = (ch == A.nch - 1) ? (int)E.ldm : min(c0 + A.CH, (int)E.ldm);
@@ -503,15 +502,13 @@ static void owner_range(const fy_rm2_job* J, int k, int32_t& lo, int32_t& hi) {
     hi = (int32_t)(n * (k + 1) / W);
 }
 
-// launch-shape knobs; environment overrides exist only for the tuning sweeps recorded in DESIGN.md
+// launch-shape knobs.  The environment overrides are TEST HOOKS: each one forces a path that the default heuristics would
+// pick only at a larger size, so that the parity tests can drive every path at a size the oracle finishes (none of them
+// changes a result beyond the summation order; the timing-only switches of round 1 are gone from the product library).
 struct ScoreTune {
-    int vec = 4;                       // floats per lane: column chunk = 64 * vec items
-    int force_select = 0;              // test hook: route every user through k_topn_select
+    int force_select = 0;              // route every user through k_topn_select
     int pack24 = 1;                    // M rows as 24-bit floats (3 bytes per element): -25 % of the dominant traffic
     int pack24_min_items = 4096;       // ... for clusters with at least this many items
-    int batch = 8;                     // row-segment loads in flight per wave
-    int nt_rows = 0;                   // rows >= this index are loaded with the non-temporal hint (0 = off)
-    int xcd_map = 0;                   // one column chunk per XCD at a time
     int max_slices = 65536;            // user slices (workgroups) per column chunk
     int users_per_wave = 16;           // users a wave of the scoring kernel walks for one column chunk
     int64_t workspace_default = (int64_t)16 << 30;   // score scratch per batch of users
@@ -520,27 +517,19 @@ struct ScoreTune {
     int prune_min_items = 8192;
     int seed_chunks = 0;               // 256-column chunks scored exactly before the bound pass (the most popular candidates);
                                        // 0 = from the list length: ~5 N columns (N = 50: one chunk, N = 100: two), at most four
-    int cooc_debug = 0;                // timing experiments only
-    int cooc_block = 0;                // test hook: force the row kernel's workgroup size
+    int cooc_block = 0;                // force the row kernel's workgroup size
     int cooc_max_ch = 19968;           // LDS accumulators of the row kernel: 156 KiB of fp64 of the 160 KiB LDS (ML-25M shape: three
-                                       // column chunks instead of four, 19.7 -> 17.8 ms; test hook: smaller forces more chunks)
-    int hot_lds = 0;                   // k_score_hot: the 128 most popular rows of a chunk stay in LDS (slower: 16 waves/CU)
-    int hot_min_items = 2048;
-    int64_t tile_bytes = (int64_t)1 << 40;   // M[row block][chunk] tile; default: one row block (sweep r1)
-    int seed_forced = 0;               // FY_SEED_CHUNKS given: prune whatever the list length (tests)
+                                       // column chunks instead of four, 19.7 -> 17.8 ms; smaller forces more chunks)
+    int seed_forced = 0;               // FY_SEED_CHUNKS given: prune whatever the list length
     int coop = 1;                      // cooperative scoring of clusters that span all ranks (needs fy_collectives)
-    int coop_force = 0;                // test hook: cooperative path also with world == 1 (identity collectives)
+    int coop_force = 0;                // cooperative path also with world == 1 (identity collectives)
     int cooc_pk = 1;                   // packed 4-byte CSR entries for the row kernel when the ratings are fp16-exact
+    double max_surv_frac = 0.25;       // a pruned batch whose surviving blocks exceed this fraction falls back to the full pass
 };
 static ScoreTune score_tune() {
     ScoreTune t;
-    if (const char* e = getenv("FY_SCORE_VEC")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) t.vec = v; }
     if (const char* e = getenv("FY_M24")) t.pack24 = atoi(e) != 0;
     if (const char* e = getenv("FY_M24_MIN_ITEMS")) t.pack24_min_items = atoi(e);
-    if (const char* e = getenv("FY_HOT_LDS")) t.hot_lds = atoi(e) != 0;
-    if (const char* e = getenv("FY_SCORE_BATCH")) t.batch = atoi(e);
-    if (const char* e = getenv("FY_SCORE_NT_ROWS")) t.nt_rows = atoi(e);
-    if (const char* e = getenv("FY_SCORE_XCD")) t.xcd_map = atoi(e) != 0;
     if (const char* e = getenv("FY_SCORE_SLICES")) t.max_slices = atoi(e);
     if (const char* e = getenv("FY_SCORE_UPW")) { int v = atoi(e); if (v >= 1) t.users_per_wave = v; }
     if (const char* e = getenv("FY_PRUNE")) t.prune = atoi(e) != 0;
@@ -551,21 +540,19 @@ static ScoreTune score_tune() {
     if (const char* e = getenv("FY_SEED_CHUNKS")) { int v = atoi(e); if (v >= 0 && v <= 4) { t.seed_chunks = v; t.seed_forced = v > 0; } }
     if (const char* e = getenv("FY_WORKSPACE_GB")) { long v = atol(e); if (v >= 1) t.workspace_default = (int64_t)v << 30; }
     if (const char* e = getenv("FY_LANES")) { int v = atoi(e); if (v >= 1 && v <= 8) t.lanes = v; }
-    if (const char* e = getenv("FY_COOC_DEBUG")) t.cooc_debug = atoi(e);
     if (const char* e = getenv("FY_COOC_BLOCK")) { int v = atoi(e); if (v == 256 || v == 512 || v == 1024) t.cooc_block = v; }
     if (const char* e = getenv("FY_COOC_MAX_CH")) { int v = atoi(e); if (v >= 64 && v <= 20224) t.cooc_max_ch = v; }
-    if (const char* e = getenv("FY_HOT_MIN_ITEMS")) t.hot_min_items = atoi(e);
     if (const char* e = getenv("FY_TOPN_FORCE_SELECT")) t.force_select = atoi(e) != 0;
-    if (const char* e = getenv("FY_SCORE_TILE_KB")) { long v = atol(e); if (v >= 16) t.tile_bytes = (int64_t)v << 10; }
+    if (const char* e = getenv("FY_MAX_SURV_FRAC")) { double v = atof(e); if (v >= 0.0) t.max_surv_frac = v; }
     return t;
 }
 
 // one cluster's launch plan
 struct Plan {
     int c;
-    int32_t Uc, sbase, pbase, Ic, a, b, CH, nch, rb_rows, nrb, q0, nq;
+    int32_t Uc, sbase, pbase, Ic, a, b, CH, nch, q0, nq;
     int64_t ldm, B;
-    bool pack24, use_hot, prune, coop;
+    bool pack24, prune, coop;
     int32_t nblk;
     int64_t ldb;
 };
@@ -673,7 +660,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
     // tau_u is the N-th best of the seed scores: a seed of only a few N columns gives a weak threshold and many survivors
     // (Netflix shape, N = 100: 2.7 % of the blocks survive a 256-column seed, 0.1 % a 512-column one)
     if (tune.seed_chunks == 0) tune.seed_chunks = (int)std::min<int64_t>(4, std::max<int64_t>(1, ceil_div(5 * (int64_t)prm.number_of_recommendations, 256)));
-    const bool pack24_allowed = tune.pack24 && tune.vec == 4;
+    const bool pack24_allowed = tune.pack24 != 0;
     int64_t coop_pair_contribs = 0;   // cooperative clusters: ordered off-diagonal co-rating pairs of this rank's matrix rows
     bool any_coop = false;
 
@@ -701,7 +688,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
 
     // ---- which users this rank emits lists for
     J->count_balanced = false;
-    if (prm.world > 1 && J->have_coll && tune.coop && tune.prune && pack24_allowed && tune.tile_bytes >= ((int64_t)1 << 40) && !tune.hot_lds) {
+    if (prm.world > 1 && J->have_coll && tune.coop && tune.prune && pack24_allowed) {
         int nonempty = 0, c1 = -1;
         for (int c = 0; c < K; c++)
             if (P.csize[c] > 0) { nonempty++; c1 = c; }
@@ -758,14 +745,12 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
         const int max_ch_lds = tune.cooc_max_ch;   // fp64 accumulators in LDS
         FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cooc_rm2<false>), hipFuncAttributeMaxDynamicSharedMemorySize, max_ch_lds * 8));
         FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cooc_rm2<true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_ch_lds * 8));
-        FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_score_hot<true>), hipFuncAttributeMaxDynamicSharedMemorySize, SCORE_HOT_ROWS * 1024));
-        FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_score_hot<false>), hipFuncAttributeMaxDynamicSharedMemorySize, SCORE_HOT_ROWS * 1024));
 
         // ---- per-cluster plan; the clusters are spread over up to four "lanes" (HIP streams with their own M / score
         // scratch): the tail of one cluster's launches -- its heaviest user sits on a single wave for milliseconds, and
         // most of its M rows have a handful of raters -- overlaps the next clusters' work instead of idling the chip.
         std::vector<Plan> plans;
-        const int VEC = tune.vec;
+        constexpr int VEC = 4;   // floats per lane of the scoring kernel: column chunk = 256 items
         for (int c = 0; c < K; c++) {
             Plan p{};
             p.c = c;
@@ -784,17 +769,12 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             pick_chunks(p.Ic, max_ch_lds, p.CH, p.nch);
             p.q0 = P.cluster_q[c];
             p.nq = P.cluster_q[c + 1] - p.q0;
-            // row blocks: tile = rb_rows x (256 * VEC) bytes <= tune.tile_bytes; one block when the cluster is small
-            p.rb_rows = (int32_t)std::max<int64_t>(64, tune.tile_bytes / (256 * VEC));
-            p.nrb = (int32_t)ceil_div(p.Ic, p.rb_rows);
-            if (p.nrb <= 1) { p.nrb = 1; p.rb_rows = p.Ic; }
-            p.use_hot = tune.hot_lds && VEC == 4 && p.nrb == 1 && p.Ic >= tune.hot_min_items;
             // branch-and-bound over 256-column blocks: only where the matrix is big enough for the bound pass to pay
             p.nblk = (int32_t)ceil_div(p.Ic, PRUNE_BLOCK);
             p.ldb = round_up(p.nblk, 256);
             // (the threshold is the N-th best of at most 1024 seed scores: for lists longer than ~200 items it is too weak --
             // N = 1000 at ML-25M shape: 77 % of the blocks survive and the three passes cost twice the plain one)
-            p.prune = tune.prune && p.pack24 && p.nrb == 1 && !p.use_hot && p.Ic >= tune.prune_min_items && p.nblk < 0xFFFF &&
+            p.prune = tune.prune && p.pack24 && p.Ic >= tune.prune_min_items && p.nblk < 0xFFFF &&
                       (tune.seed_forced || 5 * (int64_t)prm.number_of_recommendations <= 4 * 256);
             if (J->count_balanced && !p.prune) FY_FAIL(FY_ERR_STATE, "internal: count-balanced ownership without a cooperative cluster");
             // all ranks hold users of this cluster and can talk to each other: score it together, every rank with its
@@ -814,7 +794,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
         struct Lane {
             hipStream_t st;
             DevBuf<float> M, S;
-            DevBuf<int32_t> chunk_off, rb_off, hot_off, overflow, any_overflow;
+            DevBuf<int32_t> overflow, any_overflow;
             // branch and bound
             DevBuf<float> Bmax, amax, UB, tau;
             DevBuf<uint16_t> surv;
@@ -826,7 +806,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
         {
             size_t is_el = 1;
             for (auto& p : plans) is_el = std::max(is_el, (size_t)p.Ic * p.nch);
-            size_t m_el = 1, s_el = 1, co_el = 1, rb_el = 1, ho_el = 1, ov_el = 1, sl_el = 1, bm_el = 1, ub_el = 1, am_el = 1;
+            size_t m_el = 1, s_el = 1, ov_el = 1, bm_el = 1, ub_el = 1, am_el = 1;
             for (auto& p : plans) {
                 p.B = std::min<int64_t>(std::max<int64_t>(1, (ws / NS) / (p.ldm * 4)), p.b - p.a);
                 // pruned clusters keep only the seed columns of a score row (the survivors' scores are packed, see below):
@@ -836,11 +816,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 if (p.coop) continue;   // allocates for itself
                 m_el = std::max(m_el, (size_t)(p.Ic * p.ldm));
                 s_el = std::max(s_el, (size_t)(p.B * (p.prune ? seed_cols : p.ldm)));
-                co_el = std::max(co_el, (size_t)p.Uc * (p.nch + 1));
-                rb_el = std::max(rb_el, (size_t)p.Uc * (p.nrb + 1));
-                if (p.use_hot) ho_el = std::max(ho_el, (size_t)p.Uc * 3);
                 ov_el = std::max(ov_el, (size_t)p.B);
-                sl_el = std::max(sl_el, (size_t)p.nq * p.nch);
                 if (p.prune) {
                     bm_el = std::max(bm_el, (size_t)(p.Ic * p.ldb));
                     ub_el = std::max(ub_el, (size_t)(p.B * p.ldb));
@@ -859,9 +835,6 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 L.st = NS > 1 ? ctx->aux[l] : st;
                 L.M.alloc(ctx, m_el);
                 L.S.alloc(ctx, s_el);
-                L.chunk_off.alloc(ctx, co_el);
-                L.rb_off.alloc(ctx, rb_el);
-                L.hot_off.alloc(ctx, ho_el);
                 L.overflow.alloc(ctx, ov_el);
                 L.any_overflow.alloc(ctx, 1);
                 L.Bmax.alloc(ctx, bm_el);
@@ -876,7 +849,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
         }
         DevBuf<unsigned long long> prune_counters(ctx, 2);   // [0] surviving blocks, [1] log terms evaluated by the three pruned passes
         prune_counters.zero();
-        int64_t prune_blocks_total = 0, prune_seed_terms_cols = 0, coop_survived = 0;
+        int64_t prune_blocks_total = 0, prune_seed_terms_cols = 0, coop_survived = 0, fallback_survived = 0;
         for (auto& p : plans) any_coop = any_coop || p.coop;
         // segment tables of the row kernel, one per cluster, built on the main stream before the lanes fork
         std::vector<SegTable> segs(plans.size());
@@ -901,11 +874,23 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 build_segments(ctx, P.csc_slot.get(), use_pk ? csc_x_over_s.get() : csc_x.get(), co_tmp.get(), p.sbase, p.q0, p.nq, p.nch, segs[pi]);
             }
         }
-        hipEvent_t fork = nullptr;
+        // Error path: anything thrown below (an allocation, a launch, a collective) unwinds the lanes' buffers, the segment
+        // tables and the per-job arrays back into the caching allocator while kernels of OTHER lanes may still be reading
+        // them.  The guard drains every lane and the main stream first (members are destroyed in reverse order of
+        // declaration: `lanes`, `segs` and the DevBufs above were declared before it, so it runs before they are released).
+        struct LaneGuard {
+            Context* ctx;
+            hipEvent_t fork = nullptr;
+            ~LaneGuard() {
+                for (hipStream_t x : ctx->aux) (void)hipStreamSynchronize(x);
+                (void)hipStreamSynchronize(ctx->stream);
+                if (fork) (void)hipEventDestroy(fork);
+            }
+        } guard{ctx};
         if (NS > 1) {   // the lanes start after everything queued on the main stream so far
-            FY_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
-            FY_HIP(hipEventRecord(fork, st));
-            for (int l = 0; l < NS; l++) FY_HIP(hipStreamWaitEvent(lanes[l].st, fork, 0));
+            FY_HIP(hipEventCreateWithFlags(&guard.fork, hipEventDisableTiming));
+            FY_HIP(hipEventRecord(guard.fork, st));
+            for (int l = 0; l < NS; l++) FY_HIP(hipStreamWaitEvent(lanes[l].st, guard.fork, 0));
         }
 
         for (size_t pi = 0; pi < plans.size(); pi++) {
@@ -913,13 +898,13 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             Lane& L = lanes[pi % NS];
             hipStream_t ls = L.st;
             const int c = p.c;
-            const int32_t Uc = p.Uc, sbase = p.sbase, pbase = p.pbase, Ic = p.Ic, a = p.a, b = p.b, CH = p.CH, nch = p.nch;
+            const int32_t sbase = p.sbase, pbase = p.pbase, Ic = p.Ic, a = p.a, b = p.b, CH = p.CH, nch = p.nch;
             const int64_t ldm = p.ldm;
             const bool pack24 = p.pack24;
             if (p.coop) {
                 CoopShared X{J, R.get(), &tune, p_rank.get(), b_rank.get(), a_rank.get(), use_pk ? csc_x_over_s.get() : csc_x.get(), csr_x.get(), csr_e.get(),
                              use_pk ? csr_pk.get() : nullptr,
-                             n_out.get(), out_off.get(), lo, &t_cooc, &t_score, &t_topn, prune_counters.get(),
+                             n_out.get(), out_off.get(), pvpi.get(), lo, &t_cooc, &t_score, &t_topn, prune_counters.get(),
                              &prune_blocks_total, &prune_seed_terms_cols, &coop_survived, &coop_pair_contribs};
                 score_cluster_coop(X, p, ls);
                 continue;
@@ -927,7 +912,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
 
             // -- M build
             CoocArgs CA{P.rank_pair.get(), P.pair_start.get(), segs[pi].ptr.get(), segs[pi].seg.get(), segs[pi].w.get(), P.csr_idx.get(),
-                        csr_x.get(), pbase, sbase, Ic, CH, nch, 0, Ic, p.q0, p.nq, tune.cooc_debug, nullptr, 0, use_pk ? csr_pk.get() : nullptr};
+                        csr_x.get(), pbase, sbase, Ic, CH, nch, 0, Ic, p.q0, p.nq, nullptr, 0, use_pk ? csr_pk.get() : nullptr};
             MEpilogue ME{L.M.get(), ldm, p_rank.get() + pbase, b_rank.get() + pbase, (1.0 - lambda) * (1.0 - lambda), lambda * (1.0 - lambda),
                          pack24 ? 1 : 0, p.prune ? L.Bmax.get() : nullptr, p.ldb};
             if (p.prune) {
@@ -955,100 +940,111 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             // -- scoring + top-N in user batches that fit the score scratch
             const int64_t ldS = ldm, B = p.B;
             const int n_chunks = (int)ceil_div(Ic, 64 * VEC);
-            const int32_t nrb = p.nrb;
-            build_chunk_offsets(ctx, P.rowptr.get(), P.csr_idx.get(), sbase, Uc, p.rb_rows, nrb, L.rb_off.get(), ls);
-            const bool use_hot = p.use_hot;
-            if (use_hot) build_chunk_offsets(ctx, P.rowptr.get(), P.csr_idx.get(), sbase, Uc, SCORE_HOT_ROWS, 2, L.hot_off.get(), ls);
+            const int32_t* row_off = P.rowptr.get() + sbase;   // the users' CSR rows: [slot - sbase], [slot - sbase + 1]
+            auto score_args = [&](const float* Mx, int64_t ldmx, int32_t Icx, const float* ax, int32_t s0, int32_t nb, float* Sx, int64_t ldSx,
+                                  int n_slices, int nchunks) {
+                ScoreArgs SA{};
+                SA.M = Mx; SA.ldm = ldmx; SA.Ic = Icx; SA.a_rank = ax; SA.rb_off = row_off; SA.csr_idx = P.csr_idx.get(); SA.csr_e = csr_e.get();
+                SA.pvpi = pvpi.get(); SA.n_out = n_out.get(); SA.slot_lo = lo; SA.slot_base = sbase; SA.slot0 = s0; SA.n_users = nb;
+                SA.S = Sx; SA.ldS = ldSx; SA.n_slices = n_slices; SA.n_chunks = nchunks;
+                return SA;
+            };
+            // the plain full pass over a range of users: every log term, like the reference's loop (AbstractRM2Reducer.java:332-356)
+            auto full_pass = [&](int32_t s0, int32_t nb, float* Sx) {
+                const int n_slices = (int)std::max<int64_t>(1, std::min<int64_t>(tune.max_slices, ceil_div(nb, 4 * tune.users_per_wave)));
+                ScoreArgs SA = score_args(L.M.get(), ldm, Ic, a_rank.get() + pbase, s0, nb, Sx, ldS, n_slices, n_chunks);
+                const size_t ss = t_score.begin(ls);
+                if (pack24) k_score<4, true, 8><<<n_chunks * n_slices, 256, 0, ls>>>(SA.M, SA.a_rank, SA.rb_off, SA.csr_idx, SA.csr_e, SA.pvpi, SA.n_out, SA.S, SA);
+                else k_score<4, false, 8><<<n_chunks * n_slices, 256, 0, ls>>>(SA.M, SA.a_rank, SA.rb_off, SA.csr_idx, SA.csr_e, SA.pvpi, SA.n_out, SA.S, SA);
+                FY_KERNEL_CHECK();
+                t_score.end(ss, ls);
+                R->st.score_launches++;
+                TopNArgs TA{Sx, ldS, Ic, n_out.get(), out_off.get(), P.rank_item_raw.get() + pbase, P.slot2du.get(), P.uid.get(), lo, s0, c,
+                            R->d_key0.get(), R->d_key1.get(), R->d_value.get(), R->d_aux.get(), 0, 0, nullptr, nullptr, 0, nullptr, nullptr, nullptr};
+                const size_t tt = t_topn.begin(ls);
+                FY_HIP(hipMemsetAsync(L.any_overflow.get(), 0, sizeof(int32_t), ls));
+                k_topn_fast<<<nb, 256, 0, ls>>>(TA, L.overflow.get(), L.any_overflow.get(), tune.force_select);
+                FY_KERNEL_CHECK();
+                k_topn_select<<<nb, 256, 0, ls>>>(TA, L.overflow.get(), L.any_overflow.get());
+                FY_KERNEL_CHECK();
+                t_topn.end(tt, ls);
+            };
             for (int32_t s0 = a; s0 < b; s0 += (int32_t)B) {
                 const int32_t nb = (int32_t)std::min<int64_t>(B, b - s0);
-                int n_slices = (int)std::max<int64_t>(1, std::min<int64_t>(tune.max_slices, ceil_div(nb, 4 * tune.users_per_wave)));
-                const size_t ss = t_score.begin(ls);
-                if (use_hot) {
-                    // one 16-wave workgroup per CU (128 KiB of LDS); every wave gets >= 8 users to amortise the tile load
-                    const int hs = (int)std::max<int64_t>(1, std::min<int64_t>(256, ceil_div(nb, 16 * 8)));
-                    ScoreArgs SA{L.M.get(), ldm, Ic, a_rank.get() + pbase, L.hot_off.get(), P.csr_idx.get(), csr_e.get(), pvpi.get(),
-                                 n_out.get(), lo, sbase, s0, nb, L.S.get(), ldS, hs, 0, 1, 0, 0, 0, 0, nullptr, nullptr, nullptr, 0};
-                    const size_t lds = (size_t)SCORE_HOT_ROWS * 1024;
-                    if (pack24) k_score_hot<true><<<(int)(ldm / 256) * hs, 1024, lds, ls>>>(SA.M, SA.a_rank, SA.rb_off, SA.csr_idx, SA.csr_e, SA.pvpi, SA.n_out, SA.S, SA);
-                    else k_score_hot<false><<<(int)(ldm / 256) * hs, 1024, lds, ls>>>(SA.M, SA.a_rank, SA.rb_off, SA.csr_idx, SA.csr_e, SA.pvpi, SA.n_out, SA.S, SA);
-                    FY_KERNEL_CHECK();
-                    R->st.score_launches++;
+                if (!p.prune) { full_pass(s0, nb, L.S.get()); continue; }
+                const int n_slices = (int)std::max<int64_t>(1, std::min<int64_t>(tune.max_slices, ceil_div(nb, 4 * tune.users_per_wave)));
+                size_t ss = t_score.begin(ls);
+                const int seed_chunks = std::min(n_chunks, tune.seed_chunks);
+                const int seed_blocks = seed_chunks;
+                const int64_t SC = (int64_t)seed_chunks * 256;   // pitch of the compact score rows: seed columns only
+                // only the seed columns and the surviving blocks of a score row are ever written or read
+                // (1) + (3) ONE launch: exact scores of the seed columns (the most popular candidates) and the upper bounds
+                // of all 256-column blocks (the same kernel on the block-maximum matrix); the grid's tail -- the waves
+                // that walk the heaviest users -- is paid once instead of twice
+                const int bchunks = (int)(p.ldb / 256);
+                ScoreArgs SA = score_args(L.M.get(), ldm, Ic, a_rank.get() + pbase, s0, nb, L.S.get(), SC, n_slices, seed_chunks + bchunks);
+                SA.chunks1 = seed_chunks;
+                SA.M2 = L.Bmax.get();
+                SA.ldm2 = p.ldb;
+                SA.Ic2 = p.nblk;
+                SA.a2 = L.amax.get();
+                SA.S2 = L.UB.get();
+                SA.ldS2 = p.ldb;
+                SA.no_mask2 = 1;
+                k_score<4, true, 8><<<(seed_chunks + bchunks) * n_slices, 256, 0, ls>>>(SA.M, SA.a_rank, SA.rb_off, SA.csr_idx, SA.csr_e, SA.pvpi, SA.n_out, SA.S, SA);
+                FY_KERNEL_CHECK();
+                // (2) tau_u = N-th best seed score; the sorted seed head is also the user's list unless a block survives
+                TopNArgs T1{L.S.get(), SC, Ic, n_out.get(), out_off.get(), P.rank_item_raw.get() + pbase, P.slot2du.get(), P.uid.get(),
+                            lo, s0, c, R->d_key0.get(), R->d_key1.get(), R->d_value.get(), R->d_aux.get(),
+                            1, seed_chunks * 256, L.surv.get(), L.n_quads.get(), p.ldb, L.tau.get()};
+                k_topn_fast<<<nb, 256, 0, ls>>>(T1, L.overflow.get(), L.any_overflow.get(), 0);
+                FY_KERNEL_CHECK();
+                // (4) the blocks whose bound reaches tau_u, in ascending order
+                FY_HIP(hipMemsetAsync(L.n_quads.get(), 0, ((size_t)nb + 1) * sizeof(int32_t), ls));
+                k_bound_select<<<grid_for((int64_t)nb * 64, 256), 256, 0, ls>>>(L.UB.get(), p.ldb, p.nblk, seed_blocks, L.tau.get(), pvpi.get() + (s0 - lo), nb,
+                                                                               L.surv.get(), L.n_quads.get());
+                FY_KERNEL_CHECK();
+                exclusive_scan_i32(ctx, L.n_quads.get(), L.quad_prefix.get(), (size_t)nb + 1, ls);
+                // (5) exact scores of the survivors, packed: 256 floats per surviving block at entry quad_prefix[u] + k
+                int32_t hv[3] = {0, 0, 0};   // survivors, first / last CSR entry of the batch
+                FY_HIP(hipMemcpyAsync(&hv[0], L.quad_prefix.get() + nb, sizeof(int32_t), hipMemcpyDeviceToHost, ls));
+                FY_HIP(hipMemcpyAsync(&hv[1], P.rowptr.get() + s0, sizeof(int32_t), hipMemcpyDeviceToHost, ls));
+                FY_HIP(hipMemcpyAsync(&hv[2], P.rowptr.get() + s0 + nb, sizeof(int32_t), hipMemcpyDeviceToHost, ls));
+                FY_HIP(hipStreamSynchronize(ls));   // (everything queued on this lane before has finished: Ssurv may be re-sized)
+                const int32_t n_surv_total = hv[0];
+                const int64_t blocks_checked = (int64_t)nb * std::max(0, p.nblk - seed_blocks);
+                if ((double)n_surv_total > tune.max_surv_frac * (double)blocks_checked) {
+                    // The threshold did not bite (e.g. lambda = 0: a user who rated an item nobody else of the cluster rated has
+                    // only -inf scores, tau = -inf keeps every block): the survivor pass would cost more than the plain full pass
+                    // and 1 KB of scratch per survivor.  Redo the batch with the full pass, in sub-batches that fit the workspace.
+                    t_score.end(ss, ls);
+                    const int64_t sub = std::max<int64_t>(1, std::min<int64_t>((ws / NS) / (ldm * 4), nb));
+                    DevBuf<float> Sfull(ctx, (size_t)(sub * ldm));
+                    for (int32_t t0 = s0; t0 < s0 + nb; t0 += (int32_t)sub) full_pass(t0, (int32_t)std::min<int64_t>(sub, s0 + nb - t0), Sfull.get());
+                    FY_HIP(hipStreamSynchronize(ls));   // Sfull goes back to the allocator
+                    R->st.prune_fallbacks++;
+                    R->st.score_launches++;          // the fused seed + bound launch that was thrown away
+                    prune_blocks_total += blocks_checked;
+                    fallback_survived += n_surv_total;
+                    prune_seed_terms_cols += (int64_t)(hv[2] - hv[1]) * (seed_chunks * 256 + p.ldb + ldm);
+                    continue;
                 }
-                if (p.prune) {
-                    const int seed_chunks = std::min(n_chunks, tune.seed_chunks);
-                    const int seed_blocks = seed_chunks;
-                    const int64_t SC = (int64_t)seed_chunks * 256;   // pitch of the compact score rows: seed columns only
-                    // only the seed columns and the surviving blocks of a score row are ever written or read
-                    // (1) + (3) ONE launch: exact scores of the seed columns (the most popular candidates) and the upper bounds
-                    // of all 256-column blocks (the same kernel on the block-maximum matrix); the grid's tail -- the waves
-                    // that walk the heaviest users -- is paid once instead of twice (tune.fuse_bound = 0: two launches)
-                    const int bchunks = (int)(p.ldb / 256);
-                    ScoreArgs SA{L.M.get(), ldm, Ic, a_rank.get() + pbase, L.rb_off.get(), P.csr_idx.get(), csr_e.get(), pvpi.get(),
-                                 n_out.get(), lo, sbase, s0, nb, L.S.get(), SC, n_slices, 0, 1, 0, 0, seed_chunks, 0, nullptr, nullptr, nullptr, 0};
-                    SA.chunks1 = seed_chunks;
-                    SA.M2 = L.Bmax.get();
-                    SA.ldm2 = p.ldb;
-                    SA.Ic2 = p.nblk;
-                    SA.a2 = L.amax.get();
-                    SA.S2 = L.UB.get();
-                    SA.ldS2 = p.ldb;
-                    SA.no_mask2 = 2;
-                    SA.n_chunks = seed_chunks + bchunks;
-                    k_score<4, true, 8><<<(seed_chunks + bchunks) * n_slices, 256, 0, ls>>>(SA.M, SA.a_rank, SA.rb_off, SA.csr_idx, SA.csr_e, SA.pvpi, SA.n_out, SA.S, SA);
+                L.Ssurv.alloc(ctx, (size_t)std::max(1, n_surv_total) * PRUNE_BLOCK);
+                if (n_surv_total > 0) {
+                    ScoreArgs SQ = score_args(L.M.get(), ldm, Ic, a_rank.get() + pbase, s0, nb, L.Ssurv.get(), 0, n_slices, n_chunks);
+                    k_score_blocks<8><<<std::min(n_surv_total, ctx->num_cus * 16), 256, 0, ls>>>(SQ.M, SQ.a_rank, P.rowptr.get(), SQ.csr_idx, SQ.csr_e, SQ.pvpi,
+                                                                        L.quad_prefix.get(), L.surv.get(), SQ.S, SQ, p.ldb, prune_counters.get());
                     FY_KERNEL_CHECK();
-                    // (2) tau_u = N-th best seed score; the sorted seed head is also the user's list unless a block survives
-                    TopNArgs T1{L.S.get(), SC, Ic, n_out.get(), out_off.get(), P.rank_item_raw.get() + pbase, P.slot2du.get(), P.uid.get(),
-                                lo, s0, c, R->d_key0.get(), R->d_key1.get(), R->d_value.get(), R->d_aux.get(),
-                                1, seed_chunks * 256, L.surv.get(), L.n_quads.get(), p.ldb, L.tau.get()};
-                    k_topn_fast<<<nb, 256, 0, ls>>>(T1, L.overflow.get(), L.any_overflow.get(), 0);
-                    FY_KERNEL_CHECK();
-                    // (4) the blocks whose bound reaches tau_u, in ascending order
-                    FY_HIP(hipMemsetAsync(L.n_quads.get(), 0, ((size_t)nb + 1) * sizeof(int32_t), ls));
-                    k_bound_select<<<grid_for((int64_t)nb * 64, 256), 256, 0, ls>>>(L.UB.get(), p.ldb, p.nblk, seed_blocks, L.tau.get(), nb,
-                                                                                   L.surv.get(), L.n_quads.get());
-                    FY_KERNEL_CHECK();
-                    exclusive_scan_i32(ctx, L.n_quads.get(), L.quad_prefix.get(), (size_t)nb + 1, ls);
-                    // (5) exact scores of the survivors, packed: 256 floats per surviving block at entry quad_prefix[u] + k
-                    int32_t n_surv_total = 0;
-                    FY_HIP(hipMemcpyAsync(&n_surv_total, L.quad_prefix.get() + nb, sizeof(int32_t), hipMemcpyDeviceToHost, ls));
-                    FY_HIP(hipStreamSynchronize(ls));   // (everything queued on this lane before has finished: Ssurv may be re-sized)
-                    L.Ssurv.alloc(ctx, (size_t)std::max(1, n_surv_total) * PRUNE_BLOCK);
-                    if (n_surv_total > 0) {
-                        ScoreArgs SQ{L.M.get(), ldm, Ic, a_rank.get() + pbase, L.rb_off.get(), P.csr_idx.get(), csr_e.get(), pvpi.get(),
-                                     n_out.get(), lo, sbase, s0, nb, L.Ssurv.get(), 0, n_slices, 0, 1, 0, 0, n_chunks, 0, nullptr, nullptr, nullptr, 0};
-                        k_score_blocks<8><<<std::min(n_surv_total, ctx->num_cus * 16), 256, 0, ls>>>(SQ.M, SQ.a_rank, P.rowptr.get(), SQ.csr_idx, SQ.csr_e, SQ.pvpi,
-                                                                            L.quad_prefix.get(), L.surv.get(), SQ.S, SQ, p.ldb, prune_counters.get());
-                        FY_KERNEL_CHECK();
-                    }
-                    R->st.score_launches += 2;   // the fused seed + bound launch and the survivor pass
-                    prune_blocks_total += (int64_t)nb * std::max(0, p.nblk - seed_blocks);
-                    {   // log terms of the seed and bound passes of this batch: (ratings of its users) x (columns walked)
-                        int32_t r2[2];
-                        d2h(ctx, &r2[0], P.rowptr.get() + s0, 1);
-                        d2h(ctx, &r2[1], P.rowptr.get() + s0 + nb, 1);
-                        sync(ctx);
-                        prune_seed_terms_cols += (int64_t)(r2[1] - r2[0]) * (seed_chunks * 256 + p.ldb);
-                    }
-                }
-                for (int32_t rb = 0; rb < ((use_hot || p.prune) ? 0 : nrb); rb++) {
-                    ScoreArgs SA{L.M.get(), ldm, Ic, a_rank.get() + pbase, L.rb_off.get(), P.csr_idx.get(), csr_e.get(), pvpi.get(),
-                                 n_out.get(), lo, sbase, s0, nb, L.S.get(), ldS, n_slices, rb, nrb, tune.nt_rows, tune.xcd_map, n_chunks, 0, nullptr, nullptr, nullptr, 0};
-#define FY_LAUNCH_SCORE(V_, P_, B_) k_score<V_, P_, B_><<<(tune.xcd_map ? (int)round_up(n_chunks, 8) : n_chunks) * n_slices, 256, 0, ls>>>(SA.M, SA.a_rank, SA.rb_off, SA.csr_idx, SA.csr_e, SA.pvpi, SA.n_out, SA.S, SA)
-                    if (pack24 && tune.batch == 16) FY_LAUNCH_SCORE(4, true, 16);
-                    else if (pack24 && tune.batch == 12) FY_LAUNCH_SCORE(4, true, 12);
-                    else if (pack24) FY_LAUNCH_SCORE(4, true, 8);
-                    else if (VEC == 4) FY_LAUNCH_SCORE(4, false, 8);
-                    else if (VEC == 2) FY_LAUNCH_SCORE(2, false, 8);
-                    else FY_LAUNCH_SCORE(1, false, 8);
-                    FY_KERNEL_CHECK();
-                    R->st.score_launches++;
                 }
                 t_score.end(ss, ls);
-                const int32_t seed_cols_p = p.prune ? std::min(n_chunks, tune.seed_chunks) * 256 : 0;
-                TopNArgs TA{L.S.get(), p.prune ? (int64_t)seed_cols_p : ldS, Ic, n_out.get(), out_off.get(), P.rank_item_raw.get() + pbase,
+                R->st.score_launches += 2;   // the fused seed + bound launch and the survivor pass
+                prune_blocks_total += blocks_checked;
+                // log terms of the seed and bound passes of this batch: (ratings of its users) x (columns walked)
+                prune_seed_terms_cols += (int64_t)(hv[2] - hv[1]) * (seed_chunks * 256 + p.ldb);
+                const int32_t seed_cols_p = seed_chunks * 256;
+                TopNArgs TA{L.S.get(), (int64_t)seed_cols_p, Ic, n_out.get(), out_off.get(), P.rank_item_raw.get() + pbase,
                             P.slot2du.get(), P.uid.get(), lo, s0, c, R->d_key0.get(), R->d_key1.get(), R->d_value.get(), R->d_aux.get(),
-                            p.prune ? 2 : 0, seed_cols_p, L.surv.get(), L.n_quads.get(), p.ldb, L.tau.get(),
-                            p.prune ? L.Ssurv.get() : nullptr, p.prune ? L.quad_prefix.get() : nullptr};
+                            2, seed_cols_p, L.surv.get(), L.n_quads.get(), p.ldb, L.tau.get(), L.Ssurv.get(), L.quad_prefix.get()};
                 const size_t tt = t_topn.begin(ls);
                 FY_HIP(hipMemsetAsync(L.any_overflow.get(), 0, sizeof(int32_t), ls));
                 k_topn_fast<<<nb, 256, 0, ls>>>(TA, L.overflow.get(), L.any_overflow.get(), tune.force_select);
@@ -1066,15 +1062,13 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 FY_HIP(hipStreamWaitEvent(st, done, 0));
                 FY_HIP(hipEventDestroy(done));
             }
-            FY_HIP(hipEventDestroy(fork));
-            // the lanes' buffers go back to the allocator only after the join point has been reached
-            FY_HIP(hipStreamSynchronize(st));
         }
+        // (the guard's destructor drains the lanes and the main stream before any buffer of this scope is released)
         {
             unsigned long long hc[2];
             d2h(ctx, hc, prune_counters.get(), 2);
             sync(ctx);
-            R->st.blocks_survived = (int64_t)hc[0] + coop_survived;
+            R->st.blocks_survived = (int64_t)hc[0] + coop_survived + fallback_survived;
             R->st.blocks_total = prune_blocks_total;
             R->st.log_terms_evaluated = prune_blocks_total ? (int64_t)hc[1] + prune_seed_terms_cols : 0;
         }
@@ -1112,6 +1106,8 @@ void fy::rm2_partial_stats(fy_rm2_job* J, double** buf, int64_t* len) {
 void fy::rm2_job_destroy(fy_rm2_job* J) {
     if (!J) return;
     Context* ctx = J->ctx;
-    delete J;
+    // nothing of the job may still be read by a queued kernel when its arrays go back to the caching allocator
+    for (hipStream_t x : ctx->aux) (void)hipStreamSynchronize(x);
     (void)hipStreamSynchronize(ctx->stream);
+    delete J;
 }

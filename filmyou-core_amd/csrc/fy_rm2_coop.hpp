@@ -18,6 +18,7 @@ struct CoopShared {
     const float *a_rank, *csc_x, *csr_x, *csr_e;
     const uint32_t* csr_pk;        // packed CSR for the row kernel (nullptr: csr_idx / csr_x); csc_x then holds x / s_v
     const int32_t *n_out, *out_off;   // this rank's users, by slot - lo
+    const double* pvpi;               // this rank's users, by slot - lo (the complete value; pv_all below is zero on ranks != 0)
     int32_t lo;
     EventTimer *t_cooc, *t_score, *t_topn;
     unsigned long long* prune_counters;
@@ -124,7 +125,7 @@ static void score_cluster_coop(const CoopShared& X, const Plan& p, hipStream_t l
         FY_KERNEL_CHECK();
         if (nrows > 0) {
             CoocArgs CA{P.rank_pair.get(), P.pair_start.get(), seg.ptr.get(), seg.seg.get(), seg.w.get(), P.csr_idx.get(),
-                        X.csr_x, pbase, sbase, Ic, CH, nch, r0, nrows, 0, (int32_t)my_ratings, tune.cooc_debug, local_start.get(), W, X.csr_pk};
+                        X.csr_x, pbase, sbase, Ic, CH, nch, r0, nrows, 0, (int32_t)my_ratings, local_start.get(), W, X.csr_pk};
             MEpilogue ME{const_cast<float*>(Mshift), ldm, X.p_rank + pbase, X.b_rank + pbase, (1.0 - lambda) * (1.0 - lambda),
                          lambda * (1.0 - lambda), 1, const_cast<float*>(Bshift), ldb, 1};
             const int block = tune.cooc_block ? tune.cooc_block : ((CH * 8 > 48 * 1024) ? 1024 : 256);
@@ -167,9 +168,11 @@ static void score_cluster_coop(const CoopShared& X, const Plan& p, hipStream_t l
         const int32_t nk = ub[k] - ua[k];
         if (nk <= 0) continue;
         const int ns = slices_for(nk);
-        ScoreArgs SA{Mshift, ldm, Ic, X.a_rank + pbase, my_rowptr.get(), my_idx.get(), my_e.get(), pv_all.get(), n_out_all.get(),
-                     sbase, sbase, ua[k], nk, seed_send.get() + (int64_t)k * Umax * SC, SC, ns, 0, 0, 0, 0, seed_chunks + bchunks, 0,
-                     nullptr, nullptr, nullptr, 0, W, me};
+        ScoreArgs SA{};
+        SA.M = Mshift; SA.ldm = ldm; SA.Ic = Ic; SA.a_rank = X.a_rank + pbase; SA.rb_off = my_rowptr.get(); SA.csr_idx = my_idx.get();
+        SA.csr_e = my_e.get(); SA.pvpi = pv_all.get(); SA.n_out = n_out_all.get(); SA.slot_lo = sbase; SA.slot_base = sbase; SA.slot0 = ua[k];
+        SA.n_users = nk; SA.S = seed_send.get() + (int64_t)k * Umax * SC; SA.ldS = SC; SA.n_slices = ns; SA.n_chunks = seed_chunks + bchunks;
+        SA.row_mul = W; SA.row_add = me;
         SA.chunks1 = seed_chunks;
         SA.M2 = Bshift;
         SA.ldm2 = ldb;
@@ -177,7 +180,7 @@ static void score_cluster_coop(const CoopShared& X, const Plan& p, hipStream_t l
         SA.a2 = amax.get();
         SA.S2 = ub_send.get() + (int64_t)k * Umax * ldb;
         SA.ldS2 = ldb;
-        SA.no_mask2 = 2;
+        SA.no_mask2 = 1;
         k_score<4, true, 8><<<(seed_chunks + bchunks) * ns, 256, 0, ls>>>(SA.M, SA.a_rank, SA.rb_off, SA.csr_idx, SA.csr_e, SA.pvpi, SA.n_out, SA.S, SA);
         FY_KERNEL_CHECK();
         R->st.score_launches += 2;
@@ -195,7 +198,7 @@ static void score_cluster_coop(const CoopShared& X, const Plan& p, hipStream_t l
     }
     FY_HIP(hipMemsetAsync(n_quads.get(), 0, ((size_t)Umax + 1) * sizeof(int32_t), ls));
     if (n_mine > 0) {
-        k_bound_select<<<grid_for((int64_t)n_mine * 64, 256), 256, 0, ls>>>(UBsum.get(), ldb, p.nblk, seed_blocks, tau.get(), n_mine,
+        k_bound_select<<<grid_for((int64_t)n_mine * 64, 256), 256, 0, ls>>>(UBsum.get(), ldb, p.nblk, seed_blocks, tau.get(), X.pvpi + (my_a - X.lo), n_mine,
                                                                             surv.get(), n_quads.get());
         FY_KERNEL_CHECK();
     }

@@ -3,23 +3,18 @@
 // translation unit (included inside `namespace fy`, after the statistics / row-kernel sections), split out for size.
 #pragma once
 
-// ================================================================ scoring kernel (the dominant kernel)
-// Work item = (user, column chunk of 64*VEC items, row block): the wave walks the slice of the user's CSR row that falls
-// into the row block (wave-uniform scalar loads of idx and e) and for every rated item j streams the segment
-// M[j][chunk] (4*VEC bytes per lane, coalesced), adding log2(M[j][i] + a_i * e_uj) to the lane's VEC candidates.
-// No cross-lane traffic at all.
-//
-// Cache blocking (rocprof, round 1: one launch over all rows ran at 41 % L2 hit rate and 7.1 TB/s of fabric traffic,
-// i.e. it was bound by the L2-miss path): the rows are cut into blocks of `rb_rows`, one launch per block, and the grid
-// is chunk-major, so the resident workgroups of a launch touch only the tile M[row block][chunk] (rb_rows * 256 * VEC
-// bytes <= half an XCD L2).  Every tile is fetched from HBM once per XCD and all re-reads are L2 hits; the price is a
-// read-modify-write of the score row per non-empty (user, row block), a few percent of the row traffic.
+// ================================================================ scoring kernel
+// Work item = (user, column chunk of 64*VEC items): the wave walks the user's CSR row (wave-uniform scalar loads of idx
+// and e) and for every rated item j streams the segment M[j][chunk] (4*VEC bytes per lane, coalesced), adding
+// log2(M[j][i] + a_i * e_uj) to the lane's VEC candidates.  No cross-lane traffic at all.
+// (Round 1 also measured a row-blocked variant sized to the L2, a variant with the hottest rows resident in LDS and
+// non-temporal loads of the cold rows: all slower; they are no longer in the tree.)
 struct ScoreArgs {
     const float* __restrict__ M;
     int64_t ldm;
     int32_t Ic;
     const float* __restrict__ a_rank;      // l * p_i in rank order, offset by pbase
-    const int32_t* __restrict__ rb_off;    // [(slot - slot_base) * (nrb + 1) + rb] first CSR entry with idx >= rb * rb_rows
+    const int32_t* __restrict__ rb_off;    // [slot - slot_base], [slot - slot_base + 1]: the user's CSR row (rowptr of the cluster)
     const int32_t* __restrict__ csr_idx;
     const float* __restrict__ csr_e;
     const double* __restrict__ pvpi;       // indexed by slot - slot_lo
@@ -31,18 +26,8 @@ struct ScoreArgs {
     float* __restrict__ S;                 // [n_users][ldS]
     int64_t ldS;
     int32_t n_slices;
-    int32_t rb;                            // row block of this launch
-    int32_t nrb;                           // row blocks per row
-    int32_t nt_rows;                       // rows with index >= nt_rows are loaded non-temporally (0 = never)
-    int32_t xcd_map;                       // 1: workgroup b works on chunk 8 * (b / 8 / n_slices) + b % 8 (one chunk per XCD at a time)
     int32_t n_chunks;
-    int32_t no_mask;                       // 1: the columns are not items (bound pass over block maxima): no "already rated" mask;
-                                           // 2: the same, but the (partial) bounds are stored like scores (cooperative ranks)
-    // bound pass only: blocks whose upper bound reaches tau_u are appended to the user's survivor list instead of being stored
-    const float* __restrict__ tau;         // [u]
-    uint16_t* __restrict__ surv;           // [u * ldS + k]
-    int32_t* __restrict__ n_surv;          // [u], zeroed before the launch
-    int32_t seed_blocks;
+    int32_t no_mask;                       // != 0: the columns are not items (bound pass over block maxima): no "already rated" mask
     // cooperative ranks: csr_idx holds LOCAL row indices of M (k-th row of the rank); the item it stands for is
     // k * row_mul + row_add (row_mul == 0: the index is the item itself)
     int32_t row_mul, row_add;
@@ -70,35 +55,6 @@ template <> struct VecT<4> { using type = float4; };
 struct U3 {
     uint32_t a, b, c;
 };
-typedef uint32_t fy_u32x3 __attribute__((ext_vector_type(3)));
-typedef float fy_f32x4 __attribute__((ext_vector_type(4)));
-typedef float fy_f32x2 __attribute__((ext_vector_type(2)));
-
-// Row segments of unpopular items are read by few users within an L2 lifetime: loading them with the non-temporal hint
-// keeps them from evicting the popular rows every wave of the XCD re-reads.
-template <class G>
-__device__ __forceinline__ G fy_load_nt(const char* p);
-template <>
-__device__ __forceinline__ U3 fy_load_nt<U3>(const char* p) {
-    const fy_u32x3 v = __builtin_nontemporal_load(reinterpret_cast<const fy_u32x3*>(p));
-    U3 r;
-    r.a = v.x; r.b = v.y; r.c = v.z;
-    return r;
-}
-template <>
-__device__ __forceinline__ float4 fy_load_nt<float4>(const char* p) {
-    const fy_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const fy_f32x4*>(p));
-    return make_float4(v.x, v.y, v.z, v.w);
-}
-template <>
-__device__ __forceinline__ float2 fy_load_nt<float2>(const char* p) {
-    const fy_f32x2 v = __builtin_nontemporal_load(reinterpret_cast<const fy_f32x2*>(p));
-    return make_float2(v.x, v.y);
-}
-template <>
-__device__ __forceinline__ float fy_load_nt<float>(const char* p) {
-    return __builtin_nontemporal_load(reinterpret_cast<const float*>(p));
-}
 // four packed 24-bit values (12 bytes; exponent + 16 mantissa bits, no sign) -> four floats: v_perm_b32 + shift each
 __device__ __forceinline__ void fy_unpack24(const U3& d, float* f) {
     f[0] = __uint_as_float(__builtin_amdgcn_perm(0u, d.a, 0x0201000cu) >> 1);
@@ -109,11 +65,18 @@ __device__ __forceinline__ void fy_unpack24(const U3& d, float* f) {
 
 // Does a block with upper bound `ub` have to be scored exactly for a user whose N-th best seed score is `tau`?
 // tau = +inf: the user emits nothing; tau = -inf: fewer than N finite seed scores, nothing can be excluded (ties at -inf
-// are broken by item id, so even a block of -inf scores may contribute).  The margin covers the rounding of both sums.
-__device__ __forceinline__ bool fy_bound_keeps(float ub, float tau) {
+// are broken by item id, so even a block of -inf scores may contribute).
+// The margin covers the fp32 rounding of BOTH sums (the bound and the seed score behind tau).  That rounding scales with
+// the magnitude of the summed log terms, |ub - pvpi|, not with the net value |ub|: pvpi is positive whenever
+// U_c < numberOfItems (every multi-cluster job) and cancels most of the negative log sum.  Error model: a log2 term is
+// ~ -13 .. -40, eight of them are added in fp32 (partial sums up to ~300: ulp 3e-5, at most 8 roundings = 1.2e-4 per
+// batch, i.e. <= 1e-6 relative to the batch), the batches are folded in fp64: |error| <= 1e-6 * sum |log| in the worst
+// case.  With S = |pvpi| + |ub - pvpi| >= sum |log| the margin 4e-6 * S + 1e-4 is twice that bound for each of the two sums.
+__device__ __forceinline__ bool fy_bound_keeps(float ub, float tau, float pvpi) {
     if (!(ub == ub) || tau == INFINITY) return false;
     if (tau == -INFINITY) return true;
-    return ub + (1e-5f * fabsf(ub) + 1e-4f) >= tau;
+    const float S = fabsf(pvpi) + fabsf(ub - pvpi);
+    return ub + (4e-6f * S + 1e-4f) >= tau;
 }
 
 template <int VEC, bool P24, int SB>
@@ -128,13 +91,7 @@ __global__ __launch_bounds__(256) void k_score(const float* __restrict__ M_, con
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int chunk = blockIdx.x / A.n_slices;
-    int slice = blockIdx.x - chunk * A.n_slices;
-    if (A.xcd_map) {   // blocks b and b + 8 share an XCD (round-robin dispatch): give every XCD its own chunk
-        const int t = blockIdx.x >> 3;
-        chunk = (t / A.n_slices) * 8 + (blockIdx.x & 7);
-        slice = t % A.n_slices;
-        if (chunk >= A.n_chunks) return;
-    }
+    const int slice = blockIdx.x - chunk * A.n_slices;
     // fused seed + bound launch (one grid, one tail): the chunks behind the first `chunks1` belong to a second matrix
     const bool second = A.chunks1 > 0 && chunk >= A.chunks1;
     if (second) chunk -= A.chunks1;
@@ -153,18 +110,13 @@ __global__ __launch_bounds__(256) void k_score(const float* __restrict__ M_, con
     const int64_t pitch = ldm_sel * (P24 ? 3 : 4);
     const double LN2 = 0.69314718055994530942;
     const float qnan = __builtin_nanf("");
-    const bool first = A.rb == 0;
-    const int stride = A.nrb + 1;
     const int row_mul = A.row_mul ? A.row_mul : 1;
     for (int u = slice * 4 + wave; u < A.n_users; u += A.n_slices * 4) {
         const int slot = A.slot0 + u;
         if (n_out_[slot - A.slot_lo] == 0) continue;
-        const int32_t* __restrict__ ro = rb_off_ + (int64_t)(slot - A.slot_base) * stride + A.rb;
+        const int32_t* __restrict__ ro = rb_off_ + (slot - A.slot_base);
         const int beg = ro[0], end = ro[1];
-        if (!first && beg == end) continue;
         float* __restrict__ dst = Ssel + (int64_t)u * ldS_sel + col;
-        V old;
-        if (!first) old = *reinterpret_cast<const V*>(dst);      // issued early: its latency hides under the row loads
         double t[VEC];
 #pragma unroll
         for (int v = 0; v < VEC; v++) t[v] = 0.0;
@@ -180,9 +132,7 @@ __global__ __launch_bounds__(256) void k_score(const float* __restrict__ M_, con
                 const int kk = min(k + q, end - 1);
                 jj[q] = csr_idx_[kk];
                 e[q] = csr_e_[kk];
-                const char* src = Mcol + (int64_t)jj[q] * pitch;
-                if (A.nt_rows > 0 && jj[q] >= A.nt_rows) g[q] = fy_load_nt<G>(src);   // wave-uniform
-                else g[q] = *reinterpret_cast<const G*>(src);
+                g[q] = *reinterpret_cast<const G*>(Mcol + (int64_t)jj[q] * pitch);
             }
             float p[VEC];
 #pragma unroll
@@ -208,160 +158,13 @@ __global__ __launch_bounds__(256) void k_score(const float* __restrict__ M_, con
         }
         V o;
         float* ov = reinterpret_cast<float*>(&o);
-        if (first) {
-            const double base = pvpi_[slot - A.slot_lo];
+        const double base = pvpi_[slot - A.slot_lo];
 #pragma unroll
-            for (int v = 0; v < VEC; v++) ov[v] = (float)(base + LN2 * t[v]);
-        } else {
-            const float* oldv = reinterpret_cast<const float*>(&old);
-#pragma unroll
-            for (int v = 0; v < VEC; v++) ov[v] = (float)((double)oldv[v] + LN2 * t[v]);
-        }
+        for (int v = 0; v < VEC; v++) ov[v] = (float)(base + LN2 * t[v]);
 #pragma unroll
         for (int v = 0; v < VEC; v++)
             if ((mask >> v) & 1u || col + v >= Ic_sel) ov[v] = qnan;
-        if (no_mask == 1) {
-            // bound pass: column = candidate block.  Keep the blocks behind the seed whose bound (plus a margin over the
-            // rounding of both sums, each accurate to ~1e-7 relative) reaches tau_u.
-            const float t = A.tau[u];
-            int base = 0;
-            int mine[VEC];
-            unsigned long long bal[VEC];
-#pragma unroll
-            for (int v = 0; v < VEC; v++) {
-                const bool keep = fy_bound_keeps(ov[v], t) && (col + v >= A.seed_blocks);
-                bal[v] = __ballot(keep);
-                mine[v] = keep ? base + __popcll(bal[v] & ((1ull << lane) - 1ull)) : -1;
-                base += __popcll(bal[v]);
-            }
-            if (base > 0) {   // wave-uniform
-                int at = 0;
-                if (lane == 0) at = atomicAdd(&A.n_surv[u], base);
-                at = __builtin_amdgcn_readfirstlane(at);
-#pragma unroll
-                for (int v = 0; v < VEC; v++)
-                    if (mine[v] >= 0) A.surv[(int64_t)u * A.ldS + at + mine[v]] = (uint16_t)(col + v);
-            }
-            continue;
-        }
         *reinterpret_cast<V*>(dst) = o;
-    }
-}
-
-// ---------------------------------------------------------------- variant with the hottest rows resident in LDS
-// One 1024-thread workgroup per CU keeps the `H` most popular rows of its column chunk (popularity rank = row index) in
-// LDS as fp32 -- 128 rows x 1 KiB -- for its whole life and scores many users against them; those rows carry ~22 % of
-// all row reads of the ML-25M-shaped workload, which then never leave the CU.  The cold remainder of every user's row
-// is streamed from global memory exactly like k_score.  hot_off[(slot - slot_base) * 3 + {0,1,2}] = {row begin,
-// first entry with idx >= H, row end}.
-constexpr int SCORE_HOT_ROWS = 128;
-
-template <bool P24>
-__global__ __launch_bounds__(1024) void k_score_hot(const float* __restrict__ M_, const float* __restrict__ a_rank_,
-                                                    const int32_t* __restrict__ hot_off_, const int32_t* __restrict__ csr_idx_,
-                                                    const float* __restrict__ csr_e_, const double* __restrict__ pvpi_,
-                                                    const int32_t* __restrict__ n_out_, float* __restrict__ S_, ScoreArgs A) {
-    extern __shared__ float4 fy_hot_tile[];   // [H][64] float4
-    using G = typename std::conditional<P24, U3, float4>::type;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nwaves = blockDim.x >> 6;
-    const int chunk = blockIdx.x / A.n_slices;
-    const int slice = blockIdx.x - chunk * A.n_slices;
-    const int col0 = chunk * 256;
-    const int col = col0 + lane * 4;
-    const int H = min(SCORE_HOT_ROWS, A.Ic);
-    const char* __restrict__ Mcol = reinterpret_cast<const char*>(M_) + (int64_t)col * (P24 ? 3 : 4);
-    const int64_t pitch = A.ldm * (P24 ? 3 : 4);
-    // stage the hot rows: wave w loads rows w, w + nwaves, ... (one coalesced row segment per instruction)
-    for (int r = wave; r < H; r += nwaves) {
-        const G g = *reinterpret_cast<const G*>(Mcol + (int64_t)r * pitch);
-        float4 f;
-        if constexpr (P24) {
-            float t4[4];
-            fy_unpack24(g, t4);
-            f = make_float4(t4[0], t4[1], t4[2], t4[3]);
-        } else {
-            f = g;
-        }
-        fy_hot_tile[r * 64 + lane] = f;
-    }
-    float a[4];
-#pragma unroll
-    for (int v = 0; v < 4; v++) a[v] = col + v < A.Ic ? a_rank_[col + v] : 0.0f;
-    const double LN2 = 0.69314718055994530942;
-    const float qnan = __builtin_nanf("");
-    __syncthreads();
-    for (int u = slice * nwaves + wave; u < A.n_users; u += A.n_slices * nwaves) {
-        const int slot = A.slot0 + u;
-        if (n_out_[slot - A.slot_lo] == 0) continue;
-        const int32_t* __restrict__ ho = hot_off_ + (int64_t)(slot - A.slot_base) * 3;
-        const int beg = ho[0], hot_end = ho[1], end = ho[2];
-        double t[4] = {0.0, 0.0, 0.0, 0.0};
-        unsigned mask = 0;
-        // hot part: rows from LDS
-        for (int k = beg; k < hot_end; k += 8) {
-            float4 g[8];
-            float e[8];
-            int jj[8];
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-                const int kk = min(k + q, hot_end - 1);
-                jj[q] = csr_idx_[kk];
-                e[q] = csr_e_[kk];
-                g[q] = fy_hot_tile[jj[q] * 64 + lane];
-            }
-            float p[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-                if (k + q < hot_end) {
-                    p[0] += fy_log2(fmaf(a[0], e[q], g[q].x));
-                    p[1] += fy_log2(fmaf(a[1], e[q], g[q].y));
-                    p[2] += fy_log2(fmaf(a[2], e[q], g[q].z));
-                    p[3] += fy_log2(fmaf(a[3], e[q], g[q].w));
-                    const unsigned d = (unsigned)(jj[q] - col0);
-                    if (d < 256u && (int)(d >> 2) == lane) mask |= 1u << (d & 3u);
-                }
-            }
-#pragma unroll
-            for (int v = 0; v < 4; v++) t[v] += (double)p[v];
-        }
-        // cold part: rows streamed from global memory, sixteen segment loads in flight per wave (16 waves per CU)
-        constexpr int CB = 16;
-        for (int k = hot_end; k < end; k += CB) {
-            G g[CB];
-            float e[CB];
-            int jj[CB];
-#pragma unroll
-            for (int q = 0; q < CB; q++) {
-                const int kk = min(k + q, end - 1);
-                jj[q] = csr_idx_[kk];
-                e[q] = csr_e_[kk];
-                g[q] = *reinterpret_cast<const G*>(Mcol + (int64_t)jj[q] * pitch);
-            }
-            float p[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int q = 0; q < CB; q++) {
-                if (k + q < end) {
-                    float gv[4];
-                    if constexpr (P24) fy_unpack24(g[q], gv);
-                    else { gv[0] = g[q].x; gv[1] = g[q].y; gv[2] = g[q].z; gv[3] = g[q].w; }
-#pragma unroll
-                    for (int v = 0; v < 4; v++) p[v] += fy_log2(fmaf(a[v], e[q], gv[v]));
-                    const unsigned d = (unsigned)(jj[q] - col0);
-                    if (d < 256u && (int)(d >> 2) == lane) mask |= 1u << (d & 3u);
-                }
-            }
-#pragma unroll
-            for (int v = 0; v < 4; v++) t[v] += (double)p[v];
-        }
-        const double base = pvpi_[slot - A.slot_lo];
-        float4 o;
-        o.x = ((mask & 1u) || col + 0 >= A.Ic) ? qnan : (float)(base + LN2 * t[0]);
-        o.y = ((mask & 2u) || col + 1 >= A.Ic) ? qnan : (float)(base + LN2 * t[1]);
-        o.z = ((mask & 4u) || col + 2 >= A.Ic) ? qnan : (float)(base + LN2 * t[2]);
-        o.w = ((mask & 8u) || col + 3 >= A.Ic) ? qnan : (float)(base + LN2 * t[3]);
-        *reinterpret_cast<float4*>(S_ + (int64_t)u * A.ldS + col) = o;
     }
 }
 
@@ -861,16 +664,17 @@ __global__ void k_gather_rows(int32_t r0, int32_t stride, int32_t nrows, const i
 
 // owner of the user: blocks behind the seed whose (summed) bound reaches tau_u, in ascending block order
 __global__ __launch_bounds__(256) void k_bound_select(const float* __restrict__ UB, int64_t ldb, int32_t nblk, int32_t seed_blocks,
-                                                      const float* __restrict__ tau, int32_t n_users, uint16_t* __restrict__ surv,
-                                                      int32_t* __restrict__ n_surv) {
+                                                      const float* __restrict__ tau, const double* __restrict__ pvpi /* [u] */,
+                                                      int32_t n_users, uint16_t* __restrict__ surv, int32_t* __restrict__ n_surv) {
     const int lane = threadIdx.x & 63;
     const int wpb = blockDim.x >> 6;
     for (int u = blockIdx.x * wpb + (threadIdx.x >> 6); u < n_users; u += gridDim.x * wpb) {
         const float t = tau[u];
+        const float pv = (float)pvpi[u];
         int count = 0;
         for (int b0 = 0; b0 < nblk; b0 += 64) {
             const int b = b0 + lane;
-            const bool keep = b < nblk && b >= seed_blocks && fy_bound_keeps(UB[(int64_t)u * ldb + b], t);
+            const bool keep = b < nblk && b >= seed_blocks && fy_bound_keeps(UB[(int64_t)u * ldb + b], t, pv);
             const unsigned long long bal = __ballot(keep);
             if (keep) surv[(int64_t)u * ldb + count + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)b;
             count += __popcll(bal);

@@ -85,6 +85,10 @@ class Context:
     def synchronize(self):
         _check(self._lib.fy_context_synchronize(self._h))
 
+    def inject_alloc_failure(self, nth):
+        """Fault injection (tests): the nth HBM request from now fails with FY_ERR_OUT_OF_MEMORY; 0 disarms."""
+        _check(self._lib.fy_context_inject_alloc_failure(self._h, int(nth)))
+
     @property
     def stream(self):
         return self._lib.fy_context_stream(self._h)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FY_ABI_VERSION 1
+#define FY_ABI_VERSION 2
 
 typedef enum {
     FY_OK = 0,
@@ -57,6 +57,10 @@ const char* fy_last_error(void);
 int fy_context_create(int device_ordinal, fy_context** out);
 void fy_context_destroy(fy_context*);
 int fy_context_synchronize(fy_context*);
+/* Fault injection for the error-path tests (the reference has none): the nth HBM request of this
+ * context from now on (1 = the next one) fails with FY_ERR_OUT_OF_MEMORY; 0 disarms.  A failed job leaves the context
+ * usable: every stream is drained before any buffer of the job is released. */
+int fy_context_inject_alloc_failure(fy_context*, int64_t nth);
 /* The hipStream_t of the context (as void*), e.g. to order caller-side copies against the job. */
 void* fy_context_stream(fy_context*);
 
@@ -210,6 +214,7 @@ typedef struct {
     int64_t blocks_total;        /* RM2 branch and bound: (user, 256-column block) pairs behind the seed columns ... */
     int64_t blocks_survived;     /* ... and how many of them had to be scored exactly */
     int64_t log_terms_evaluated; /* log terms actually evaluated (seed + bound + survivor passes); 0 = no pruning: log_terms */
+    int64_t prune_fallbacks;     /* user batches whose bound did not bite (e.g. lambda = 0) and that were redone with the full pass */
 } fy_stats;
 int fy_result_stats(fy_result*, fy_stats* out);
 

@@ -1,0 +1,40 @@
+"""Config C4 of BASELINE.json: Netflix-Prize-shaped synthetic ratings (480 189 x 17 770, 100 M ratings, integers 1..5),
+RM2 top-100 + item-item similarity.  The only config that takes the two-chunk seed of the branch and bound (N = 100) and
+the single-LDS-chunk row kernel.  Same checks as at ML-25M shape (tests/fullsize_checks.py), including the all-rows
+comparison of the pruned job with the plain full pass (48 M rows)."""
+import pytest
+
+from fullsize_checks import assert_same_lists, check_itemsim, check_rm2, load_shape, run_rm2
+
+pytestmark = pytest.mark.gpu
+LAM, TOPN = 0.1, 100
+
+
+@pytest.fixture(scope="module")
+def data():
+    return load_shape("netflix")
+
+
+@pytest.fixture(scope="module")
+def pruned(data):
+    return run_rm2(data, TOPN, LAM)
+
+
+def test_rm2_netflix_shape(data, pruned):
+    rows, sums, st = pruned
+    assert st["blocks_total"] > 0 and st["blocks_survived"] < 0.05 * st["blocks_total"]
+    worst = check_rm2(data, rows, sums, st, TOPN, LAM, n_picks=6)
+    print("netflix-shape worst relative error vs fp64 definition: %.2e" % worst)
+
+
+def test_rm2_netflix_pruned_equals_full_pass_all_rows(data, pruned):
+    rows, _, st = pruned
+    rows_full, _, st_full = run_rm2(data, TOPN, LAM, env={"FY_PRUNE": "0"})
+    assert st_full["blocks_total"] == 0 and st_full["recs"] == st["recs"]
+    n_diff, worst = assert_same_lists(rows, rows_full)
+    print("pruned vs full pass: %d rows, %d differ (ties at a cut-off), worst score difference %.2e" % (len(rows["user"]), n_diff, worst))
+    assert n_diff <= 1e-5 * len(rows["user"])
+
+
+def test_itemsim_netflix_shape(data):
+    check_itemsim(data, n_rows=4)

@@ -163,3 +163,80 @@ def test_failing_collective_fails_the_job(forced):
     with pytest.raises(RuntimeError, match="RM2 failed!: collective"):
         P.RM2Job(conf, ctx).run(data, clustering=clustering, rank=0, world=2, collectives=Broken())
     ctx.close()
+
+
+def test_threshold_that_does_not_bite_falls_back_to_the_full_pass(forced, monkeypatch):
+    """lambda = 0 is legal (the reference accepts it): a user who rated an item nobody else of the cluster rated has only
+    -inf scores, tau = -inf keeps every block.  Such batches are redone with the plain full pass instead of a survivor
+    pass over (almost) everything; FY_MAX_SURV_FRAC=0 forces the fallback for every batch."""
+    P = pkg()
+    data, clustering, conf, ref = make("ml100k", 3, "0.0", 30)
+    monkeypatch.setenv("FY_MAX_SURV_FRAC", "0")
+    ctx = P.Context(0)
+    rec = P.RM2Job(conf, ctx).run(data, clustering=clustering)
+    assert rec.stats["prune_fallbacks"] == 3 and rec.stats["blocks_total"] > 0
+    assert_topn_matches(rec.rows(), ref, 30)
+    ctx.close()
+
+
+def test_margin_with_heavy_users_and_positive_pvpi(forced):
+    """The rounding of the bound scales with the sum of |log| terms, not with the net |UB|: with numberOfItems >> U_c the
+    positive pvpi cancels most of the log sum (every multi-cluster job).  Heavy users, 8 clusters, numberOfItems forced
+    large, pruning on vs off: identical lists."""
+    import os
+    P = pkg()
+    S = synth()
+    u, i, s, facts = S.generate("ml1m")
+    u, i, s = u.numpy(), i.numpy(), s.numpy()
+    uu = np.unique(u)
+    K = 8
+    clustering = (uu, S.hash_clustering(uu, K))
+    conf = P.Configuration()
+    conf.set("lambda", "0.1")
+    conf.setInt("numberOfItems", 5_000_000)        # pvpi = (n - 1) ln(5e6) - n ln(U_c) > 0 and large
+    conf.setInt("numberOfClusters", K)
+    conf.setInt("numberOfRecommendations", 50)
+    ctx = P.Context(0)
+    pruned = P.RM2Job(conf, ctx).run((u, i, s), clustering=clustering)
+    assert pruned.stats["blocks_total"] > 0 and pruned.stats["prune_fallbacks"] == 0
+    rp = pruned.rows()
+    os.environ["FY_PRUNE"] = "0"
+    try:
+        full = P.RM2Job(conf, ctx).run((u, i, s), clustering=clustering)
+    finally:
+        del os.environ["FY_PRUNE"]
+    assert full.stats["blocks_total"] == 0
+    from fullsize_checks import assert_same_lists
+    n_diff, worst = assert_same_lists(rp, full.rows())
+    assert n_diff <= 2, n_diff
+    ctx.close()
+
+
+def test_failed_multi_cluster_job_leaves_the_context_usable(forced):
+    """an error thrown while several clusters are in flight on the lane streams must drain those lanes before
+    the job's buffers go back to the caching allocator.  Every k-th HBM request of a 3-cluster pruned job is made to fail
+    (fy_context_inject_alloc_failure); after each failure a clean job on the SAME context must still match the oracle."""
+    P = pkg()
+    data, clustering, conf, ref = make("ml100k", 3, "0.5", 100)
+    ctx = P.Context(0)
+    ratings = P.Ratings(ctx, *data)
+    failures = 0
+    nth = 1
+    while True:
+        ctx.inject_alloc_failure(nth)
+        try:
+            rec = P.RM2Job(conf, ctx).run(ratings, clustering=clustering)
+        except P.FilmYouError as e:
+            assert "injected fault" in str(e)
+            failures += 1
+            ctx.inject_alloc_failure(0)
+            clean = P.RM2Job(conf, ctx).run(ratings, clustering=clustering)
+            assert_topn_matches(clean.rows(), ref, 100)
+            clean.close()
+            nth += 7
+            continue
+        ctx.inject_alloc_failure(0)
+        assert_topn_matches(rec.rows(), ref, 100)     # nth beyond the job's last request: it ran to completion
+        break
+    assert failures >= 10, failures
+    ctx.close()
