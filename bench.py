@@ -1,27 +1,30 @@
 #!/usr/bin/env python3
 """bench.py -- whole-job throughput of the RM2 top-N scorer (and the item-item similarity build) on MI355X.
 
-Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by
-`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`, one rank per GPU over RCCL.
+Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`.  For N > 1 one rank per GPU over
+RCCL: either the driver launches this file under `python -m torch.distributed.run --nproc-per-node N ...` (RANK /
+LOCAL_RANK / WORLD_SIZE in the environment), or -- WORLD_SIZE unset -- this script starts the N ranks itself, as child
+processes, BEFORE anything touches a GPU, and exits with their code.
 One "step" = one complete RM2 job over the ML-25M-shaped synthetic ratings, which are resident in HBM when the timed
 region starts: COO -> CSR/CSC, statistics, (all-gather), per-cluster co-rating matrix, scoring, top-N.
 Rank 0 prints ONE JSON line.  `value` = top-N recommendation rows produced by all ranks per second.
 """
 import argparse
+import hashlib
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np
-import torch
-import torch.distributed as dist
-
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+L2_PEAK_GBS = 34500.0   # MI355X_MICROARCH.md, "L2 (per XCD)": ~34.5 TB/s aggregate over the 8 XCDs
+DTYPE = "f32 (scores and logs fp32 / v_log_f32, folded in fp64; co-rating sums fp64; M stored as 24-bit e8m16 floats above 4096 items; ratings fp16 in the row kernel when exactly representable)"
 
 
 def parse():
@@ -33,38 +36,88 @@ def parse():
     ap.add_argument("--clusters", type=int, default=1, help="numberOfClusters (users hashed to clusters); 1 = one neighbourhood")
     ap.add_argument("--top-n", type=int, default=None)
     ap.add_argument("--lam", type=float, default=0.1)
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
     ap.add_argument("--no-itemsim", action="store_true", help="skip the item-item similarity leg")
     ap.add_argument("--no-factorization", action="store_true", help="skip the PPC factorisation + cluster assignment leg")
+    ap.add_argument("--no-regime", action="store_true", help="skip the reference-regime legs (50 clusters; top-1000)")
     ap.add_argument("--cpu-users", type=int, default=0, help="users in the CPU sample cluster (0 = auto)")
     return ap.parse_args()
 
 
-def cpu_baseline(S, shape, facts, lam, top_n, n_users_sample):
-    """The faithful CPU oracle (kind "port": this image has no JVM for the reference itself) timed on a bounded
-    sample: one cluster of `n_users_sample` users drawn from the same synthetic data set, scored with the reference's
-    brute-force loop nest on the host cores."""
+def launch_ranks(n):
+    """WORLD_SIZE unset and --gpus N > 1: start the N ranks ourselves (torch.distributed.run, rendezvous on 127.0.0.1).
+    Nothing in this process has touched a GPU yet; the ranks are fresh child processes."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def source_rev():
+    """Hash of the kernel sources the roofline numbers belong to (profiles/rN/traffic.json is stamped with it)."""
+    h = hashlib.sha256()
+    for f in ("fy_cooc.hpp", "fy_rm2.hip", "fy_rm2_kernels.hpp"):
+        with open(os.path.join(ROOT, "filmyou-core_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def cpu_legs(S, shape, facts, lam, top_n, n_users_sample, np):
+    """CPU baselines (kind "port": this image has no JVM for the reference itself), all on bounded samples of the same
+    synthetic data set, on the host cores of the GPU box:
+      cpu_baseline        the faithful oracle (the reference's brute-force loop nest), OpenMP over the target users, all cores
+      cpu_baseline_1core  the same on one core = what Hadoop's LocalJobRunner (a serial reducer) would do
+      cpu_baseline_gram   a CPU scorer restructured like the GPU path (cluster Gram + per-user correction): the "best CPU" line
+    """
     import oracle
-    cores = max(1, min(16, os.cpu_count() or 1))
+    cores = max(1, os.cpu_count() or 1)
     rng = np.random.Generator(np.random.PCG64(7))
-    users = np.sort(rng.choice(facts["n_users"], size=min(n_users_sample, facts["n_users"]), replace=False)) + 1
-    u, i, s, _ = S.generate(shape, users=users, device="cpu")
-    u, i, s = u.numpy(), i.numpy(), s.numpy()
-    t0 = time.time()
-    ref = oracle.rm2(u, i, s, lam=lam, number_of_items=facts["n_items"], number_of_recommendations=top_n,
-                     number_of_clusters=1, n_threads=cores)
-    dt = time.time() - t0
-    recs = len(ref["rec_user"])
-    return {"value": recs / dt, "unit": "recs/s", "cores": cores, "kind": "port",
-            "sample": "one %d-user cluster sampled from the same %s-shaped data (%d ratings, %d candidate items, "
-                      "%.3g log-terms x %d neighbours), oracle/rm2_oracle.c with %d OpenMP threads, %.1f s; the "
-                      "reference's cost per term grows with the cluster size, the GPU path's does not"
-                      % (len(users), shape, len(u), len(ref["item_id"]), ref["log_terms"], len(users) - 1, cores, dt),
-            "seconds": dt, "log_terms_per_s": ref["log_terms"] / dt}
+    out = {}
+
+    def sample(n):
+        users = np.sort(rng.choice(facts["n_users"], size=min(n, facts["n_users"]), replace=False)) + 1
+        u, i, s, _ = S.generate(shape, users=users, device="cpu")
+        return users, u.numpy(), i.numpy(), s.numpy()
+
+    def leg(kind, n, threads, fn):
+        users, u, i, s = sample(n)
+        t0 = time.time()
+        ref = fn(u, i, s, threads)
+        dt = time.time() - t0
+        recs = len(ref["rec_user"])
+        return {"value": recs / dt, "unit": "recs/s", "cores": threads, "kind": "port", "host_nproc": cores,
+                "sample": "one %d-user cluster sampled from the same %s-shaped data (%d ratings, %d candidate items, %.3g log-terms), "
+                          "%s, %d thread(s), %.1f s" % (len(users), shape, len(u), len(ref["item_id"]), ref["log_terms"], kind, threads, dt),
+                "seconds": dt, "log_terms_per_s": ref["log_terms"] / dt}
+
+    brute = lambda u, i, s, th: oracle.rm2(u, i, s, lam=lam, number_of_items=facts["n_items"], number_of_recommendations=top_n,
+                                           number_of_clusters=1, n_threads=th)
+    out["cpu_baseline"] = leg("oracle/rm2_oracle.c (the reference's loop nest: U_c - 1 multiply-adds per log term)", n_users_sample, cores, brute)
+    out["cpu_baseline"]["note"] = ("the reference's cost per term grows with the cluster size, the GPU path's does not: "
+                                   "a GPU/CPU ratio taken from this line mostly measures that O(U_c) loop, not kernel quality")
+    n1 = max(40, int(n_users_sample / max(1.0, cores ** (1.0 / 3.0)) / 1.6))
+    out["cpu_baseline_1core"] = leg("oracle/rm2_oracle.c, serial (LocalJobRunner runs one reducer thread)", n1, 1, brute)
+    if hasattr(oracle, "rm2_gram"):
+        gram = lambda u, i, s, th: oracle.rm2_gram(u, i, s, lam=lam, number_of_items=facts["n_items"], number_of_recommendations=top_n,
+                                                   number_of_clusters=1, n_threads=th)
+        out["cpu_baseline_gram"] = leg("oracle/rm2_gram.c (Gram-restructured CPU scorer, same math as the GPU path)",
+                                       {"ml25m": 3000, "netflix": 3000}.get(shape, 2000), cores, gram)
+    return out
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ and os.environ.get("FY_BENCH_REHEARSAL") != "1":
+        sys.exit(launch_ranks(a.gpus))
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
     P = importlib.import_module("filmyou-core_amd")
     S = importlib.import_module("filmyou-core_amd.synth")
     par = importlib.import_module("filmyou-core_amd.parallel")
@@ -72,8 +125,8 @@ def main():
     # one-GPU box (RCCL refuses two ranks on one device); never used for reported numbers
     rehearsal = os.environ.get("FY_BENCH_REHEARSAL") == "1"
     rank, local_rank, world = par.init_distributed(backend="gloo" if rehearsal else None)
-    if world != a.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    if world != a.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: the line would be labelled with the wrong GPU count" % (a.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     if rehearsal:
@@ -87,35 +140,25 @@ def main():
     user, item, score, facts = S.generate(a.shape, device=dev)
     torch.cuda.synchronize()
     gen_s = time.time() - t0
-    K = a.clusters
-    clustering = None
-    if K > 1:
-        uu = np.arange(1, facts["n_users"] + 1, dtype=np.int32)
-        clustering = (uu, S.hash_clustering(uu, K))
 
-    conf = P.Configuration()
-    conf.set("lambda", repr(a.lam))
-    conf.setInt("numberOfItems", facts["n_items"])
-    conf.setInt("numberOfClusters", K)
-    conf.setInt("numberOfRecommendations", top_n)
     ctx = P.Context(local_rank)
     ratings = P.Ratings(ctx, user, item, score)       # resident in HBM before the timed region
-    # world > 1: RCCL collectives through torch.distributed (fy_collectives): the item statistics are all-gathered and
-    # a cluster that spans all ranks is scored cooperatively (row-sharded matrix build, reduce-scattered partial sums);
+    # world > 1: RCCL collectives (fy_collectives): the item statistics are all-gathered and a cluster that spans all
+    # ranks is scored cooperatively (row-sharded matrix build, reduce-scattered partial sums).  Transport: the compiled
+    # RCCL binding of the library when it is present, else torch.distributed on the library's stream;
     # FY_BENCH_EXCHANGE_ONLY=1 keeps the round-1 flow (statistics exchange only, matrix replicated) for comparison
     exchange = collectives = None
+    transport = None
     if world > 1:
         if os.environ.get("FY_BENCH_EXCHANGE_ONLY") == "1":
             exchange = par.StatsExchange(local_rank)
+            transport = "statistics all-gather only (torch.distributed/%s)" % dist.get_backend()
+        elif not rehearsal and hasattr(par, "RcclCollectives") and os.environ.get("FY_BENCH_TORCH_COLLECTIVES") != "1":
+            collectives = par.RcclCollectives(ctx, rank, world)
+            transport = "librccl.so through the library's compiled fy_collectives (ncclAllGather / ncclReduceScatter on the job's stream)"
         else:
             collectives = par.TorchCollectives(local_rank)
-    job = P.RM2Job(conf, ctx)
-
-    def step():
-        rec = job.run(ratings, clustering=clustering, rank=rank, world=world, exchange=exchange, collectives=collectives)
-        st = rec.stats
-        rec.close()
-        return st
+            transport = "torch.distributed/%s on the job's stream" % dist.get_backend()
 
     def fence():
         ctx.synchronize()
@@ -132,83 +175,128 @@ def main():
             else:
                 dist.all_reduce(t, op=op)
 
-    for _ in range(a.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    stats = [step() for _ in range(a.steps)]
-    fence()
-    elapsed = time.perf_counter() - t0
-    tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    recs = torch.tensor([float(stats[-1]["recs"]), float(stats[-1]["log_terms"]), float(stats[-1]["users_scored"])],
-                        dtype=torch.float64, device=dev)
-    reduce_(tt, dist.ReduceOp.MAX)
-    reduce_(recs, dist.ReduceOp.SUM)
-    elapsed = float(tt.item())
-    total_recs, total_terms, total_users = (float(x) for x in recs.tolist())
+    def time_job(K, n_rec, steps, warmup):
+        """W untimed + K timed complete jobs between fences; returns (per-step stats, elapsed seconds = max over ranks, totals)."""
+        clustering = None
+        if K > 1:
+            uu = np.arange(1, facts["n_users"] + 1, dtype=np.int32)
+            clustering = (uu, S.hash_clustering(uu, K))
+        conf = P.Configuration()
+        conf.set("lambda", repr(a.lam))
+        conf.setInt("numberOfItems", facts["n_items"])
+        conf.setInt("numberOfClusters", K)
+        conf.setInt("numberOfRecommendations", n_rec)
+        job = P.RM2Job(conf, ctx)
+
+        def step():
+            rec = job.run(ratings, clustering=clustering, rank=rank, world=world, exchange=exchange, collectives=collectives)
+            st = rec.stats
+            rec.close()
+            return st
+
+        for _ in range(warmup):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        stats = [step() for _ in range(steps)]
+        fence()
+        elapsed = time.perf_counter() - t0
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tot = torch.tensor([float(stats[-1]["recs"]), float(stats[-1]["log_terms"]), float(stats[-1]["users_scored"])],
+                           dtype=torch.float64, device=dev)
+        reduce_(tt, dist.ReduceOp.MAX)
+        reduce_(tot, dist.ReduceOp.SUM)
+        return stats, float(tt.item()), [float(x) for x in tot.tolist()], (job, clustering)
+
+    K = a.clusters
+    stats, elapsed, (total_recs, total_terms, total_users), (job, clustering) = time_job(K, top_n, a.steps, a.warmup)
     ms_per_step = 1e3 * elapsed / a.steps
 
     # ---- roofline of the dominant kernel, from HIP events the library records on ITS stream around every launch.
     # Candidates: the co-rating row kernel (k_cooc_rm2, builds M) and the scoring kernels (k_score*, one family).
     # Algorithmic bytes are SURVEY.md 8d's: 8 B per unordered co-rating pair contribution / 4 B per evaluated log-term.
     st = stats[-1]
-    ms_score = float(np.mean([s["ms_score"] for s in stats]))
-    ms_cooc = float(np.mean([s["ms_cooc"] for s in stats]))
+    mean = lambda k: float(np.mean([s[k] for s in stats]))
+    ms_score, ms_cooc = mean("ms_score"), mean("ms_cooc")
     terms_eval = st["log_terms_evaluated"] if st["log_terms_evaluated"] > 0 else st["log_terms"]
     unordered_pairs = (st["pair_contribs"] - st["nnz"]) // 2
-    cand = {
-        "k_cooc_rm2": {"ms": ms_cooc, "bytes": 8.0 * unordered_pairs, "launches": st["cooc_launches"]},
-        "k_score": {"ms": ms_score, "bytes": 4.0 * terms_eval, "launches": st["score_launches"]},
-    }
-    dom = max(cand, key=lambda k: cand[k]["ms"])
+    rev = source_rev()
+    # HBM-side bytes per launch from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same command
+    # (tools/profile_round.sh), corrected as MI355X_MICROARCH.md prescribes; committed under profiles/ and stamped with
+    # the hash of the kernel sources it was measured on -- a stale file gives null, not an old number
+    traffic, traffic_note = {}, "no profiles/r*/traffic.json"
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")))
+    if cands and a.shape == "ml25m" and K == 1:
+        with open(cands[-1]) as f:
+            tj = json.load(f)
+        if tj.get("source_rev") == rev:
+            traffic, traffic_note = tj, "%s (rocprofv3 --pmc, same kernel sources %s)" % (os.path.relpath(cands[-1], ROOT), rev)
+        else:
+            traffic_note = "%s was measured on kernel sources %s, this build is %s: not reported" % (os.path.relpath(cands[-1], ROOT), tj.get("source_rev"), rev)
 
-    def roof(name):
-        c = cand[name]
-        ach = c["bytes"] / (c["ms"] * 1e-3) / 1e9 if c["ms"] > 0 else 0.0
-        return {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS, "traffic": None, "launches_per_step": c["launches"],
-                "avg_launch_ms": c["ms"] / max(1, c["launches"]),
-                "algorithmic_bytes_per_launch": c["bytes"] / max(1, c["launches"])}
+    roofline = {"bound": "hbm", "kernel": "k_cooc_rm2", "achieved": 8.0 * unordered_pairs / (ms_cooc * 1e-3) / 1e9 if ms_cooc > 0 else 0.0,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": traffic.get("k_cooc_rm2", {}).get("hbm_bytes_per_launch"),
+                "traffic_source": traffic_note, "launches_per_step": st["cooc_launches"],
+                "avg_launch_ms": ms_cooc / max(1, st["cooc_launches"]),
+                "algorithmic_bytes_per_launch": 8.0 * unordered_pairs / max(1, st["cooc_launches"]),
+                "share_of_step": ms_cooc / ms_per_step if ms_per_step > 0 else None}
+    roofline["frac"] = roofline["achieved"] / HBM_PEAK_GBS
+    # The scoring family is NOT priced against HBM: the branch and bound evaluates ~1.4 % of the reference's log terms and
+    # the column panels it reads (seed columns, block maxima) live in L2 / Infinity Cache, so an HBM fraction means nothing
+    # there (round 1 printed 1.09).  Its bound is the L2: 4 B per EVALUATED log term against the aggregate L2 bandwidth.
+    other = {"bound": "l2", "kernel": "k_score family (seed + bound pass, survivor pass)",
+             "achieved": 4.0 * terms_eval / (ms_score * 1e-3) / 1e9 if ms_score > 0 else 0.0, "peak": L2_PEAK_GBS, "unit": "GB/s",
+             "log_terms_evaluated": terms_eval, "log_terms_reference": st["log_terms"],
+             "reference_terms_per_s": st["log_terms"] / (ms_score * 1e-3) if ms_score > 0 else None,
+             "blocks_survived_frac": (st["blocks_survived"] / st["blocks_total"]) if st["blocks_total"] else None,
+             "traffic": traffic.get("k_score", {}).get("hbm_bytes_per_launch"), "ms": ms_score,
+             "note": "4 B per evaluated log term against the L2; SURVEY 8d's unit (4 B x the reference's terms) does not apply: "
+                     "98.6 % of those terms are excluded by the exact bound, never read"}
+    other["frac"] = other["achieved"] / L2_PEAK_GBS
 
-    roofline = roof(dom)
-    if a.shape == "ml25m" and K == 1:
-        # HBM-side bytes per launch from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same command
-        # (tools/profile_round.sh), corrected as MI355X_MICROARCH.md prescribes; committed under profiles/
-        import glob
-        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")))
-        if cands:
-            with open(cands[-1]) as f:
-                tj = json.load(f)
-            if dom in tj:
-                roofline["traffic"] = tj[dom]["hbm_bytes_per_launch"]
-    other = roof("k_score" if dom != "k_score" else "k_cooc_rm2")
-    other["log_terms_evaluated"] = terms_eval
-    other["log_terms_reference"] = st["log_terms"]
-    other["blocks_survived_frac"] = (st["blocks_survived"] / st["blocks_total"]) if st["blocks_total"] else None
-    other["note"] = ("scoring family (seed pass, block-maximum bound pass, survivor pass); frac > 1 would mean the column "
-                     "panels are served from L2 / Infinity Cache")
-
+    phases = {k: mean(k) for k in ("ms_prepare", "ms_tables", "ms_cooc", "ms_score", "ms_topn", "ms_total")}
+    phases["ms_job"] = phases["ms_prepare"] + phases["ms_total"]            # ms_total = everything after prepare (HIP events)
+    phases["ms_other_in_job"] = phases["ms_total"] - phases["ms_tables"] - phases["ms_cooc"] - phases["ms_score"] - phases["ms_topn"]
+    phases["ms_host_gaps"] = ms_per_step - phases["ms_job"]                  # wall clock outside the two event spans
     out = {
         "metric": "top-N recs/sec (RM2), %s shape" % a.shape, "value": total_recs / (elapsed / a.steps), "unit": "recs/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "strong", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
         "config": {"workload": "%s-shaped synthetic ratings (%d users x %d items, %d nnz), RM2 top-%d, lambda %g, "
                                "numberOfClusters %d, users range-sharded over %d GPU(s)"
                                % (a.shape, facts["n_users"], facts["n_items"], facts["nnz"], top_n, a.lam, K, world),
-                   "shape": a.shape, "top_n": top_n, "clusters": K, "lambda": a.lam, "nnz": facts["nnz"]},
+                   "shape": a.shape, "top_n": top_n, "clusters": K, "lambda": a.lam, "nnz": facts["nnz"],
+                   "headline": "one neighbourhood (numberOfClusters 1) is the hardest case and one the reference cannot run "
+                               "(its dense cache would need 77 TB); the reference's own regime is in reference_regime"},
         "lists_per_s": total_users / (elapsed / a.steps), "log_terms_per_step": total_terms,
-        "phase_ms_rank0": {k: float(np.mean([s[k] for s in stats])) for k in ("ms_prepare", "ms_cooc", "ms_score", "ms_topn", "ms_total")},
-        "datagen_s": gen_s, "roofline": roofline, "roofline_other_kernel": other,
+        "phase_ms_rank0": phases, "datagen_s": gen_s, "roofline": roofline, "roofline_other_kernel": other,
+        "kernel_source_rev": rev,
     }
 
     if world > 1:
         n_runs = a.steps + a.warmup
-        out["multi_gpu"] = {"mode": "statistics exchange only (matrix replicated per rank)" if collectives is None else
-                            "fy_collectives over torch.distributed/%s: statistics all-gather + cooperative scoring of clusters "
-                            "that span all ranks" % dist.get_backend(),
-                            "collective_calls_per_step": None if collectives is None else
-                            {k: v / n_runs for k, v in collectives.calls.items() if k != "bytes"},
-                            "payload_bytes_per_rank_per_step": None if collectives is None else collectives.calls["bytes"] / n_runs}
+        calls = getattr(collectives, "calls", None)
+        out["multi_gpu"] = {"rccl_ranks": 0 if rehearsal else world, "transport": transport,
+                            "collective_calls_per_step": None if not calls else {k: v / n_runs for k, v in calls.items() if k != "bytes"},
+                            "payload_bytes_per_rank_per_step": None if not calls else calls["bytes"] / n_runs}
+        out["cpu_baseline"] = None
+        out["cpu_baseline_note"] = "timed on rank 0 of the N = 1 run only (see that line)"
+
+    # ---- the reference's own operating regime, beside the headline: many clusters (numberOfClusters is a required option,
+    # 50 in T/rmrecommender/TestRMRecommenderJob.java:49) and the default list length 1000 (RMRecommenderDriver.java:95)
+    if world == 1 and not a.no_regime and a.shape == "ml25m" and K == 1:
+        reg = {}
+        for name, kk, nn in (("clusters_50_top_50", 50, top_n), ("clusters_50_top_1000", 50, 1000), ("clusters_1_top_1000", 1, 1000)):
+            try:
+                s2, el2, (r2, t2, u2), _ = time_job(kk, nn, 2, 1)
+                reg[name] = {"value": r2 / (el2 / 2), "unit": "recs/s", "ms_per_step": 1e3 * el2 / 2, "lists_per_s": u2 / (el2 / 2),
+                             "log_terms_per_s": t2 / (el2 / 2),
+                             "phase_ms": {k: float(np.mean([x[k] for x in s2])) for k in ("ms_prepare", "ms_tables", "ms_cooc", "ms_score", "ms_topn", "ms_total")},
+                             "pruned": bool(s2[-1]["blocks_total"] > 0)}
+            except RuntimeError as e:
+                reg[name] = {"error": str(e)}
+        out["reference_regime"] = reg
 
     # ---- item-item similarity build on the same ratings (second headline unit: pairs/s)
     if not a.no_itemsim:
@@ -291,8 +379,11 @@ def main():
                                  "note": "host COO -> HBM -> job -> rows back in host memory, one run"}
     if rank == 0 and world == 1 and not a.no_cpu:
         n_cpu = a.cpu_users or {"ml25m": 270, "netflix": 200, "ml1m": 800, "ml100k": 943}.get(a.shape, 200)
-        out["cpu_baseline"] = cpu_baseline(S, a.shape, facts, a.lam, top_n, n_cpu)
-    elif rank == 0:
+        out.update(cpu_legs(S, a.shape, facts, a.lam, top_n, n_cpu, np))
+        bl = importlib.import_module("tools.cpu_baselines") if os.path.exists(os.path.join(ROOT, "tools", "cpu_baselines.py")) else None
+        if bl is not None:
+            out.update(bl.extra_legs(P, S, ctx, a.lam))
+    elif rank == 0 and world == 1:
         out["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(out))

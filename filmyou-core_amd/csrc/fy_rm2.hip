@@ -647,8 +647,9 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
     R->st.n_users = P.nU;
     R->st.n_items = P.nI;
     R->st.ms_prepare = J->ms_prepare;
-    EventTimer t_total(ctx), t_cooc(ctx), t_score(ctx), t_topn(ctx);
+    EventTimer t_total(ctx), t_cooc(ctx), t_score(ctx), t_topn(ctx), t_tables(ctx);
     const size_t span_total = t_total.begin();
+    size_t span_tables = t_tables.begin();
     if (P.nnz == 0) {
         t_total.end(span_total);
         sync(ctx);
@@ -686,6 +687,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                                                                    p_rank.get(), b_rank.get(), lambda, csr_x.get(), csr_e.get());
     FY_KERNEL_CHECK();
 
+    t_tables.end(span_tables);
     // ---- which users this rank emits lists for
     J->count_balanced = false;
     if (prm.world > 1 && J->have_coll && tune.coop && tune.prune && pack24_allowed) {
@@ -853,6 +855,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
         for (auto& p : plans) any_coop = any_coop || p.coop;
         // segment tables of the row kernel, one per cluster, built on the main stream before the lanes fork
         std::vector<SegTable> segs(plans.size());
+        span_tables = t_tables.begin();
         {
             size_t co_all = 1;
             for (auto& p : plans) co_all = std::max(co_all, (size_t)p.Uc * (p.nch + 1));
@@ -874,6 +877,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 build_segments(ctx, P.csc_slot.get(), use_pk ? csc_x_over_s.get() : csc_x.get(), co_tmp.get(), p.sbase, p.q0, p.nq, p.nch, segs[pi]);
             }
         }
+        t_tables.end(span_tables);
         // Error path: anything thrown below (an allocation, a launch, a collective) unwinds the lanes' buffers, the segment
         // tables and the per-job arrays back into the caching allocator while kernels of OTHER lanes may still be reading
         // them.  The guard drains every lane and the main stream first (members are destroyed in reverse order of
@@ -1089,6 +1093,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
     R->st.ms_score = t_score.total_ms();
     R->st.ms_topn = t_topn.total_ms();
     R->st.ms_total = t_total.total_ms();
+    R->st.ms_tables = t_tables.total_ms();
     return R.release();
 }
 

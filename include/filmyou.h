@@ -215,6 +215,7 @@ typedef struct {
     int64_t blocks_survived;     /* ... and how many of them had to be scored exactly */
     int64_t log_terms_evaluated; /* log terms actually evaluated (seed + bound + survivor passes); 0 = no pruning: log_terms */
     int64_t prune_fallbacks;     /* user batches whose bound did not bite (e.g. lambda = 0) and that were redone with the full pass */
+    double ms_tables;            /* RM2: p(i|C), per-rating values, packed CSR, chunk offsets and segment tables (between prepare and the M build) */
 } fy_stats;
 int fy_result_stats(fy_result*, fy_stats* out);
 

@@ -2,7 +2,9 @@
 """profiles/rN/summary_pmc_{fetch,write}.txt -> profiles/rN/traffic.json: HBM-side bytes per launch of the two kernel
 families bench.py prices (gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md: the counter reads half of a wide
 coalesced read, so it is doubled; WRITE_SIZE is exact).  Usage: make_traffic_json.py profiles/rN"""
+import hashlib
 import json
+import os
 import re
 import sys
 
@@ -23,7 +25,18 @@ def family(prefix):
             "hbm_bytes_per_launch": (2 * fs + ws) * 1024 / max(n, 1)}
 
 
-out = {"k_cooc_rm2": family("k_cooc_rm2"), "k_score": family("k_score"),
+def source_rev():
+    """the same hash bench.py computes: the file is only reported for the kernel sources it was measured on"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for name in ("fy_cooc.hpp", "fy_rm2.hip", "fy_rm2_kernels.hpp"):
+        with open(os.path.join(root, "filmyou-core_amd", "csrc", name), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+out = {"source_rev": sys.argv[2] if len(sys.argv) > 2 else source_rev(),
+       "k_cooc_rm2": family("k_cooc_rm2"), "k_score": family("k_score"),
        "note": "FETCH_SIZE (KB) doubled per MI355X_MICROARCH.md; summed over the launches of the profiled jobs and divided by "
                "their number; config: ml25m shape, numberOfClusters 1, top-50 (python3 bench.py --steps 1 --warmup 1 --no-cpu)"}
 json.dump(out, open(d + "/traffic.json", "w"), indent=1)

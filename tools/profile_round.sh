@@ -6,7 +6,7 @@ TAG=$1; shift
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
-ARGS="--steps 1 --warmup 1 --no-cpu $*"
+ARGS="--steps 1 --warmup 1 --no-cpu --no-regime $*"
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t --output-format csv -- python3 bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err || exit 1
 python3 tools/prof_summary.py $OUT/trace > $OUT/summary_trace.txt
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o p --output-format csv -- python3 bench.py $ARGS > /dev/null 2> $OUT/pmc_fetch.err || exit 2
