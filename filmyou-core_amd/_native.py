@@ -12,16 +12,16 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libfilmyou_hip.so")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include", "filmyou.h")
-SOURCES = ["fy_api.hip", "fy_prep.hip", "fy_rm2.hip", "fy_itemsim.hip", "fy_itemcf.hip", "fy_cluster.hip", "fy_nmf.hip"]
+SOURCES = ["fy_api.hip", "fy_prep.hip", "fy_rm2.hip", "fy_itemsim.hip", "fy_itemcf.hip", "fy_cluster.hip", "fy_nmf.hip", "fy_rccl.hip"]
 HEADERS = ["fy_common.hpp", "fy_prep.hpp", "fy_cooc.hpp", "fy_rm2.hpp", "fy_rm2_kernels.hpp", "fy_rm2_coop.hpp"]  # fy_itemcf.hip uses fy_prep.hpp / fy_rm2.hpp
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics", "-Wall",
-               "-Wno-unused-result"]
+               "-Wno-unused-result", "-ldl"]
 
 # every symbol include/filmyou.h declares (tests check the library exports exactly these)
 SYMBOLS = [
     "fy_abi_version", "fy_last_error", "fy_context_create", "fy_context_destroy", "fy_context_synchronize", "fy_context_inject_alloc_failure",
     "fy_context_stream", "fy_ratings_create", "fy_ratings_destroy", "fy_ratings_nnz", "fy_rm2_prepare",
-    "fy_rm2_partial_stats", "fy_rm2_set_global_stats", "fy_rm2_set_collectives", "fy_rm2_score", "fy_rm2_job_destroy", "fy_rm2_run",
+    "fy_rm2_partial_stats", "fy_rm2_set_global_stats", "fy_rm2_set_collectives", "fy_rccl_unique_id", "fy_rccl_create", "fy_rccl_collectives", "fy_rccl_counters", "fy_rccl_destroy", "fy_rm2_score", "fy_rm2_job_destroy", "fy_rm2_run",
     "fy_itemsim_build", "fy_itemsim_run", "fy_itemcf_recommend", "fy_cluster_assign", "fy_nmf_factorize", "fy_result_size", "fy_result_key0", "fy_result_key1", "fy_result_value",
     "fy_result_aux", "fy_result_n_users", "fy_result_user_id", "fy_result_user_sum", "fy_result_n_items",
     "fy_result_item_id", "fy_result_item_coll", "fy_result_total_sum", "fy_result_free", "fy_result_stats",
@@ -154,6 +154,12 @@ def load():
     L.fy_nmf_factorize.argtypes = [vp, C.POINTER(NMFParams), vp, vp, vp, C.POINTER(Stats)]
     L.fy_cluster_assign.argtypes = [vp, i32, i32, vp, C.c_int, i32, i32, i32, vp, vp, vp]
     L.fy_rm2_set_collectives.argtypes = [vp, C.POINTER(Collectives)]
+    L.fy_rccl_unique_id.argtypes = [vp]
+    L.fy_rccl_create.argtypes = [vp, C.c_int, C.c_int, vp, pvp]
+    L.fy_rccl_collectives.argtypes = [vp, C.POINTER(Collectives)]
+    L.fy_rccl_counters.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
+    L.fy_rccl_destroy.argtypes = [vp]
+    L.fy_rccl_destroy.restype = None
     L.fy_rm2_score.argtypes = [vp, pvp]
     L.fy_rm2_job_destroy.argtypes = [vp]
     L.fy_rm2_job_destroy.restype = None

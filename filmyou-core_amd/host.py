@@ -343,6 +343,11 @@ class PreparedRM2:
         stream)` / `comm.reduce_scatter_f32(send, recv, count, stream)` get raw device pointers and the hipStream_t the
         operation has to be ordered on; an exception inside them fails the job (FY_ERR_COLLECTIVE)."""
         self._comm_error = None
+        if hasattr(comm, "native_struct"):       # compiled transport (parallel.RcclCollectives): C callbacks, no Python in the path
+            self._coll = comm.native_struct
+            self._keep_comm = comm
+            _check(self._lib.fy_rm2_set_collectives(self._h, C.byref(self._coll)))
+            return
 
         def guard(fn):
             def call(_user, send, recv, n, stream):

@@ -149,6 +149,55 @@ class TorchCollectives:
         self._after_host()
 
 
+class RcclCollectives:
+    """fy_collectives played by the library's own compiled RCCL transport (fy_rccl_*, csrc/fy_rccl.hip): ncclAllGather /
+    ncclReduceScatter on the job's stream, no Python and no host synchronisation in the path.  torch.distributed is used
+    once, to hand rank 0's 128-byte ncclUniqueId to the other ranks (a C++ / JNI host uses its own channel for that)."""
+
+    def __init__(self, ctx, rank, world, group=None):
+        import ctypes as C
+        from . import _native
+        self._lib = _native.load()
+        self._ctx = ctx
+        self.rank, self.world = rank, world
+        idbuf = C.create_string_buffer(128)
+        if rank == 0:
+            rc = self._lib.fy_rccl_unique_id(idbuf)
+            if rc:
+                raise RuntimeError("fy_rccl_unique_id: %s" % self._lib.fy_last_error().decode())
+        if world > 1:
+            box = [idbuf.raw if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0, group=group)
+            idbuf = C.create_string_buffer(box[0], 128)
+        h = C.c_void_p()
+        rc = self._lib.fy_rccl_create(ctx._h, rank, world, idbuf, C.byref(h))
+        if rc:
+            raise RuntimeError("fy_rccl_create: %s" % self._lib.fy_last_error().decode())
+        self._h = h
+        self.native_struct = _native.Collectives()
+        rc = self._lib.fy_rccl_collectives(self._h, C.byref(self.native_struct))
+        if rc:
+            raise RuntimeError("fy_rccl_collectives: %s" % self._lib.fy_last_error().decode())
+
+    @property
+    def calls(self):
+        import ctypes as C
+        a, r, b = C.c_int64(), C.c_int64(), C.c_int64()
+        self._lib.fy_rccl_counters(self._h, C.byref(a), C.byref(r), C.byref(b))
+        return {"all_gather": a.value, "reduce_scatter_f32": r.value, "bytes": b.value}
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.fy_rccl_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class ThreadGroup:
     """In-process stand-in for a process group: `world` threads of ONE process, each with its own fy context on the
     same GPU, meet at a barrier.  Test harness for the cooperative multi-rank path on a one-GPU box.

@@ -121,6 +121,19 @@ typedef struct {
     int (*reduce_scatter_f32)(void* user, const float* send, float* recv, int64_t count, void* stream);
 } fy_collectives;
 int fy_rm2_set_collectives(fy_rm2_job*, const fy_collectives*);
+
+/* The compiled transport for fy_collectives: RCCL (ncclAllGather / ncclReduceScatter over xGMI) queued on the context's own
+ * stream, no host synchronisation.  librccl.so is opened at run time, a single-GPU host does not need it.  One process per
+ * GPU: rank 0 makes the 128-byte id (fy_rccl_unique_id) and hands it to the other ranks by whatever channel the host has
+ * (the Hadoop Configuration / a file / torch.distributed's store); fy_rccl_create is collective over all ranks
+ * (ncclCommInitRank).  Replaces the shuffle + DistributedCache + counter exchange of M/rm/RM2Job.java:130-149, 184-198,
+ * 260-263 for hosts that are not Python (the C++ mirror, the JNI shim). */
+typedef struct fy_rccl fy_rccl;
+int fy_rccl_unique_id(char* out128);
+int fy_rccl_create(fy_context*, int rank, int world, const char* id128, fy_rccl** out);
+int fy_rccl_collectives(fy_rccl*, fy_collectives* out);   /* fills the callbacks; `out->user` is the fy_rccl, which must outlive the job */
+int fy_rccl_counters(const fy_rccl*, int64_t* all_gathers, int64_t* reduce_scatters, int64_t* payload_bytes);
+void fy_rccl_destroy(fy_rccl*);
 /* Stage 2 (job RM2-3): per-cluster co-rating matrix, p(i|u) scoring of this rank's users, top-N. */
 int fy_rm2_score(fy_rm2_job*, fy_result** out);
 void fy_rm2_job_destroy(fy_rm2_job*);

@@ -47,6 +47,8 @@ def _load():
     vp, i64 = C.c_void_p, C.c_int64
     L.rm2o_run.argtypes = [C.POINTER(_RM2Params), i64, vp, vp, vp, i64, vp, vp, vp, C.POINTER(vp)]
     L.rm2o_run.restype = C.c_int
+    L.rm2o_run_gram.argtypes = L.rm2o_run.argtypes
+    L.rm2o_run_gram.restype = C.c_int
     L.rm2o_last_error.restype = C.c_char_p
     L.rm2o_free.argtypes = [vp]
     for name, rt in (("n_recs", i64), ("rec_user", vp), ("rec_item", vp), ("rec_cluster", vp), ("rec_score", vp),
@@ -91,8 +93,13 @@ def _i32(a):
     return np.ascontiguousarray(a, dtype=np.int32)
 
 
+def rm2_gram(*args, **kw):
+    """The Gram-restructured CPU scorer (bench.py's cpu_baseline_gram; same interface as rm2)."""
+    return rm2(*args, _gram=True, **kw)
+
+
 def rm2(user, item, score, *, lam, number_of_items, number_of_recommendations, number_of_clusters,
-        map_user=None, map_cluster=None, cluster_count=None, filter_users=0, n_threads=1):
+        map_user=None, map_cluster=None, cluster_count=None, filter_users=0, n_threads=1, _gram=False):
     """Run the RM2 oracle.  Returns a dict of numpy arrays (see oracle.h for the ordering)."""
     L = _load()
     user, item = _i32(user), _i32(item)
@@ -106,7 +113,7 @@ def rm2(user, item, score, *, lam, number_of_items, number_of_recommendations, n
     P = _RM2Params(float(lam), int(number_of_items), int(number_of_recommendations), int(filter_users),
                    int(number_of_clusters), int(n_threads))
     out = C.c_void_p()
-    rc = L.rm2o_run(C.byref(P), len(user), user.ctypes.data, item.ctypes.data, score.ctypes.data, len(mu),
+    rc = (L.rm2o_run_gram if _gram else L.rm2o_run)(C.byref(P), len(user), user.ctypes.data, item.ctypes.data, score.ctypes.data, len(mu),
                     mu.ctypes.data, mc.ctypes.data, cc.ctypes.data if cc is not None else None, C.byref(out))
     if rc != 0:
         raise RuntimeError("rm2 oracle failed (%d): %s" % (rc, L.rm2o_last_error().decode()))

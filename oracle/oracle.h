@@ -25,6 +25,10 @@ typedef struct rm2o_result rm2o_result;
 int rm2o_run(const rm2o_params* P, int64_t nnz, const int32_t* user, const int32_t* item, const float* score,
              int64_t n_map, const int32_t* map_user, const int32_t* map_cluster, const int32_t* cluster_count,
              rm2o_result** out);
+/* the same job, scoring restructured around a per-cluster Gram matrix ("best CPU" baseline; not the parity oracle) */
+int rm2o_run_gram(const rm2o_params* P, int64_t nnz, const int32_t* user, const int32_t* item, const float* score,
+                  int64_t n_map, const int32_t* map_user, const int32_t* map_cluster, const int32_t* cluster_count,
+                  rm2o_result** out);
 const char* rm2o_last_error(void);
 void rm2o_free(rm2o_result*);
 /* recommendations: grouped by cluster asc, user id asc, then best first (ties: ascending item id) */

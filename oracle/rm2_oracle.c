@@ -151,9 +151,10 @@ static double now_s(void) {
 #endif
 }
 
-int rm2o_run(const rm2o_params* P, int64_t nnz_in, const int32_t* user, const int32_t* item, const float* score,
-             int64_t n_map, const int32_t* map_user, const int32_t* map_cluster, const int32_t* cluster_count,
-             rm2o_result** out) {
+/* `gram` != 0 selects the restructured scorer of rm2o_run_gram (below); everything in front of the per-user loop is shared */
+static int run_impl(const rm2o_params* P, int64_t nnz_in, const int32_t* user, const int32_t* item, const float* score,
+                    int64_t n_map, const int32_t* map_user, const int32_t* map_cluster, const int32_t* cluster_count,
+                    rm2o_result** out, int gram) {
     int rc = 0;
     rm2o_result* R = (rm2o_result*)calloc(1, sizeof *R);
     int32_t *uid = NULL, *iid = NULL, *du = NULL, *di = NULL, *ucl = NULL, *csize = NULL, *cstart = NULL, *cusers = NULL;
@@ -270,9 +271,46 @@ int rm2o_run(const rm2o_params* P, int64_t nnz_in, const int32_t* user, const in
             if (loc[i] >= 0) items[loc[i]] = (int32_t)i;
 
         /* cache[v][i] = probItemGivenUser(i, v) = (1-lambda)*(rating/sum) + lambda*p(i|C), rating = 0.0 if absent */
-        double* cache = (double*)malloc(sizeof(double) * (size_t)Uc * (size_t)Ic);
-        if (!cache) { free(loc); free(items); FAIL(-5, "cluster %d: cannot allocate the %d x %d cache", c, Uc, Ic); }
-        for (int a = 0; a < Uc; a++) {
+        double* cache = NULL;
+        double *G = NULL, *bvec = NULL;   /* gram scorer only */
+        if (gram) {
+            /* "Best CPU" restructuring (NOT the reference's loop nest; the same identity the GPU path uses, in fp64):
+             *   sum_{v != u} c_vi c_vj = G[j][i] + (l p_i) e_uj   for i not rated by u,
+             *   G[j][i] = (1-l)^2 (X^T X)_ji + l (1-l) p_j b_i,  X_vi = r_vi / s_v,  b_i = sum_v X_vi,
+             *   e_uj    = (1-l) (b_j - x_uj) + l (U_c - 1) p_j.
+             * One dense Ic x Ic matrix per cluster replaces the U_c - 1 multiply-adds per log term. */
+            if ((double)Ic * (double)Ic * 8.0 > 12e9) { free(loc); free(items); FAIL(-6, "cluster %d: the %d x %d Gram does not fit the CPU baseline's budget", c, Ic, Ic); }
+            G = (double*)calloc((size_t)Ic * (size_t)Ic, sizeof(double));
+            bvec = (double*)calloc((size_t)Ic + 1, sizeof(double));
+            if (!G || !bvec) { free(G); free(bvec); free(loc); free(items); FAIL(-5, "cluster %d: cannot allocate the %d x %d Gram", c, Ic, Ic); }
+            for (int a = 0; a < Uc; a++) {
+                const double sum = usum[cu[a]];
+                for (int64_t e = rowptr[cu[a]]; e < rowptr[cu[a] + 1]; e++) bvec[loc[col[e]]] += (double)val[e] / sum;
+            }
+            /* X^T X: every user adds the outer product of its row; rows of G are independent -> parallel over j */
+            const double w2 = (1 - lambda) * (1 - lambda), w1 = lambda * (1 - lambda);
+#pragma omp parallel for schedule(dynamic, 8) num_threads(nthreads)
+            for (int j = 0; j < Ic; j++) {
+                double* row = G + (size_t)j * Ic;
+                const double pj = icoll[items[j]];
+                for (int i = 0; i < Ic; i++) row[i] = w1 * pj * bvec[i];
+            }
+            /* scatter by user (sequential over users, parallel over the user's rated rows: distinct rows of G) */
+            for (int a = 0; a < Uc; a++) {
+                const double sum = usum[cu[a]];
+                const int64_t r0 = rowptr[cu[a]], r1 = rowptr[cu[a] + 1];
+#pragma omp parallel for schedule(static) num_threads(nthreads) if (r1 - r0 > 256)
+                for (int64_t e = r0; e < r1; e++) {
+                    double* row = G + (size_t)loc[col[e]] * Ic;
+                    const double xj = w2 * (double)val[e] / sum;
+                    for (int64_t f = r0; f < r1; f++) row[loc[col[f]]] += xj * ((double)val[f] / sum);
+                }
+            }
+        } else {
+            cache = (double*)malloc(sizeof(double) * (size_t)Uc * (size_t)Ic);
+            if (!cache) { free(loc); free(items); FAIL(-5, "cluster %d: cannot allocate the %d x %d cache", c, Uc, Ic); }
+        }
+        for (int a = 0; a < Uc && !gram; a++) {
             double* row = cache + (size_t)a * Ic;
             const double sum = usum[cu[a]];
             for (int i = 0; i < Ic; i++) row[i] = (1 - lambda) * (0.0 / sum) + lambda * icoll[items[i]];
@@ -300,7 +338,24 @@ int rm2o_run(const rm2o_params* P, int64_t nnz_in, const int32_t* user, const in
             cand* list = (cand*)malloc(sizeof(cand) * (size_t)n_unrated);
             int m = 0;
             const double pvpi = (n - 1) * log((double)P->number_of_items) - n * log((double)Uc);
-            for (int i = 0; i < Ic; i++) {
+            if (gram) {
+                /* rows of G of the user's rated items are streamed once each; acc[i] collects the log terms */
+                double* acc = (double*)calloc((size_t)Ic, sizeof(double));
+                const double sum_u = usum[u];
+                for (int k = 0; k < n; k++) {
+                    const int j = rated[k];
+                    const double x = (double)val[rowptr[u] + k] / sum_u;
+                    const double e = (1 - lambda) * (bvec[j] - x) + lambda * (double)(Uc - 1) * icoll[items[j]];
+                    const double* row = G + (size_t)j * Ic;
+                    for (int i = 0; i < Ic; i++) acc[i] += log(row[i] + lambda * icoll[items[i]] * e);
+                }
+                for (int i = 0; i < Ic; i++) {
+                    if (is_rated[i]) continue;
+                    list[m].item_local = i; list[m].item_raw = iid[items[i]]; list[m].score = acc[i] + pvpi; m++;
+                }
+                free(acc);
+            }
+            for (int i = 0; i < Ic && !gram; i++) {
                 if (is_rated[i]) continue;
                 double log_result = 0.0;
                 for (int k = 0; k < n; k++) {
@@ -324,7 +379,7 @@ int rm2o_run(const rm2o_params* P, int64_t nnz_in, const int32_t* user, const in
         }
         t_score += now_s() - t0;
         R->log_terms += c_terms;
-        R->fma_terms += c_terms * (int64_t)(Uc - 1);
+        R->fma_terms += gram ? 0 : c_terms * (int64_t)(Uc - 1);
 
         for (int a = 0; a < Uc; a++) {
             if (!ulist[a]) continue;
@@ -344,7 +399,7 @@ int rm2o_run(const rm2o_params* P, int64_t nnz_in, const int32_t* user, const in
             }
             free(ulist[a]);
         }
-        free(ulist); free(ucount); free(cache); free(items); free(loc);
+        free(ulist); free(ucount); free(cache); free(G); free(bvec); free(items); free(loc);
     }
 
     R->n_users = nU; R->user_id = uid; R->user_sum = usum; uid = NULL; usum = NULL;
@@ -357,4 +412,19 @@ done:
     if (rc) { rm2o_free(R); R = NULL; }
     *out = R;
     return rc;
+}
+
+int rm2o_run(const rm2o_params* P, int64_t nnz_in, const int32_t* user, const int32_t* item, const float* score,
+             int64_t n_map, const int32_t* map_user, const int32_t* map_cluster, const int32_t* cluster_count,
+             rm2o_result** out) {
+    return run_impl(P, nnz_in, user, item, score, n_map, map_user, map_cluster, cluster_count, out, 0);
+}
+
+/* The same job with the scoring loop restructured around a per-cluster Gram matrix (see run_impl): bench.py's
+ * "cpu_baseline_gram" line, so that the GPU / CPU ratio is not inflated by the reference's O(U_c) inner loop.
+ * Not the reference's algorithm: checked against rm2o_run (tests/test_oracle_golden.py), never used as the parity oracle. */
+int rm2o_run_gram(const rm2o_params* P, int64_t nnz_in, const int32_t* user, const int32_t* item, const float* score,
+                  int64_t n_map, const int32_t* map_user, const int32_t* map_cluster, const int32_t* cluster_count,
+                  rm2o_result** out) {
+    return run_impl(P, nnz_in, user, item, score, n_map, map_user, map_cluster, cluster_count, out, 1);
 }

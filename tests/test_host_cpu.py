@@ -47,3 +47,22 @@ def test_argument_checks_fire_before_the_device_is_touched():
         P.NMFDriver(fconf, _NoDevice()).run((u, u, np.ones(1, np.float32)), np.ones((4, 2)), np.ones((2, 2)))
     with pytest.raises(ValueError, match="users x clusters"):
         P.ClusterAssignmentJob(_NoDevice()).run(np.ones(5))
+
+
+def test_bench_refuses_a_mislabelled_gpu_count():
+    """bench.py --gpus N must run N ranks or fail: with WORLD_SIZE unset it starts the ranks itself (each of them then fails
+    loudly here, there is no GPU); with a WORLD_SIZE that disagrees with --gpus it refuses to print a line."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--shape", "ml100k"],
+                         env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "--gpus 2 but WORLD_SIZE=1" in bad.stderr and "{" not in bad.stdout
+    import torch
+    if not torch.cuda.is_available():
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--shape", "ml100k"],
+                             env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode != 0 and "{" not in out.stdout
+        assert out.stderr.count("needs an MI355X") >= 1          # the child ranks were started and refused to fall back

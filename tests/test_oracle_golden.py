@@ -185,3 +185,34 @@ def test_factorisation_oracle_reproduces_the_reference_vectors(name, ppc):
         H, _ = oracle.nmf((u + 1).astype(np.int32), (i + 1).astype(np.int32), Ap[i, u].astype(np.float32), d["h0p"], d["w0p"],
                           iterations=1, ppc=True)
         assert np.abs(H - np.array(d["h1p"])).max() < 1e-7
+
+
+def test_gram_restructured_cpu_scorer_equals_the_oracle(rm_golden):
+    """bench.py's "best CPU" line (oracle/rm2_oracle.c, rm2o_run_gram) is the same job with the scoring loop restructured
+    around a per-cluster Gram matrix -- the identity the GPU path uses, here in fp64.  It must give the oracle's rows:
+    on the reference's fixture (507 rows) and on an ML-100K-shaped data set with 3 clusters."""
+    a = run_golden(rm_golden)
+    user, item, score = rm_golden["coo"]
+    p = rm_golden["params"]
+    b = oracle.rm2_gram(user, item, score, lam=p["lambda"], number_of_items=rm_golden["numberOfItems"],
+                        number_of_recommendations=p["numberOfRecommendations"], number_of_clusters=rm_golden["numberOfClusters"],
+                        map_user=rm_golden["map_user"], map_cluster=rm_golden["map_cluster"], cluster_count=rm_golden["cluster_count"])
+    assert len(b["rec_user"]) == 507
+    ka = {(int(u), int(i)): float(s) for u, i, s in zip(a["rec_user"], a["rec_item"], a["rec_score"])}
+    kb = {(int(u), int(i)): float(s) for u, i, s in zip(b["rec_user"], b["rec_item"], b["rec_score"])}
+    assert ka.keys() == kb.keys()
+    assert max(abs(ka[k] - kb[k]) / abs(ka[k]) for k in ka) <= 2e-7
+
+    import importlib
+    S = importlib.import_module("filmyou-core_amd.synth")
+    u, i, s, facts = S.generate("ml100k")
+    u, i, s = u.numpy(), i.numpy(), s.numpy()
+    uu = np.unique(u)
+    mc = S.hash_clustering(uu, 3)
+    kw = dict(lam=0.1, number_of_items=facts["n_items"], number_of_recommendations=20, number_of_clusters=3, map_user=uu, map_cluster=mc, n_threads=8)
+    a, b = oracle.rm2(u, i, s, **kw), oracle.rm2_gram(u, i, s, **kw)
+    assert a["log_terms"] == b["log_terms"] and len(a["rec_user"]) == len(b["rec_user"])
+    np.testing.assert_array_equal(a["rec_user"], b["rec_user"])
+    same = a["rec_item"] == b["rec_item"]
+    assert same.mean() > 0.999                                        # a near-tie may swap two neighbours
+    np.testing.assert_allclose(a["rec_score"][same], b["rec_score"][same], rtol=2e-6)

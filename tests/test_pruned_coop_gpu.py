@@ -179,11 +179,13 @@ def test_threshold_that_does_not_bite_falls_back_to_the_full_pass(forced, monkey
     ctx.close()
 
 
-def test_margin_with_heavy_users_and_positive_pvpi(forced):
+def test_margin_with_heavy_users_and_positive_pvpi(forced, monkeypatch):
     """The rounding of the bound scales with the sum of |log| terms, not with the net |UB|: with numberOfItems >> U_c the
     positive pvpi cancels most of the log sum (every multi-cluster job).  Heavy users, 8 clusters, numberOfItems forced
-    large, pruning on vs off: identical lists."""
+    large, pruning on vs off: identical lists.  (With 15 blocks per row many survive: the fallback to the full pass is
+    switched off so that the survivor pass itself is what is compared.)"""
     import os
+    monkeypatch.setenv("FY_MAX_SURV_FRAC", "1e9")
     P = pkg()
     S = synth()
     u, i, s, facts = S.generate("ml1m")
@@ -226,7 +228,7 @@ def test_failed_multi_cluster_job_leaves_the_context_usable(forced):
         ctx.inject_alloc_failure(nth)
         try:
             rec = P.RM2Job(conf, ctx).run(ratings, clustering=clustering)
-        except P.FilmYouError as e:
+        except RuntimeError as e:                      # the host mirror's "RM2 failed!: ..." (RM2Job.java:145-147)
             assert "injected fault" in str(e)
             failures += 1
             ctx.inject_alloc_failure(0)
