@@ -57,6 +57,18 @@ def launch_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
+def host_cores():
+    """Threads for the CPU legs: the cores this process may run on, at most 16 -- a one-GPU box of the pool is a 1/8 share
+    (16 cores) of a 256-thread host, and the OpenMP loops of the oracles get slower, not faster, when they are spread over
+    all 256 hardware threads (measured: 540 recs/s with 256 threads against 1013 with 16 on the same sample).  The JSON line
+    states both numbers (cores, host_nproc)."""
+    try:
+        allowed = len(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = os.cpu_count() or 1
+    return max(1, min(16, allowed))
+
+
 def source_rev():
     """Hash of the kernel sources the roofline numbers belong to (profiles/rN/traffic.json is stamped with it)."""
     h = hashlib.sha256()
@@ -74,7 +86,7 @@ def cpu_legs(S, shape, facts, lam, top_n, n_users_sample, np):
       cpu_baseline_gram   a CPU scorer restructured like the GPU path (cluster Gram + per-user correction): the "best CPU" line
     """
     import oracle
-    cores = max(1, os.cpu_count() or 1)
+    cores = host_cores()
     rng = np.random.Generator(np.random.PCG64(7))
     out = {}
 
@@ -89,7 +101,7 @@ def cpu_legs(S, shape, facts, lam, top_n, n_users_sample, np):
         ref = fn(u, i, s, threads)
         dt = time.time() - t0
         recs = len(ref["rec_user"])
-        return {"value": recs / dt, "unit": "recs/s", "cores": threads, "kind": "port", "host_nproc": cores,
+        return {"value": recs / dt, "unit": "recs/s", "cores": threads, "kind": "port", "host_nproc": os.cpu_count(),
                 "sample": "one %d-user cluster sampled from the same %s-shaped data (%d ratings, %d candidate items, %.3g log-terms), "
                           "%s, %d thread(s), %.1f s" % (len(users), shape, len(u), len(ref["item_id"]), ref["log_terms"], kind, threads, dt),
                 "seconds": dt, "log_terms_per_s": ref["log_terms"] / dt}

@@ -51,42 +51,34 @@ struct CoocArgs {
     const int2* __restrict__ item_seg;
 };
 
-// Accumulates chunk `ch` of row `row` into the workgroup's dynamic LDS (fy_cooc_acc[0..CH), zeroed by the caller; all
-// threads call this).
-//
-// Unit of work = one SEGMENT (<= 64 entries of one rater's row slice, one entry per lane).  The segments of an item row
-// are contiguous in the segment table, so a wave simply takes 64 of them at a time (wave w: segments 64 w, 64 (w + nwaves),
-// ...), broadcasts their descriptors with v_readlane, eight at a time: eight coalesced loads, then eight LDS atomics.
-// Heavy users -- raters of very many rows with slices of thousands of entries, half of all rater visits at ML-25M shape --
-// are spread over all waves of the workgroup by construction; there is no per-rater loop left.
-// History (rocprof, ML-25M shape, ms per M build): one scalar chain per rater 110; per-lane binary-search expansion 362;
-// 4 raters per wave-step 84; + pipelined long-slice loop 48 (of which 28 were waves idling behind the wave that held a
-// long slice); LDS queue for the remainders 104; segment s of rater r -> wave (r + s) mod 16 with every wave reading all
-// metadata 90; persistent workgroups 47; this version (segments precomputed per CSC entry): DESIGN.md section 7.
 #ifndef FY_COOC_NB
-#define FY_COOC_NB 8    // segment loads per group; two groups are in flight per wave (see cooc_accumulate_row)
+#define FY_COOC_NB 8    // segment loads per group; two groups are in flight per wave (see cooc_accumulate_segments)
 #endif
-extern __shared__ double fy_cooc_acc[];
+extern __shared__ __attribute__((aligned(16))) double fy_cooc_acc[];
 
-template <bool PK = false>
-__device__ __forceinline__ void cooc_accumulate_row(const CoocArgs& A, int row, int ch, int lrow = 0) {
+// first batch of segment descriptors of this wave for the segment range [s_begin, s_end): issued early by the caller (the
+// RM2 row kernel loads them for the NEXT item before the epilogue of the current one)
+struct SegBatch {
+    int2 d;
+    float w;
+};
+__device__ __forceinline__ SegBatch cooc_first_batch(const CoocArgs& A, int s_begin, int s_end) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    SegBatch B{make_int2(0, 0), 0.0f};
+    const int sb = s_begin + wave * 64;
+    if (sb + lane < s_end) { B.d = A.seg[sb + lane]; B.w = A.seg_w[sb + lane]; }
+    return B;
+}
+
+// ACC = double: ds_add_f64 (item-item similarity: sums of up to 10^5 products compared at 2e-6); ACC = float: ds_add_f32
+// (RM2: the sums are rounded to 24 bits afterwards and enter the score through a logarithm -- DESIGN.md section 2 -- and
+// half the LDS per column lets two workgroups share a CU, one accumulating while the other is in its epilogue).
+template <bool PK, class ACC>
+__device__ __forceinline__ void cooc_accumulate_segments(const CoocArgs& A, ACC* __restrict__ acc, int s_begin, int s_end, int c0, SegBatch first) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = blockDim.x >> 6;
-    int s_begin, s_end;
-    if (A.item_seg) {
-        const int2 se = A.item_seg[(int64_t)lrow * A.nch + ch];
-        s_begin = se.x;
-        s_end = se.y;
-    } else {
-        const int pair = A.rank_pair[A.pbase + row];
-        int e0 = A.pair_start[pair], e1 = A.pair_start[pair + 1];
-        if (A.local_start) { e0 = A.local_start[lrow]; e1 = A.local_start[lrow + 1]; }
-        const int32_t* __restrict__ sp = A.seg_ptr + (int64_t)ch * (A.nq + 1) - A.q0;
-        s_begin = sp[e0];
-        s_end = sp[e1];
-    }
-    const int c0 = ch * A.CH;
     const int32_t* __restrict__ csr_idx = A.csr_idx;
     const float* __restrict__ csr_w = A.csr_w;
     const uint32_t* __restrict__ csr_pk = A.csr_pk;
@@ -132,13 +124,12 @@ __device__ __forceinline__ void cooc_accumulate_row(const CoocArgs& A, int row, 
         }
 #pragma unroll
         for (int q = 0; q < NB; q++)
-            if (lane < G.L[q]) atomicAdd(&fy_cooc_acc[G.idx[q]], (double)G.W[q] * (double)G.x[q]);   // ds_add_f64
+            if (lane < G.L[q]) atomicAdd(&acc[G.idx[q]], (ACC)G.W[q] * (ACC)G.x[q]);   // ds_add_f64 / ds_add_f32
     };
     int sb = s_begin + wave * 64;
     if (sb >= s_end) return;
-    int2 d = make_int2(0, 0);
-    float w = 0.0f;
-    if (sb + lane < s_end) { d = A.seg[sb + lane]; w = A.seg_w[sb + lane]; }
+    int2 d = first.d;
+    float w = first.w;
     while (sb < s_end) {   // wave-uniform
         const int nloc = min(64, s_end - sb);
         const int sb_next = sb + nwaves * 64;
@@ -158,6 +149,36 @@ __device__ __forceinline__ void cooc_accumulate_row(const CoocArgs& A, int row, 
         w = wn;
         sb = sb_next;
     }
+}
+
+// Accumulates chunk `ch` of row `row` into the workgroup's dynamic LDS (fy_cooc_acc[0..CH) as fp64, zeroed by the caller;
+// all threads call this).
+//
+// Unit of work = one SEGMENT (<= 64 entries of one rater's row slice, one entry per lane).  The segments of an item row
+// are contiguous in the segment table, so a wave simply takes 64 of them at a time (wave w: segments 64 w, 64 (w + nwaves),
+// ...), broadcasts their descriptors with v_readlane, eight at a time: eight coalesced loads, then eight LDS atomics.
+// Heavy users -- raters of very many rows with slices of thousands of entries, half of all rater visits at ML-25M shape --
+// are spread over all waves of the workgroup by construction; there is no per-rater loop left.
+// History (rocprof, ML-25M shape, ms per M build): one scalar chain per rater 110; per-lane binary-search expansion 362;
+// 4 raters per wave-step 84; + pipelined long-slice loop 48 (of which 28 were waves idling behind the wave that held a
+// long slice); LDS queue for the remainders 104; segment s of rater r -> wave (r + s) mod 16 with every wave reading all
+// metadata 90; persistent workgroups 47; segments precomputed per CSC entry: DESIGN.md section 7.
+template <bool PK = false>
+__device__ __forceinline__ void cooc_accumulate_row(const CoocArgs& A, int row, int ch, int lrow = 0) {
+    int s_begin, s_end;
+    if (A.item_seg) {
+        const int2 se = A.item_seg[(int64_t)lrow * A.nch + ch];
+        s_begin = se.x;
+        s_end = se.y;
+    } else {
+        const int pair = A.rank_pair[A.pbase + row];
+        int e0 = A.pair_start[pair], e1 = A.pair_start[pair + 1];
+        if (A.local_start) { e0 = A.local_start[lrow]; e1 = A.local_start[lrow + 1]; }
+        const int32_t* __restrict__ sp = A.seg_ptr + (int64_t)ch * (A.nq + 1) - A.q0;
+        s_begin = sp[e0];
+        s_end = sp[e1];
+    }
+    cooc_accumulate_segments<PK, double>(A, fy_cooc_acc, s_begin, s_end, ch * A.CH, cooc_first_batch(A, s_begin, s_end));
 }
 
 // segment range of every (row, chunk) item of a launch (CoocArgs::item_seg)
@@ -186,6 +207,10 @@ void build_segments(Context* ctx, const int32_t* csc_slot, const float* csc_w, c
 // chunk_off table for one cluster: one thread per (slot, boundary)
 void build_chunk_offsets(Context* ctx, const int32_t* rowptr, const int32_t* csr_idx, int32_t slot_base, int32_t n_slots,
                          int32_t CH, int32_t nch, int32_t* chunk_off, hipStream_t st = nullptr);
+
+// columns of LDS accumulators a workgroup of the RM2 row kernel allocates for chunks of CH columns: its epilogue reads whole
+// 256-column blocks up to the padded row length, which overshoots a chunk whose width is not a multiple of 256 by < 256
+__host__ __device__ inline int cooc_lds_columns(int CH) { return (CH % 256 == 0) ? CH : ((CH + 255) / 256) * 256 + 256; }
 
 // picks the chunk width for a cluster with Ic items: whole row when it fits the LDS budget.  Chunks are multiples of 256
 // columns whenever there are several (a wave of the epilogue then owns exactly one 256-column block, fy_rm2.hip).

@@ -150,13 +150,15 @@ __global__ void k_item_coll(int32_t nI, const double* __restrict__ stats, double
     if (blockIdx.x == 0 && threadIdx.x == 0) *total_out = total;
 }
 
-// p(i|C) of every (cluster, item) in rank order, a = l * p
+// p(i|C) of every (cluster, item) in rank order, a = l * p, b rounded once to fp32
 __global__ void k_pair_p(int32_t nP, const int32_t* __restrict__ rank_pair, const int32_t* __restrict__ pair_di,
-                         const double* __restrict__ icoll, double lambda, double* __restrict__ p_rank, float* __restrict__ a_rank) {
+                         const double* __restrict__ icoll, double lambda, const double* __restrict__ b_rank,
+                         double* __restrict__ p_rank, float* __restrict__ a_rank, float* __restrict__ b_rank32) {
     for (int32_t pos = blockIdx.x * blockDim.x + threadIdx.x; pos < nP; pos += gridDim.x * blockDim.x) {
         const double p = icoll[pair_di[rank_pair[pos]]];
         p_rank[pos] = p;
         a_rank[pos] = (float)(lambda * p);
+        b_rank32[pos] = (float)b_rank[pos];
     }
 }
 
@@ -184,7 +186,7 @@ __global__ void k_csr_values(int32_t nU, const int32_t* __restrict__ rowptr, con
                              const int32_t* __restrict__ ucluster, const double* __restrict__ usum,
                              const int32_t* __restrict__ csize, const int32_t* __restrict__ pcstart,
                              const double* __restrict__ p_rank, const double* __restrict__ b_rank, double lambda,
-                             float* __restrict__ csr_x, float* __restrict__ csr_e) {
+                             float* __restrict__ csr_x, float* __restrict__ csr_e, float* __restrict__ csr_q) {
     const int lane = threadIdx.x & 63;
     const int wpb = blockDim.x >> 6;
     for (int32_t s = blockIdx.x * wpb + (threadIdx.x >> 6); s < nU; s += gridDim.x * wpb) {
@@ -200,6 +202,7 @@ __global__ void k_csr_values(int32_t nU, const int32_t* __restrict__ rowptr, con
             if (!(e > 0.0)) e = 0.0;
             csr_x[f] = (float)x;
             csr_e[f] = (float)e;
+            csr_q[f] = (float)(lambda * (1.0 - lambda) * p_rank[pb + j]);     // q_j: the rank-one part of a term is q_j b_i
         }
     }
 }
@@ -352,14 +355,13 @@ void build_segments(Context* ctx, const int32_t* csc_slot, const float* csc_w, c
     }
 }
 
-// ================================================================ M build: co-rating row kernel + RM2 epilogue
+// ================================================================ G build: co-rating row kernel + RM2 epilogue
+// G[j][i] = (1-l)^2 (X^T X)_ji, the pure co-rating Gram (the rank-one part l (1-l) p_j b_i of the reference's inner sum is
+// applied by the scoring kernels): symmetric, exactly zero for never co-rated pairs.
 struct MEpilogue {
     float* __restrict__ M;
     int64_t ldm;
-    const double* __restrict__ p_rank;   // already offset by pbase
-    const double* __restrict__ b_rank;
-    double w2;    // (1-l)^2
-    double w1;    // l (1-l)
+    float w2;     // (1-l)^2
     int pack24;   // 3 bytes per element: 8 exponent + 16 mantissa bits of the (non-negative) fp32, rounded to nearest
     float* __restrict__ Bmax;   // optional [row][ldb] in the 24-bit packed format (3 bytes per entry): maximum of the (rounded) row
                                 // over every 256-column block
@@ -370,46 +372,66 @@ struct MEpilogue {
 // Persistent workgroups pull (row, chunk) items from a global counter (rows are in popularity order: heavy items first);
 // the epilogue re-zeroes the accumulators it reads, so an item costs one accumulate phase, one barrier, one epilogue and
 // one barrier -- no dispatch, no separate clearing pass.
-template <bool PK>
+//
+// Round 2: (1) accumulators in fp32 (ds_add_f32, ACC = float): half the LDS per column, so TWO workgroups share a CU and
+// one streams rater slices while the other sits in its barrier / epilogue (one 16-wave workgroup per CU spent half of
+// every item's 25 us waiting: three dependent round trips in front of the first slice load, then the epilogue); ACC =
+// double keeps the round-1 arithmetic (FY_COOC_F64=1).  (2) The item counter is read TWO items ahead by thread 0, which
+// also fetches the segment range of the next item while the current one is accumulated; after the barrier every wave issues
+// the load of its first 64 segment descriptors of the NEXT item, and only then runs the epilogue: of the three round
+// trips in front of an item's first slice load none is exposed any more.  (3) The epilogue no longer reads b and p.
+template <bool PK, class ACC>
 __global__ void k_cooc_rm2(CoocArgs A, MEpilogue E, int n_items, int* __restrict__ next_item) {
-    double* acc = fy_cooc_acc;
-    __shared__ int sh_item;
-    for (int t = threadIdx.x; t < A.CH; t += blockDim.x) acc[t] = 0.0;
+    ACC* __restrict__ acc = reinterpret_cast<ACC*>(fy_cooc_acc);
+    __shared__ int sh_item, sh_s0, sh_s1;
+    const int CHp = cooc_lds_columns(A.CH);   // allocated (and zeroed) columns: the epilogue reads whole 256-column blocks
+    for (int t = threadIdx.x; t < CHp; t += blockDim.x) acc[t] = (ACC)0;
     // items are handed out by a global counter: the chunks of a row differ a lot in weight (chunk 0 holds the popular
     // columns), a static stride would leave three quarters of the workgroups idle behind the chunk-0 owners
-    int next = 0;
-    if (threadIdx.x == 0) next = atomicAdd(next_item, 1);
-    for (;;) {
-        if (threadIdx.x == 0) sh_item = next;
-        __syncthreads();
-        const int item = sh_item;
-        if (item >= n_items) break;
-        // the counter's round trip for the NEXT item hides behind this item's work
-        if (threadIdx.x == 0) next = atomicAdd(next_item, 1);
+    int next = 0, next2 = 0;      // thread 0 only: the next item and the one after it
+    if (threadIdx.x == 0) {
+        const int first = atomicAdd(next_item, 1);
+        next = atomicAdd(next_item, 1);
+        const int2 se = first < n_items ? A.item_seg[first] : make_int2(0, 0);
+        sh_item = first;
+        sh_s0 = se.x;
+        sh_s1 = se.y;
+    }
+    __syncthreads();
+    int item = sh_item, s0 = sh_s0, s1 = sh_s1;
+    SegBatch batch = cooc_first_batch(A, s0, s1);
+    while (item < n_items) {     // block-uniform
+        int2 se_next = make_int2(0, 0);
+        if (threadIdx.x == 0) {
+            next2 = atomicAdd(next_item, 1);                         // arrives during this item's work
+            if (next < n_items) se_next = A.item_seg[next];          // address known since the previous item
+        }
         const int lrow = item / A.nch;
         const int row = A.row0 + lrow * (A.row_stride ? A.row_stride : 1);
         const int mrow = E.local_rows ? lrow : row;
-        const int ch = item % A.nch;
-        cooc_accumulate_row<PK>(A, row, ch, lrow);
-        __syncthreads();
+        const int ch = item - lrow * A.nch;
         const int c0 = ch * A.CH;
+        cooc_accumulate_segments<PK, ACC>(A, acc, s0, s1, c0, batch);
+        // (every thread read sh_* of THIS item before the barrier that ended the previous epilogue)
+        if (threadIdx.x == 0) { sh_item = next; sh_s0 = se_next.x; sh_s1 = se_next.y; }
+        __syncthreads();     // all atomics of this item are done; the next item is published
+        const int nitem = sh_item;
+        s0 = sh_s0;
+        s1 = sh_s1;
+        batch = cooc_first_batch(A, s0, s1);     // in flight during the epilogue
         // the last chunk also writes the padding columns [Ic, ldm) so the scoring kernel may load whole 256-wide chunks
         const int c1 = (ch == A.nch - 1) ? (int)E.ldm : min(c0 + A.CH, (int)E.ldm);
-        const double pj = E.p_rank[row];
         if (E.pack24) {
             // four columns -> three dwords (c0 and c1 are multiples of 64)
             uint32_t* __restrict__ out3 = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(E.M) + (int64_t)mrow * E.ldm * 3);
             for (int c4 = (c0 >> 2) + threadIdx.x; 4 * c4 < c1; c4 += blockDim.x) {
                 uint32_t v[4];
+                ACC* ap = acc + (4 * c4 - c0);
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    const int col = 4 * c4 + q;
-                    float f = 0.0f;
-                    if (col < A.Ic) {
-                        f = (float)(E.w2 * acc[col - c0] + E.w1 * pj * E.b_rank[col]);
-                        acc[col - c0] = 0.0;
-                    }
-                    v[q] = ((__float_as_uint(f) << 1) + 0x80u) >> 8;   // M >= 0: drop the sign, keep 8 exponent + 16 mantissa bits, round to nearest
+                    const float f = E.w2 * (float)ap[q];          // columns >= Ic were never touched: 0
+                    ap[q] = (ACC)0;
+                    v[q] = ((__float_as_uint(f) << 1) + 0x80u) >> 8;   // G >= 0: drop the sign, keep 8 exponent + 16 mantissa bits, round to nearest
                 }
                 out3[3 * c4 + 0] = v[0] | (v[1] << 24);
                 out3[3 * c4 + 1] = (v[1] >> 8) | (v[2] << 16);
@@ -417,36 +439,40 @@ __global__ void k_cooc_rm2(CoocArgs A, MEpilogue E, int n_items, int* __restrict
                 if (E.Bmax) {
                     // maximum of the values exactly as the scoring kernel will unpack them; one wave = one 256-column
                     // block (c0 and c1 are multiples of 256 when the bound matrix is requested, see pick_chunks)
-                    float m = 0.0f;
+                    uint32_t m = max(max(v[0], v[1]), max(v[2], v[3]));     // non-negative floats order like their bit patterns
 #pragma unroll
-                    for (int q = 0; q < 4; q++) m = fmaxf(m, __uint_as_float((v[q] << 8) >> 1));
-#pragma unroll
-                    for (int o = 1; o < 64; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-                    if ((threadIdx.x & 63) == 0) {
+                    for (int o = 1; o < 64; o <<= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+                    if ((threadIdx.x & 63) == 0 && m) {
                         // the maximum of 24-bit values is itself one: Bmax is stored in the same packed format (3 bytes per
                         // block, byte stores: the four blocks of a packed group belong to different waves or chunks), so
-                        // the bound pass streams 768 instead of 1024 bytes per rated item
-                        const uint32_t pv = (__float_as_uint(m) << 1) >> 8;
+                        // the bound pass streams 768 instead of 1024 bytes per rated item.  (Zero maxima are not stored:
+                        // the matrix was cleared before the launch.)
                         uint8_t* bp = reinterpret_cast<uint8_t*>(E.Bmax) + ((int64_t)mrow * E.ldb + (c4 >> 6)) * 3;
-                        bp[0] = (uint8_t)pv;
-                        bp[1] = (uint8_t)(pv >> 8);
-                        bp[2] = (uint8_t)(pv >> 16);
+                        bp[0] = (uint8_t)m;
+                        bp[1] = (uint8_t)(m >> 8);
+                        bp[2] = (uint8_t)(m >> 16);
                     }
                 }
             }
         } else {
             float* __restrict__ out = E.M + (int64_t)mrow * E.ldm;
             for (int col = c0 + threadIdx.x; col < c1; col += blockDim.x) {
-                float v = 0.0f;
-                if (col < A.Ic) {
-                    v = (float)(E.w2 * acc[col - c0] + E.w1 * pj * E.b_rank[col]);
-                    acc[col - c0] = 0.0;
-                }
-                out[col] = v;
+                out[col] = E.w2 * (float)acc[col - c0];
+                acc[col - c0] = (ACC)0;
             }
         }
+        item = nitem;
+        if (threadIdx.x == 0) next = next2;
         __syncthreads();   // the accumulators are clean again before the next item's atomics
     }
+}
+
+static void cooc_rm2_allow_lds() {
+    const int bytes = 160 * 1024 - 256;     // everything but the kernel's few static words
+    FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cooc_rm2<false, double>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cooc_rm2<true, double>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cooc_rm2<false, float>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cooc_rm2<true, float>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
 }
 
 #include "fy_rm2_kernels.hpp"   // scoring, top-N, branch-and-bound and cooperative-rank kernels (part of this translation unit)
@@ -524,6 +550,7 @@ struct ScoreTune {
     int coop = 1;                      // cooperative scoring of clusters that span all ranks (needs fy_collectives)
     int coop_force = 0;                // cooperative path also with world == 1 (identity collectives)
     int cooc_pk = 1;                   // packed 4-byte CSR entries for the row kernel when the ratings are fp16-exact
+    int cooc_f64 = 0;                  // row kernel accumulators in fp64 (round-1 arithmetic; one workgroup per CU)
     double max_surv_frac = 0.25;       // a pruned batch whose surviving blocks exceed this fraction falls back to the full pass
 };
 static ScoreTune score_tune() {
@@ -536,6 +563,7 @@ static ScoreTune score_tune() {
     if (const char* e = getenv("FY_COOP")) t.coop = atoi(e) != 0;
     if (const char* e = getenv("FY_COOP_FORCE")) t.coop_force = atoi(e) != 0;
     if (const char* e = getenv("FY_COOC_PK")) t.cooc_pk = atoi(e) != 0;
+    if (const char* e = getenv("FY_COOC_F64")) t.cooc_f64 = atoi(e) != 0;
     if (const char* e = getenv("FY_PRUNE_MIN_ITEMS")) t.prune_min_items = atoi(e);
     if (const char* e = getenv("FY_SEED_CHUNKS")) { int v = atoi(e); if (v >= 0 && v <= 4) { t.seed_chunks = v; t.seed_forced = v > 0; } }
     if (const char* e = getenv("FY_WORKSPACE_GB")) { long v = atol(e); if (v >= 1) t.workspace_default = (int64_t)v << 30; }
@@ -545,6 +573,27 @@ static ScoreTune score_tune() {
     if (const char* e = getenv("FY_TOPN_FORCE_SELECT")) t.force_select = atoi(e) != 0;
     if (const char* e = getenv("FY_MAX_SURV_FRAC")) { double v = atof(e); if (v >= 0.0) t.max_surv_frac = v; }
     return t;
+}
+
+// launch shape of the RM2 row kernel: as many workgroups per CU as the LDS accumulators allow (fp32: two for ML-25M's
+// 19 712-column chunks), 2048 threads per CU at most
+static void launch_cooc_rm2(Context* ctx, const ScoreTune& tune, bool use_pk, const CoocArgs& CA, const MEpilogue& ME, int n_items,
+                            int32_t* counter, hipStream_t st) {
+    if (n_items <= 0) return;
+    const size_t lds = (size_t)cooc_lds_columns(CA.CH) * (tune.cooc_f64 ? 8 : 4);
+    const int by_lds = (int)std::max<size_t>(1, (160 * 1024 - 512) / (lds + 64));
+    int block = tune.cooc_block;
+    if (!block) block = by_lds >= 4 ? 256 : (by_lds >= 2 ? 512 : 1024);
+    const int per_cu = std::max(1, std::min(by_lds, 2048 / block));
+    const int grid = std::min(n_items, ctx->num_cus * per_cu);
+    if (tune.cooc_f64) {
+        if (use_pk) k_cooc_rm2<true, double><<<grid, block, lds, st>>>(CA, ME, n_items, counter);
+        else k_cooc_rm2<false, double><<<grid, block, lds, st>>>(CA, ME, n_items, counter);
+    } else {
+        if (use_pk) k_cooc_rm2<true, float><<<grid, block, lds, st>>>(CA, ME, n_items, counter);
+        else k_cooc_rm2<false, float><<<grid, block, lds, st>>>(CA, ME, n_items, counter);
+    }
+    FY_KERNEL_CHECK();
 }
 
 // one cluster's launch plan
@@ -672,10 +721,11 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
     FY_KERNEL_CHECK();
     DevBuf<double> p_rank(ctx, nP);
     DevBuf<double>& b_rank = J->b_rank;
-    DevBuf<float> a_rank(ctx, nP);
-    k_pair_p<<<grid_for(nP), 256, 0, st>>>(nP, P.rank_pair.get(), P.pair_di.get(), R->d_icoll.get(), lambda, p_rank.get(), a_rank.get());
+    DevBuf<float> a_rank(ctx, nP), b_rank32(ctx, nP);
+    k_pair_p<<<grid_for(nP), 256, 0, st>>>(nP, P.rank_pair.get(), P.pair_di.get(), R->d_icoll.get(), lambda, b_rank.get(), p_rank.get(), a_rank.get(),
+                                           b_rank32.get());
     FY_KERNEL_CHECK();
-    DevBuf<float> csc_x(ctx, P.nnz), csr_x(ctx, P.nnz), csr_e(ctx, P.nnz);
+    DevBuf<float> csc_x(ctx, P.nnz), csr_x(ctx, P.nnz), csr_e(ctx, P.nnz), csr_q(ctx, P.nnz);
     const bool use_pk = tune.cooc_pk && P.ratings_fp16_exact;   // packed CSR for the row kernel
     DevBuf<float> csc_x_over_s(ctx, use_pk ? (size_t)P.nnz : 1);
     DevBuf<uint32_t> csr_pk(ctx, use_pk ? (size_t)P.nnz : 1);
@@ -684,7 +734,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
     FY_KERNEL_CHECK();
     k_csr_values<<<grid_for((int64_t)nU * 64, 256), 256, 0, st>>>(nU, P.rowptr.get(), P.csr_idx.get(), P.csr_r.get(), P.slot2du.get(),
                                                                    P.ucluster.get(), P.usum.get(), P.d_csize.get(), P.d_pcstart.get(),
-                                                                   p_rank.get(), b_rank.get(), lambda, csr_x.get(), csr_e.get());
+                                                                   p_rank.get(), b_rank.get(), lambda, csr_x.get(), csr_e.get(), csr_q.get());
     FY_KERNEL_CHECK();
 
     t_tables.end(span_tables);
@@ -745,8 +795,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
     if (n_recs > 0 && max_Ic > 0) {
         const int64_t ws = prm.workspace_bytes > 0 ? prm.workspace_bytes : tune.workspace_default;
         const int max_ch_lds = tune.cooc_max_ch;   // fp64 accumulators in LDS
-        FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cooc_rm2<false>), hipFuncAttributeMaxDynamicSharedMemorySize, max_ch_lds * 8));
-        FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cooc_rm2<true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_ch_lds * 8));
+        cooc_rm2_allow_lds();
 
         // ---- per-cluster plan; the clusters are spread over up to four "lanes" (HIP streams with their own M / score
         // scratch): the tail of one cluster's launches -- its heaviest user sits on a single wave for milliseconds, and
@@ -798,7 +847,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             DevBuf<float> M, S;
             DevBuf<int32_t> overflow, any_overflow;
             // branch and bound
-            DevBuf<float> Bmax, amax, UB, tau;
+            DevBuf<float> Bmax, amax, bmax, UB, tau;
             DevBuf<uint16_t> surv;
             DevBuf<int32_t> n_quads, quad_prefix;
             DevBuf<int2> item_seg;
@@ -841,6 +890,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 L.any_overflow.alloc(ctx, 1);
                 L.Bmax.alloc(ctx, bm_el);
                 L.amax.alloc(ctx, am_el);
+                L.bmax.alloc(ctx, am_el);
                 L.UB.alloc(ctx, ub_el);
                 L.tau.alloc(ctx, ov_el);
                 L.surv.alloc(ctx, ub_el);
@@ -906,7 +956,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             const int64_t ldm = p.ldm;
             const bool pack24 = p.pack24;
             if (p.coop) {
-                CoopShared X{J, R.get(), &tune, p_rank.get(), b_rank.get(), a_rank.get(), use_pk ? csc_x_over_s.get() : csc_x.get(), csr_x.get(), csr_e.get(),
+                CoopShared X{J, R.get(), &tune, b_rank32.get(), a_rank.get(), use_pk ? csc_x_over_s.get() : csc_x.get(), csr_x.get(), csr_e.get(), csr_q.get(),
                              use_pk ? csr_pk.get() : nullptr,
                              n_out.get(), out_off.get(), pvpi.get(), lo, &t_cooc, &t_score, &t_topn, prune_counters.get(),
                              &prune_blocks_total, &prune_seed_terms_cols, &coop_survived, &coop_pair_contribs};
@@ -917,25 +967,20 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             // -- M build
             CoocArgs CA{P.rank_pair.get(), P.pair_start.get(), segs[pi].ptr.get(), segs[pi].seg.get(), segs[pi].w.get(), P.csr_idx.get(),
                         csr_x.get(), pbase, sbase, Ic, CH, nch, 0, Ic, p.q0, p.nq, nullptr, 0, use_pk ? csr_pk.get() : nullptr};
-            MEpilogue ME{L.M.get(), ldm, p_rank.get() + pbase, b_rank.get() + pbase, (1.0 - lambda) * (1.0 - lambda), lambda * (1.0 - lambda),
-                         pack24 ? 1 : 0, p.prune ? L.Bmax.get() : nullptr, p.ldb};
+            MEpilogue ME{L.M.get(), ldm, (float)((1.0 - lambda) * (1.0 - lambda)), pack24 ? 1 : 0, p.prune ? L.Bmax.get() : nullptr, p.ldb, 0};
             if (p.prune) {
                 FY_HIP(hipMemsetAsync(L.Bmax.get(), 0, (size_t)Ic * p.ldb * 3, ls));
-                k_block_amax<<<grid_for(p.ldb), 256, 0, ls>>>(Ic, (int32_t)p.ldb, a_rank.get() + pbase, L.amax.get());
+                k_block_amax<<<grid_for(p.ldb), 256, 0, ls>>>(Ic, (int32_t)p.ldb, a_rank.get() + pbase, b_rank32.get() + pbase, L.amax.get(), L.bmax.get());
                 FY_KERNEL_CHECK();
             }
-            const int block = tune.cooc_block ? tune.cooc_block : ((CH * 8 > 48 * 1024) ? 1024 : 256);
             const size_t sp = t_cooc.begin(ls);
             {
                 const int n_items = Ic * nch;
                 k_item_segments<<<grid_for(n_items), 256, 0, ls>>>(CA, L.item_seg.get());
                 FY_KERNEL_CHECK();
                 CA.item_seg = L.item_seg.get();
-                const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2048 / block, (160 * 1024) / ((size_t)CH * 8 + 1024)));
-                const int grid = std::min(n_items, ctx->num_cus * per_cu);
                 FY_HIP(hipMemsetAsync(L.any_overflow.get(), 0, sizeof(int32_t), ls));   // reused as the item counter
-                if (use_pk) k_cooc_rm2<true><<<grid, block, (size_t)CH * 8, ls>>>(CA, ME, n_items, L.any_overflow.get());
-                else k_cooc_rm2<false><<<grid, block, (size_t)CH * 8, ls>>>(CA, ME, n_items, L.any_overflow.get());
+                launch_cooc_rm2(ctx, tune, use_pk, CA, ME, n_items, L.any_overflow.get(), ls);
             }
             FY_KERNEL_CHECK();
             t_cooc.end(sp, ls);
@@ -948,7 +993,8 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             auto score_args = [&](const float* Mx, int64_t ldmx, int32_t Icx, const float* ax, int32_t s0, int32_t nb, float* Sx, int64_t ldSx,
                                   int n_slices, int nchunks) {
                 ScoreArgs SA{};
-                SA.M = Mx; SA.ldm = ldmx; SA.Ic = Icx; SA.a_rank = ax; SA.rb_off = row_off; SA.csr_idx = P.csr_idx.get(); SA.csr_e = csr_e.get();
+                SA.M = Mx; SA.ldm = ldmx; SA.Ic = Icx; SA.a_rank = ax; SA.b_rank = b_rank32.get() + pbase; SA.rb_off = row_off;
+                SA.csr_idx = P.csr_idx.get(); SA.csr_e = csr_e.get(); SA.csr_q = csr_q.get();
                 SA.pvpi = pvpi.get(); SA.n_out = n_out.get(); SA.slot_lo = lo; SA.slot_base = sbase; SA.slot0 = s0; SA.n_users = nb;
                 SA.S = Sx; SA.ldS = ldSx; SA.n_slices = n_slices; SA.n_chunks = nchunks;
                 return SA;
@@ -958,8 +1004,8 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 const int n_slices = (int)std::max<int64_t>(1, std::min<int64_t>(tune.max_slices, ceil_div(nb, 4 * tune.users_per_wave)));
                 ScoreArgs SA = score_args(L.M.get(), ldm, Ic, a_rank.get() + pbase, s0, nb, Sx, ldS, n_slices, n_chunks);
                 const size_t ss = t_score.begin(ls);
-                if (pack24) k_score<4, true, 8><<<n_chunks * n_slices, 256, 0, ls>>>(SA.M, SA.a_rank, SA.rb_off, SA.csr_idx, SA.csr_e, SA.pvpi, SA.n_out, SA.S, SA);
-                else k_score<4, false, 8><<<n_chunks * n_slices, 256, 0, ls>>>(SA.M, SA.a_rank, SA.rb_off, SA.csr_idx, SA.csr_e, SA.pvpi, SA.n_out, SA.S, SA);
+                if (pack24) k_score<4, true, 8><<<n_chunks * n_slices, 256, 0, ls>>>(SA.M, SA.a_rank, SA.rb_off, SA.csr_idx, SA.csr_e, SA.csr_q, SA.pvpi, SA.n_out, SA.S, SA);
+                else k_score<4, false, 8><<<n_chunks * n_slices, 256, 0, ls>>>(SA.M, SA.a_rank, SA.rb_off, SA.csr_idx, SA.csr_e, SA.csr_q, SA.pvpi, SA.n_out, SA.S, SA);
                 FY_KERNEL_CHECK();
                 t_score.end(ss, ls);
                 R->st.score_launches++;
@@ -992,10 +1038,11 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 SA.ldm2 = p.ldb;
                 SA.Ic2 = p.nblk;
                 SA.a2 = L.amax.get();
+                SA.b2 = L.bmax.get();
                 SA.S2 = L.UB.get();
                 SA.ldS2 = p.ldb;
                 SA.no_mask2 = 1;
-                k_score<4, true, 8><<<(seed_chunks + bchunks) * n_slices, 256, 0, ls>>>(SA.M, SA.a_rank, SA.rb_off, SA.csr_idx, SA.csr_e, SA.pvpi, SA.n_out, SA.S, SA);
+                k_score<4, true, 8><<<(seed_chunks + bchunks) * n_slices, 256, 0, ls>>>(SA.M, SA.a_rank, SA.rb_off, SA.csr_idx, SA.csr_e, SA.csr_q, SA.pvpi, SA.n_out, SA.S, SA);
                 FY_KERNEL_CHECK();
                 // (2) tau_u = N-th best seed score; the sorted seed head is also the user's list unless a block survives
                 TopNArgs T1{L.S.get(), SC, Ic, n_out.get(), out_off.get(), P.rank_item_raw.get() + pbase, P.slot2du.get(), P.uid.get(),
@@ -1036,7 +1083,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 L.Ssurv.alloc(ctx, (size_t)std::max(1, n_surv_total) * PRUNE_BLOCK);
                 if (n_surv_total > 0) {
                     ScoreArgs SQ = score_args(L.M.get(), ldm, Ic, a_rank.get() + pbase, s0, nb, L.Ssurv.get(), 0, n_slices, n_chunks);
-                    k_score_blocks<8><<<std::min(n_surv_total, ctx->num_cus * 16), 256, 0, ls>>>(SQ.M, SQ.a_rank, P.rowptr.get(), SQ.csr_idx, SQ.csr_e, SQ.pvpi,
+                    k_score_blocks<8><<<std::min(n_surv_total, ctx->num_cus * 16), 256, 0, ls>>>(SQ.M, SQ.a_rank, P.rowptr.get(), SQ.csr_idx, SQ.csr_e, SQ.csr_q, SQ.pvpi,
                                                                         L.quad_prefix.get(), L.surv.get(), SQ.S, SQ, p.ldb, prune_counters.get());
                     FY_KERNEL_CHECK();
                 }

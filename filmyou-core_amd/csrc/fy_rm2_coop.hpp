@@ -14,8 +14,8 @@ struct CoopShared {
     fy_rm2_job* J;
     fy_result* R;
     const ScoreTune* tune;
-    const double *p_rank, *b_rank;
-    const float *a_rank, *csc_x, *csr_x, *csr_e;
+    const float *b_rank;              // b_i (fp32), rank order
+    const float *a_rank, *csc_x, *csr_x, *csr_e, *csr_q;
     const uint32_t* csr_pk;        // packed CSR for the row kernel (nullptr: csr_idx / csr_x); csc_x then holds x / s_v
     const int32_t *n_out, *out_off;   // this rank's users, by slot - lo
     const double* pvpi;               // this rank's users, by slot - lo (the complete value; pv_all below is zero on ranks != 0)
@@ -86,12 +86,12 @@ static void score_cluster_coop(const CoopShared& X, const Plan& p, hipStream_t l
     const int64_t SC = (int64_t)seed_chunks * 256;
     const int bchunks = (int)(ldb / 256);
     DevBuf<float> Mloc(ctx, (size_t)std::max<int64_t>(1, (int64_t)nrows * ldm * 3 / 4 + 4)), Bloc(ctx, (size_t)std::max<int64_t>(1, (int64_t)nrows * ldb));
-    DevBuf<float> amax(ctx, (size_t)ldb);
+    DevBuf<float> amax(ctx, (size_t)ldb), bmax(ctx, (size_t)ldb);
     DevBuf<int32_t> n_out_all(ctx, (size_t)Uc), item_counter(ctx, 1);
     // my compact CSR over all users of the cluster (local row indices); its size is not known on the host: room for all
     const int64_t nnz_c = (int64_t)p.nq;
     DevBuf<int32_t> my_cnt(ctx, (size_t)Uc + 1), my_rowptr(ctx, (size_t)Uc + 1), my_idx(ctx, (size_t)std::max<int64_t>(1, nnz_c));
-    DevBuf<float> my_e(ctx, (size_t)std::max<int64_t>(1, nnz_c));
+    DevBuf<float> my_e(ctx, (size_t)std::max<int64_t>(1, nnz_c)), my_q(ctx, (size_t)std::max<int64_t>(1, nnz_c));
     DevBuf<double> pv_all(ctx, (size_t)Uc);
     DevBuf<unsigned long long> dummy(ctx, 2);
     DevBuf<float> seed_send(ctx, (size_t)((int64_t)W * Umax * SC)), seed(ctx, (size_t)((int64_t)Umax * SC));
@@ -121,25 +121,19 @@ static void score_cluster_coop(const CoopShared& X, const Plan& p, hipStream_t l
         }
         build_segments(ctx, my_slot.get(), my_w.get(), co_tmp.get(), sbase, 0, (int32_t)my_ratings, nch, seg, ls);
         FY_HIP(hipMemsetAsync(Bloc.get(), 0, (size_t)std::max<int64_t>(1, (int64_t)nrows * ldb) * 3, ls));
-        k_block_amax<<<grid_for(ldb), 256, 0, ls>>>(Ic, (int32_t)ldb, X.a_rank + pbase, amax.get());
+        k_block_amax<<<grid_for(ldb), 256, 0, ls>>>(Ic, (int32_t)ldb, X.a_rank + pbase, X.b_rank + pbase, amax.get(), bmax.get());
         FY_KERNEL_CHECK();
         if (nrows > 0) {
             CoocArgs CA{P.rank_pair.get(), P.pair_start.get(), seg.ptr.get(), seg.seg.get(), seg.w.get(), P.csr_idx.get(),
                         X.csr_x, pbase, sbase, Ic, CH, nch, r0, nrows, 0, (int32_t)my_ratings, local_start.get(), W, X.csr_pk};
-            MEpilogue ME{const_cast<float*>(Mshift), ldm, X.p_rank + pbase, X.b_rank + pbase, (1.0 - lambda) * (1.0 - lambda),
-                         lambda * (1.0 - lambda), 1, const_cast<float*>(Bshift), ldb, 1};
-            const int block = tune.cooc_block ? tune.cooc_block : ((CH * 8 > 48 * 1024) ? 1024 : 256);
+            MEpilogue ME{const_cast<float*>(Mshift), ldm, (float)((1.0 - lambda) * (1.0 - lambda)), 1, const_cast<float*>(Bshift), ldb, 1};
             const size_t sp = X.t_cooc->begin(ls);
             const int n_items = nrows * nch;
             k_item_segments<<<grid_for(n_items), 256, 0, ls>>>(CA, item_seg.get());
             FY_KERNEL_CHECK();
             CA.item_seg = item_seg.get();
-            const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2048 / block, (160 * 1024) / ((size_t)CH * 8 + 1024)));
-            const int grid = std::min(n_items, ctx->num_cus * per_cu);
             FY_HIP(hipMemsetAsync(item_counter.get(), 0, sizeof(int32_t), ls));
-            if (X.csr_pk) k_cooc_rm2<true><<<grid, block, (size_t)CH * 8, ls>>>(CA, ME, n_items, item_counter.get());
-            else k_cooc_rm2<false><<<grid, block, (size_t)CH * 8, ls>>>(CA, ME, n_items, item_counter.get());
-            FY_KERNEL_CHECK();
+            launch_cooc_rm2(ctx, tune, X.csr_pk != nullptr, CA, ME, n_items, item_counter.get(), ls);
             X.t_cooc->end(sp, ls);
             R->st.cooc_launches++;
         }
@@ -150,8 +144,8 @@ static void score_cluster_coop(const CoopShared& X, const Plan& p, hipStream_t l
     k_my_csr_count<<<grid_for(((int64_t)Uc + 1) * 64, 256), 256, 0, ls>>>(Uc, sbase, P.rowptr.get(), P.csr_idx.get(), W, me, my_cnt.get());
     FY_KERNEL_CHECK();
     exclusive_scan_i32(ctx, my_cnt.get(), my_rowptr.get(), (size_t)Uc + 1, ls);
-    k_my_csr_fill<<<grid_for((int64_t)Uc * 64, 256), 256, 0, ls>>>(Uc, sbase, P.rowptr.get(), P.csr_idx.get(), X.csr_e, W, me, my_rowptr.get(),
-                                                                   my_idx.get(), my_e.get());
+    k_my_csr_fill<<<grid_for((int64_t)Uc * 64, 256), 256, 0, ls>>>(Uc, sbase, P.rowptr.get(), P.csr_idx.get(), X.csr_e, X.csr_q, W, me, my_rowptr.get(),
+                                                                   my_idx.get(), my_e.get(), my_q.get());
     FY_KERNEL_CHECK();
     FY_HIP(hipMemsetAsync(dummy.get(), 0, 2 * sizeof(unsigned long long), ls));
     k_user_meta<<<grid_for(Uc), 256, 0, ls>>>(sbase, sbase + Uc, P.slot2du.get(), P.uid.get(), P.ucluster.get(), P.udeg.get(),
@@ -169,8 +163,8 @@ static void score_cluster_coop(const CoopShared& X, const Plan& p, hipStream_t l
         if (nk <= 0) continue;
         const int ns = slices_for(nk);
         ScoreArgs SA{};
-        SA.M = Mshift; SA.ldm = ldm; SA.Ic = Ic; SA.a_rank = X.a_rank + pbase; SA.rb_off = my_rowptr.get(); SA.csr_idx = my_idx.get();
-        SA.csr_e = my_e.get(); SA.pvpi = pv_all.get(); SA.n_out = n_out_all.get(); SA.slot_lo = sbase; SA.slot_base = sbase; SA.slot0 = ua[k];
+        SA.M = Mshift; SA.ldm = ldm; SA.Ic = Ic; SA.a_rank = X.a_rank + pbase; SA.b_rank = X.b_rank + pbase; SA.rb_off = my_rowptr.get();
+        SA.csr_idx = my_idx.get(); SA.csr_e = my_e.get(); SA.csr_q = my_q.get(); SA.pvpi = pv_all.get(); SA.n_out = n_out_all.get(); SA.slot_lo = sbase; SA.slot_base = sbase; SA.slot0 = ua[k];
         SA.n_users = nk; SA.S = seed_send.get() + (int64_t)k * Umax * SC; SA.ldS = SC; SA.n_slices = ns; SA.n_chunks = seed_chunks + bchunks;
         SA.row_mul = W; SA.row_add = me;
         SA.chunks1 = seed_chunks;
@@ -178,10 +172,11 @@ static void score_cluster_coop(const CoopShared& X, const Plan& p, hipStream_t l
         SA.ldm2 = ldb;
         SA.Ic2 = p.nblk;
         SA.a2 = amax.get();
+        SA.b2 = bmax.get();
         SA.S2 = ub_send.get() + (int64_t)k * Umax * ldb;
         SA.ldS2 = ldb;
         SA.no_mask2 = 1;
-        k_score<4, true, 8><<<(seed_chunks + bchunks) * ns, 256, 0, ls>>>(SA.M, SA.a_rank, SA.rb_off, SA.csr_idx, SA.csr_e, SA.pvpi, SA.n_out, SA.S, SA);
+        k_score<4, true, 8><<<(seed_chunks + bchunks) * ns, 256, 0, ls>>>(SA.M, SA.a_rank, SA.rb_off, SA.csr_idx, SA.csr_e, SA.csr_q, SA.pvpi, SA.n_out, SA.S, SA);
         FY_KERNEL_CHECK();
         R->st.score_launches += 2;
     }
@@ -228,7 +223,7 @@ static void score_cluster_coop(const CoopShared& X, const Plan& p, hipStream_t l
         coll_all_gather(J, entries.get(), entries_all.get(), (int64_t)t_max * (int64_t)sizeof(long long), ls);
         ss = X.t_score->begin(ls);
         // ---- (7) partial exact scores of all survivors over my rows, reduce-scatter to the owners
-        k_score_entries<8><<<ctx->num_cus * 8, 256, 0, ls>>>(Mshift, X.a_rank + pbase, my_rowptr.get(), my_idx.get(), my_e.get(), pv_all.get(),
+        k_score_entries<8><<<ctx->num_cus * 8, 256, 0, ls>>>(Mshift, X.a_rank + pbase, X.b_rank + pbase, my_rowptr.get(), my_idx.get(), my_e.get(), my_q.get(), pv_all.get(),
                                                              entries_all.get(), counts.get(), W, t_max, sbase, Ic, ldm, W, me, Spart.get(),
                                                              X.prune_counters);
         FY_KERNEL_CHECK();

@@ -4,9 +4,11 @@
 #pragma once
 
 // ================================================================ scoring kernel
-// Work item = (user, column chunk of 64*VEC items): the wave walks the user's CSR row (wave-uniform scalar loads of idx
-// and e) and for every rated item j streams the segment M[j][chunk] (4*VEC bytes per lane, coalesced), adding
-// log2(M[j][i] + a_i * e_uj) to the lane's VEC candidates.  No cross-lane traffic at all.
+// Work item = (user, column chunk of 64*VEC items): the wave walks the user's CSR row (wave-uniform scalar loads of idx,
+// e and q) and for every rated item j streams the segment G[j][chunk] (4*VEC bytes per lane, coalesced), adding
+// log2(G[j][i] + q_j * b_i + a_i * e_uj) to the lane's VEC candidates (G = (1-l)^2 X^T X, q_j = l (1-l) p_j, a_i = l p_i:
+// the rank-one part of the reference's inner sum is applied here, one FMA per term, so that the stored matrix is the pure
+// co-rating Gram -- symmetric, and zero wherever two items were never co-rated).  No cross-lane traffic at all.
 // (Round 1 also measured a row-blocked variant sized to the L2, a variant with the hottest rows resident in LDS and
 // non-temporal loads of the cold rows: all slower; they are no longer in the tree.)
 struct ScoreArgs {
@@ -14,9 +16,11 @@ struct ScoreArgs {
     int64_t ldm;
     int32_t Ic;
     const float* __restrict__ a_rank;      // l * p_i in rank order, offset by pbase
+    const float* __restrict__ b_rank;      // b_i = sum_v x_vi (fp32) in rank order, offset by pbase
     const int32_t* __restrict__ rb_off;    // [slot - slot_base], [slot - slot_base + 1]: the user's CSR row (rowptr of the cluster)
     const int32_t* __restrict__ csr_idx;
     const float* __restrict__ csr_e;
+    const float* __restrict__ csr_q;       // q_j = l (1-l) p_j per rating (same indexing as csr_e)
     const double* __restrict__ pvpi;       // indexed by slot - slot_lo
     const int32_t* __restrict__ n_out;     // indexed by slot - slot_lo; 0 = user gets no list
     int32_t slot_lo;                       // first slot of this rank
@@ -37,6 +41,7 @@ struct ScoreArgs {
     int64_t ldm2;
     int32_t Ic2;
     const float* __restrict__ a2;
+    const float* __restrict__ b2;
     float* __restrict__ S2;
     int64_t ldS2;
     int32_t no_mask2;
@@ -82,7 +87,8 @@ __device__ __forceinline__ bool fy_bound_keeps(float ub, float tau, float pvpi) 
 template <int VEC, bool P24, int SB>
 __global__ __launch_bounds__(256) void k_score(const float* __restrict__ M_, const float* __restrict__ a_rank_,
                                                const int32_t* __restrict__ rb_off_, const int32_t* __restrict__ csr_idx_,
-                                               const float* __restrict__ csr_e_, const double* __restrict__ pvpi_,
+                                               const float* __restrict__ csr_e_, const float* __restrict__ csr_q_,
+                                               const double* __restrict__ pvpi_,
                                                const int32_t* __restrict__ n_out_, float* __restrict__ S_, ScoreArgs A) {
     using V = typename VecT<VEC>::type;
     using G = typename std::conditional<P24, U3, V>::type;   // what one lane loads per row
@@ -97,14 +103,18 @@ __global__ __launch_bounds__(256) void k_score(const float* __restrict__ M_, con
     if (second) chunk -= A.chunks1;
     const float* __restrict__ Msel = second ? A.M2 : M_;
     const float* __restrict__ asel = second ? A.a2 : a_rank_;
+    const float* __restrict__ bsel = second ? A.b2 : A.b_rank;
     float* __restrict__ Ssel = second ? A.S2 : S_;
     const int64_t ldm_sel = second ? A.ldm2 : A.ldm, ldS_sel = second ? A.ldS2 : A.ldS;
     const int Ic_sel = second ? A.Ic2 : A.Ic, no_mask = second ? A.no_mask2 : A.no_mask;
     const int col0 = chunk * CW;
     const int col = col0 + lane * VEC;
-    float a[VEC];
+    float a[VEC], bb[VEC];
 #pragma unroll
-    for (int v = 0; v < VEC; v++) a[v] = col + v < Ic_sel ? asel[col + v] : 0.0f;
+    for (int v = 0; v < VEC; v++) {
+        a[v] = col + v < Ic_sel ? asel[col + v] : 0.0f;
+        bb[v] = col + v < Ic_sel ? bsel[col + v] : 0.0f;
+    }
     // byte address of this lane's part of row 0; the row pitch is ldm * (P24 ? 3 : 4) bytes
     const char* __restrict__ Mcol = reinterpret_cast<const char*>(Msel) + (int64_t)col * (P24 ? 3 : 4);
     const int64_t pitch = ldm_sel * (P24 ? 3 : 4);
@@ -125,13 +135,14 @@ __global__ __launch_bounds__(256) void k_score(const float* __restrict__ M_, con
         // (out-of-range slots re-load the last valid row -- an L1 hit -- and are skipped by a wave-uniform test)
         for (int k = beg; k < end; k += SB) {
             G g[SB];
-            float e[SB];
+            float e[SB], qq[SB];
             int jj[SB];
 #pragma unroll
             for (int q = 0; q < SB; q++) {
                 const int kk = min(k + q, end - 1);
                 jj[q] = csr_idx_[kk];
                 e[q] = csr_e_[kk];
+                qq[q] = csr_q_[kk];
                 g[q] = *reinterpret_cast<const G*>(Mcol + (int64_t)jj[q] * pitch);
             }
             float p[VEC];
@@ -148,7 +159,7 @@ __global__ __launch_bounds__(256) void k_score(const float* __restrict__ M_, con
                         for (int v = 0; v < VEC; v++) gv[v] = gp[v];
                     }
 #pragma unroll
-                    for (int v = 0; v < VEC; v++) p[v] += fy_log2(fmaf(a[v], e[q], gv[v]));
+                    for (int v = 0; v < VEC; v++) p[v] += fy_log2(fmaf(qq[q], bb[v], fmaf(a[v], e[q], gv[v])));
                     const unsigned d = (unsigned)(jj[q] * row_mul + A.row_add - col0);
                     if (!no_mask && d < (unsigned)CW && (int)(d / VEC) == lane) mask |= 1u << (d % VEC);
                 }
@@ -501,20 +512,22 @@ __global__ __launch_bounds__(256) void k_topn_select(TopNArgs A, const int32_t* 
 
 // ================================================================ exact pruning of candidate blocks (branch and bound)
 // For a block B of 256 candidate columns,
-//     UB(u, B) = pvpi + sum_{j in rated(u)} ln( max_{i in B} M[j][i] + (max_{i in B} a_i) * e_uj )  >=  score(u, i)  for all i in B,
-// because every term is monotone in M[j][i] and a_i.  Evaluating UB is the scoring kernel itself run on the reduced
+//     UB(u, B) = pvpi + sum_{j in rated(u)} ln( max_{i in B} G[j][i] + q_j max_{i in B} b_i + (max_{i in B} a_i) * e_uj )  >=  score(u, i)
+// for all i in B, because every term is monotone in G[j][i], b_i and a_i (all factors are non-negative).  Evaluating UB is the scoring kernel itself run on the reduced
 // matrix Bmax[j][B] (1/256 of the columns).  With tau_u = the N-th best EXACT score among the first `seed` (most
 // popular) columns, a block whose UB is below tau_u cannot contribute to the user's top N and is skipped; the exact
 // kernel then runs only on the surviving (user, block) pairs.  RM2 scores fall steeply with candidate popularity, so on
 // MovieLens-shaped data well under 1 % of the tail blocks survive -- the lists are bit-for-bit those of the full pass.
 constexpr int PRUNE_BLOCK = 256;   // = the column chunk of the scoring kernel: a surviving block is one (user, chunk) work item
 
-// block maxima of a = lambda * p
-__global__ void k_block_amax(int32_t Ic, int32_t ldb, const float* __restrict__ a_rank, float* __restrict__ amax) {
+// block maxima of a = lambda * p and of b (the rank-one part of a term, q_j b_i + a_i e_uj, is monotone in both)
+__global__ void k_block_amax(int32_t Ic, int32_t ldb, const float* __restrict__ a_rank, const float* __restrict__ b_rank,
+                             float* __restrict__ amax, float* __restrict__ bmax) {
     for (int32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < ldb; b += gridDim.x * blockDim.x) {
-        float m = 0.0f;
-        for (int i = b * PRUNE_BLOCK; i < min(Ic, (b + 1) * PRUNE_BLOCK); i++) m = fmaxf(m, a_rank[i]);
+        float m = 0.0f, mb = 0.0f;
+        for (int i = b * PRUNE_BLOCK; i < min(Ic, (b + 1) * PRUNE_BLOCK); i++) { m = fmaxf(m, a_rank[i]); mb = fmaxf(mb, b_rank[i]); }
         amax[b] = m;
+        bmax[b] = mb;
     }
 }
 
@@ -524,7 +537,8 @@ __global__ void k_block_amax(int32_t Ic, int32_t ldb, const float* __restrict__ 
 template <int SB>
 __global__ __launch_bounds__(256) void k_score_blocks(const float* __restrict__ M_, const float* __restrict__ a_rank_,
                                                       const int32_t* __restrict__ rowptr_, const int32_t* __restrict__ csr_idx_,
-                                                      const float* __restrict__ csr_e_, const double* __restrict__ pvpi_,
+                                                      const float* __restrict__ csr_e_, const float* __restrict__ csr_q_,
+                                                      const double* __restrict__ pvpi_,
                                                       const int32_t* __restrict__ surv_prefix_, const uint16_t* __restrict__ surv_,
                                                       float* __restrict__ S_, ScoreArgs A, int64_t ldb,
                                                       unsigned long long* __restrict__ counters) {
@@ -548,9 +562,12 @@ __global__ __launch_bounds__(256) void k_score_blocks(const float* __restrict__ 
         const int slot = A.slot0 + u;
         const int col0 = (int)surv_[(int64_t)u * ldb + (w - surv_prefix_[u])] * PRUNE_BLOCK;
         const int col = col0 + lane * 4;
-        float a[4];
+        float a[4], bb[4];
 #pragma unroll
-        for (int v = 0; v < 4; v++) a[v] = col + v < A.Ic ? a_rank_[col + v] : 0.0f;
+        for (int v = 0; v < 4; v++) {
+            a[v] = col + v < A.Ic ? a_rank_[col + v] : 0.0f;
+            bb[v] = col + v < A.Ic ? A.b_rank[col + v] : 0.0f;
+        }
         const char* __restrict__ Mcol = reinterpret_cast<const char*>(M_) + (int64_t)col * 3;
         const int row_beg = rowptr_[slot], row_end = rowptr_[slot + 1];
         const int quarter = (((row_end - row_beg + 3) >> 2) + SB - 1) / SB * SB;   // whole batches per wave
@@ -559,13 +576,14 @@ __global__ __launch_bounds__(256) void k_score_blocks(const float* __restrict__ 
         unsigned mask = 0;
         for (int k = beg; k < end; k += SB) {
             U3 g[SB];
-            float e[SB];
+            float e[SB], qq[SB];
             int jj[SB];
 #pragma unroll
             for (int x = 0; x < SB; x++) {
                 const int kk = min(k + x, end - 1);
                 jj[x] = csr_idx_[kk];
                 e[x] = csr_e_[kk];
+                qq[x] = csr_q_[kk];
                 g[x] = *reinterpret_cast<const U3*>(Mcol + (int64_t)jj[x] * pitch);
             }
             float p[4] = {0.f, 0.f, 0.f, 0.f};
@@ -575,7 +593,7 @@ __global__ __launch_bounds__(256) void k_score_blocks(const float* __restrict__ 
                     float gv[4];
                     fy_unpack24(g[x], gv);
 #pragma unroll
-                    for (int v = 0; v < 4; v++) p[v] += fy_log2(fmaf(a[v], e[x], gv[v]));
+                    for (int v = 0; v < 4; v++) p[v] += fy_log2(fmaf(qq[x], bb[v], fmaf(a[v], e[x], gv[v])));
                     const unsigned d = (unsigned)(jj[x] - col);
                     if (d < 4u) mask |= 1u << d;
                 }
@@ -627,8 +645,9 @@ __global__ void k_my_csr_count(int32_t n_slots, int32_t slot_base, const int32_t
     }
 }
 __global__ void k_my_csr_fill(int32_t n_slots, int32_t slot_base, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ csr_idx,
-                              const float* __restrict__ csr_e, int32_t world, int32_t me, const int32_t* __restrict__ my_rowptr,
-                              int32_t* __restrict__ my_idx, float* __restrict__ my_e) {
+                              const float* __restrict__ csr_e, const float* __restrict__ csr_q, int32_t world, int32_t me,
+                              const int32_t* __restrict__ my_rowptr, int32_t* __restrict__ my_idx, float* __restrict__ my_e,
+                              float* __restrict__ my_q) {
     const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
     for (int32_t v = blockIdx.x * wpb + (threadIdx.x >> 6); v < n_slots; v += gridDim.x * wpb) {
         int at = my_rowptr[v];
@@ -642,6 +661,7 @@ __global__ void k_my_csr_fill(int32_t n_slots, int32_t slot_base, const int32_t*
                 const int k = at + __popcll(bal & ((1ull << lane) - 1ull));
                 my_idx[k] = j / world;
                 my_e[k] = csr_e[f];
+                my_q[k] = csr_q[f];
             }
             at += __popcll(bal);
         }
@@ -699,8 +719,10 @@ __global__ void k_surv_entries(int32_t n_users, int32_t slot0, const int32_t* __
 // 256 floats at Spart[w * 256]; entry w = k * t_max + i belongs to rank k and exists when i < counts[k]
 template <int SB>
 __global__ __launch_bounds__(256) void k_score_entries(const float* __restrict__ M_, const float* __restrict__ a_rank_,
+                                                       const float* __restrict__ b_rank_,
                                                        const int32_t* __restrict__ range_off_, const int32_t* __restrict__ csr_idx_,
-                                                       const float* __restrict__ csr_e_, const double* __restrict__ pvpi_,
+                                                       const float* __restrict__ csr_e_, const float* __restrict__ csr_q_,
+                                                       const double* __restrict__ pvpi_,
                                                        const long long* __restrict__ entries_, const int32_t* __restrict__ counts_,
                                                        int32_t world, int32_t t_max, int32_t slot_base, int32_t Ic, int64_t ldm,
                                                        int32_t row_mul, int32_t row_add, float* __restrict__ Spart_,
@@ -720,22 +742,26 @@ __global__ __launch_bounds__(256) void k_score_entries(const float* __restrict__
         const int slot = (int)(en >> 16);
         const int col0 = (int)(en & 0xFFFF) * PRUNE_BLOCK;
         const int col = col0 + lane * 4;
-        float a[4];
+        float a[4], bb[4];
 #pragma unroll
-        for (int v = 0; v < 4; v++) a[v] = col + v < Ic ? a_rank_[col + v] : 0.0f;
+        for (int v = 0; v < 4; v++) {
+            a[v] = col + v < Ic ? a_rank_[col + v] : 0.0f;
+            bb[v] = col + v < Ic ? b_rank_[col + v] : 0.0f;
+        }
         const char* __restrict__ Mcol = reinterpret_cast<const char*>(M_) + (int64_t)col * 3;
         const int beg = range_off_[slot - slot_base], end = range_off_[slot - slot_base + 1];
         double t[4] = {0.0, 0.0, 0.0, 0.0};
         unsigned mask = 0;
         for (int kk0 = beg; kk0 < end; kk0 += SB) {
             U3 g[SB];
-            float e[SB];
+            float e[SB], qq[SB];
             int jj[SB];
 #pragma unroll
             for (int x = 0; x < SB; x++) {
                 const int kk = min(kk0 + x, end - 1);
                 jj[x] = csr_idx_[kk];
                 e[x] = csr_e_[kk];
+                qq[x] = csr_q_[kk];
                 g[x] = *reinterpret_cast<const U3*>(Mcol + (int64_t)jj[x] * pitch);
             }
             float p[4] = {0.f, 0.f, 0.f, 0.f};
@@ -745,7 +771,7 @@ __global__ __launch_bounds__(256) void k_score_entries(const float* __restrict__
                     float gv[4];
                     fy_unpack24(g[x], gv);
 #pragma unroll
-                    for (int v = 0; v < 4; v++) p[v] += fy_log2(fmaf(a[v], e[x], gv[v]));
+                    for (int v = 0; v < 4; v++) p[v] += fy_log2(fmaf(qq[x], bb[v], fmaf(a[v], e[x], gv[v])));
                     const unsigned d = (unsigned)(jj[x] * row_mul + row_add - col);
                     if (d < 4u) mask |= 1u << d;
                 }

@@ -15,7 +15,10 @@ import numpy as np
 
 def extra_legs(P, S, ctx, lam, device="cpu"):
     import oracle
-    cores = max(1, os.cpu_count() or 1)
+    try:
+        cores = max(1, min(16, len(os.sched_getaffinity(0))))      # the box's CPU share for one GPU (see bench.py:host_cores)
+    except AttributeError:
+        cores = max(1, min(16, os.cpu_count() or 1))
     out = {}
     # ---- item-sim on a subsample of the ML-25M-shaped users
     rng = np.random.Generator(np.random.PCG64(9))
@@ -75,5 +78,5 @@ def extra_legs(P, S, ctx, lam, device="cpu"):
         "cpu_faithful_1core_recs_per_s": n / t_1, "cpu_faithful_1core_seconds_scaled": t_1,
         "cpu_faithful_1core_note": "one core on the first cluster, scaled by the exact multiply-add count (x%.1f)" % (ref["fma_terms"] / max(1, part["fma_terms"])),
         "cpu_gram_recs_per_s": n / t_gram, "cpu_gram_seconds": t_gram, "cpu_gram_cores": cores,
-        "gpu_over_cpu_faithful": t_all / t_gpu, "gpu_over_cpu_gram": t_gram / t_gpu, "host_nproc": cores}
+        "gpu_over_cpu_faithful": t_all / t_gpu, "gpu_over_cpu_gram": t_gram / t_gpu, "host_nproc": os.cpu_count()}
     return out
