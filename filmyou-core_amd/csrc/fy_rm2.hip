@@ -399,6 +399,11 @@ __global__ void k_cooc_rm2(CoocArgs A, MEpilogue E, int n_items, int* __restrict
     }
     __syncthreads();
     int item = sh_item, s0 = sh_s0, s1 = sh_s1;
+    // Every wave must have read the first item before thread 0 publishes the second one (it does so as soon as ITS share of
+    // the first item is accumulated).  Inside the loop the barrier behind the epilogue separates the two; here nothing did:
+    // with other kernels competing for the CU a delayed wave read the second item as its first -- thousands of wrong matrix
+    // rows per job, only with several job lanes in flight (tools/debug_margin.py found it).
+    __syncthreads();
     SegBatch batch = cooc_first_batch(A, s0, s1);
     while (item < n_items) {     // block-uniform
         int2 se_next = make_int2(0, 0);
