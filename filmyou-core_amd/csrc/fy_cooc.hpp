@@ -49,6 +49,7 @@ struct CoocArgs {
     // optional: [k * nch + ch] = {first, end} segment of chunk ch of the launch's k-th row, precomputed (k_item_segments):
     // one load instead of the rank_pair -> pair_start -> seg_ptr chain in front of every (row, chunk) item
     const int2* __restrict__ item_seg;
+    uint32_t pk_bytes;   // size of csr_pk in bytes (< 4 GiB): record count of the buffer descriptor the packed walk loads through
 };
 
 #ifndef FY_COOC_NB
@@ -136,14 +137,85 @@ __device__ __forceinline__ void cooc_accumulate_segments(const CoocArgs& A, ACC*
         int2 dn = make_int2(0, 0);
         float wn = 0.0f;
         if (sb_next + lane < s_end) { dn = A.seg[sb_next + lane]; wn = A.seg_w[sb_next + lane]; }
+        // Two groups of NB loads are in flight at any time.  The body is STRAIGHT-LINE code (one wave-uniform exit test per
+        // pair of groups, no conditional issue): with `if (has_b) issue(...)` in the loop the compiler's wait-count pass merged
+        // the two paths and waited for ALL outstanding loads (s_waitcnt vmcnt(0)) in front of every group of atomics, i.e. only
+        // NB loads per wave were really in flight (ISA dump, round 2).  Descriptor slots behind `nloc` are empty (length 0,
+        // first entry 0): their loads hit one cached line and their atomics are predicated off.
         Group GA, GB;
         issue(GA, d, w, 0);
-        for (int g = 0; g < nloc; g += 2 * NB) {
-            const bool has_b = g + NB < nloc, has_a2 = g + 2 * NB < nloc;
-            if (has_b) issue(GB, d, w, g + NB);
+#pragma unroll 1
+        for (int g = 0; g < 64; g += 2 * NB) {
+            issue(GB, d, w, g + NB);
             commit(GA);
-            if (has_a2) issue(GA, d, w, g + 2 * NB);
-            if (has_b) commit(GB);
+            if (g + 2 * NB < 64) issue(GA, d, w, g + 2 * NB);      // (compile-time for the last trip of a 64-slot batch only when unrolled; cheap test otherwise)
+            commit(GB);
+            if (g + 2 * NB >= nloc) break;
+        }
+        d = dn;
+        w = wn;
+        sb = sb_next;
+    }
+}
+
+// The packed walk (PK), written for the instruction issue: round 2's counters showed the SIMDs issuing for 16.4 of the
+// kernel's 17.8 ms (SQ_ACTIVE_INST_ANY; 21.8 VALU instructions per 64-entry segment), with the LDS at ~40 % and the memory
+// system at ~60 % of what they sustain -- the walk is bound by instructions per segment, not by bytes, latency or atomics.
+// Per segment now: three v_readlane (first entry, length, weight), ONE buffer_load_dword whose address needs no VALU at all
+// (descriptor in SGPRs, the segment's first entry as scalar offset, lane * 4 as the constant vector offset; lanes behind the
+// segment's end simply load the following entries -- in bounds or zeroed by the descriptor's range check -- and are masked at
+// the atomic), then v_cvt_f32_f16, v_mul_f32 (weight x rating: 24 x 11 significant bits, rounded once to fp32 -- 6e-8
+// relative per contribution, the same error the fp32 weight already carries), v_cvt_f64_f32, the LDS address and the
+// lane < length compare.
+template <class ACC>
+__device__ __forceinline__ void cooc_accumulate_pk(const CoocArgs& A, ACC* __restrict__ acc, int s_begin, int s_end, SegBatch first) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwaves = blockDim.x >> 6;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(A.csr_pk), 0, (int)A.pk_bytes, 0x00020000);
+    const int lane4 = lane * 4;
+    constexpr int NB = FY_COOC_NB;
+    struct Group {
+        int L[NB];
+        float W[NB];
+        uint32_t pk[NB];
+    };
+    auto issue = [&](Group& G, const int2& d, float w, int g) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < NB; q++) {
+            const int F = __builtin_amdgcn_readlane(d.x, g + q);
+            G.L[q] = __builtin_amdgcn_readlane(d.y, g + q);
+            G.W[q] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(w), g + q));
+            G.pk[q] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, lane4, F * 4, 0);
+        }
+    };
+    auto commit = [&](Group& G) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < NB; q++) {
+            const float x = __half2float(__ushort_as_half((unsigned short)(G.pk[q] >> 16)));
+            const ACC v = (ACC)(G.W[q] * x);
+            if (lane < G.L[q]) atomicAdd(&acc[G.pk[q] & 0xFFFFu], v);   // ds_add_f64
+        }
+    };
+    int sb = s_begin + wave * 64;
+    if (sb >= s_end) return;
+    int2 d = first.d;
+    float w = first.w;
+    while (sb < s_end) {   // wave-uniform
+        const int nloc = min(64, s_end - sb);
+        const int sb_next = sb + nwaves * 64;
+        int2 dn = make_int2(0, 0);
+        float wn = 0.0f;
+        if (sb_next + lane < s_end) { dn = A.seg[sb_next + lane]; wn = A.seg_w[sb_next + lane]; }
+        Group GA, GB;      // two groups of NB loads in flight; straight-line body (see cooc_accumulate_segments)
+        issue(GA, d, w, 0);
+#pragma unroll 1
+        for (int g = 0; g < 64; g += 2 * NB) {
+            issue(GB, d, w, g + NB);
+            commit(GA);
+            if (g + 2 * NB < 64) issue(GA, d, w, g + 2 * NB);
+            commit(GB);
+            if (g + 2 * NB >= nloc) break;
         }
         d = dn;
         w = wn;
@@ -178,7 +250,8 @@ __device__ __forceinline__ void cooc_accumulate_row(const CoocArgs& A, int row, 
         s_begin = sp[e0];
         s_end = sp[e1];
     }
-    cooc_accumulate_segments<PK, double>(A, fy_cooc_acc, s_begin, s_end, ch * A.CH, cooc_first_batch(A, s_begin, s_end));
+    if constexpr (PK) cooc_accumulate_pk<double>(A, fy_cooc_acc, s_begin, s_end, cooc_first_batch(A, s_begin, s_end));
+    else cooc_accumulate_segments<false, double>(A, fy_cooc_acc, s_begin, s_end, ch * A.CH, cooc_first_batch(A, s_begin, s_end));
 }
 
 // segment range of every (row, chunk) item of a launch (CoocArgs::item_seg)

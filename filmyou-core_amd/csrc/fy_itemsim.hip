@@ -468,7 +468,7 @@ fy_result* itemsim_build(Context* ctx, const fy_itemsim_params* prm, const fy_ra
         }
         CoocArgs CA{P.rank_pair.get(), P.pair_start.get(), segs.ptr.get(), segs.seg.get(), segs.w.get(), P.csr_idx.get(),
                     csr_w.get(), 0, 0, Ic, CH, nch, prm->rank, rows_mine, 0, (int32_t)P.nnz, nullptr, prm->world,
-                    use_pk ? csr_pk.get() : nullptr, nullptr};
+                    use_pk ? csr_pk.get() : nullptr, nullptr, (uint32_t)std::min<int64_t>((int64_t)P.nnz * 4, 0xFFFFFFFFll)};
         DevBuf<int2> item_seg(ctx, (size_t)rows_mine * nch);
         DevBuf<int32_t> part_cnt(ctx, (size_t)rows_mine * nch);
         part_cnt.zero();

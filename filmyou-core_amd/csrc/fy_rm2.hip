@@ -416,7 +416,8 @@ __global__ void k_cooc_rm2(CoocArgs A, MEpilogue E, int n_items, int* __restrict
         const int mrow = E.local_rows ? lrow : row;
         const int ch = item - lrow * A.nch;
         const int c0 = ch * A.CH;
-        cooc_accumulate_segments<PK, ACC>(A, acc, s0, s1, c0, batch);
+        if constexpr (PK) cooc_accumulate_pk<ACC>(A, acc, s0, s1, batch);
+        else cooc_accumulate_segments<false, ACC>(A, acc, s0, s1, c0, batch);
         // (every thread read sh_* of THIS item before the barrier that ended the previous epilogue)
         if (threadIdx.x == 0) { sh_item = next; sh_s0 = se_next.x; sh_s1 = se_next.y; }
         __syncthreads();     // all atomics of this item are done; the next item is published
@@ -555,7 +556,7 @@ struct ScoreTune {
     int coop = 1;                      // cooperative scoring of clusters that span all ranks (needs fy_collectives)
     int coop_force = 0;                // cooperative path also with world == 1 (identity collectives)
     int cooc_pk = 1;                   // packed 4-byte CSR entries for the row kernel when the ratings are fp16-exact
-    int cooc_f64 = 0;                  // row kernel accumulators in fp64 (round-1 arithmetic; one workgroup per CU)
+    int cooc_f32 = 0;                  // row kernel accumulators in fp32 (ds_add_f32): MEASUREMENT ONLY -- 4x slower, see fy_cooc.hpp
     double max_surv_frac = 0.25;       // a pruned batch whose surviving blocks exceed this fraction falls back to the full pass
 };
 static ScoreTune score_tune() {
@@ -568,7 +569,7 @@ static ScoreTune score_tune() {
     if (const char* e = getenv("FY_COOP")) t.coop = atoi(e) != 0;
     if (const char* e = getenv("FY_COOP_FORCE")) t.coop_force = atoi(e) != 0;
     if (const char* e = getenv("FY_COOC_PK")) t.cooc_pk = atoi(e) != 0;
-    if (const char* e = getenv("FY_COOC_F64")) t.cooc_f64 = atoi(e) != 0;
+    if (const char* e = getenv("FY_COOC_F32")) t.cooc_f32 = atoi(e) != 0;
     if (const char* e = getenv("FY_PRUNE_MIN_ITEMS")) t.prune_min_items = atoi(e);
     if (const char* e = getenv("FY_SEED_CHUNKS")) { int v = atoi(e); if (v >= 0 && v <= 4) { t.seed_chunks = v; t.seed_forced = v > 0; } }
     if (const char* e = getenv("FY_WORKSPACE_GB")) { long v = atol(e); if (v >= 1) t.workspace_default = (int64_t)v << 30; }
@@ -585,13 +586,13 @@ static ScoreTune score_tune() {
 static void launch_cooc_rm2(Context* ctx, const ScoreTune& tune, bool use_pk, const CoocArgs& CA, const MEpilogue& ME, int n_items,
                             int32_t* counter, hipStream_t st) {
     if (n_items <= 0) return;
-    const size_t lds = (size_t)cooc_lds_columns(CA.CH) * (tune.cooc_f64 ? 8 : 4);
+    const size_t lds = (size_t)cooc_lds_columns(CA.CH) * (tune.cooc_f32 ? 4 : 8);
     const int by_lds = (int)std::max<size_t>(1, (160 * 1024 - 512) / (lds + 64));
     int block = tune.cooc_block;
     if (!block) block = by_lds >= 4 ? 256 : (by_lds >= 2 ? 512 : 1024);
     const int per_cu = std::max(1, std::min(by_lds, 2048 / block));
     const int grid = std::min(n_items, ctx->num_cus * per_cu);
-    if (tune.cooc_f64) {
+    if (!tune.cooc_f32) {
         if (use_pk) k_cooc_rm2<true, double><<<grid, block, lds, st>>>(CA, ME, n_items, counter);
         else k_cooc_rm2<false, double><<<grid, block, lds, st>>>(CA, ME, n_items, counter);
     } else {
@@ -971,7 +972,8 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
 
             // -- M build
             CoocArgs CA{P.rank_pair.get(), P.pair_start.get(), segs[pi].ptr.get(), segs[pi].seg.get(), segs[pi].w.get(), P.csr_idx.get(),
-                        csr_x.get(), pbase, sbase, Ic, CH, nch, 0, Ic, p.q0, p.nq, nullptr, 0, use_pk ? csr_pk.get() : nullptr};
+                        csr_x.get(), pbase, sbase, Ic, CH, nch, 0, Ic, p.q0, p.nq, nullptr, 0, use_pk ? csr_pk.get() : nullptr, nullptr,
+                        (uint32_t)std::min<int64_t>((int64_t)P.nnz * 4, 0xFFFFFFFFll)};
             MEpilogue ME{L.M.get(), ldm, (float)((1.0 - lambda) * (1.0 - lambda)), pack24 ? 1 : 0, p.prune ? L.Bmax.get() : nullptr, p.ldb, 0};
             if (p.prune) {
                 FY_HIP(hipMemsetAsync(L.Bmax.get(), 0, (size_t)Ic * p.ldb * 3, ls));

@@ -125,7 +125,8 @@ static void score_cluster_coop(const CoopShared& X, const Plan& p, hipStream_t l
         FY_KERNEL_CHECK();
         if (nrows > 0) {
             CoocArgs CA{P.rank_pair.get(), P.pair_start.get(), seg.ptr.get(), seg.seg.get(), seg.w.get(), P.csr_idx.get(),
-                        X.csr_x, pbase, sbase, Ic, CH, nch, r0, nrows, 0, (int32_t)my_ratings, local_start.get(), W, X.csr_pk};
+                        X.csr_x, pbase, sbase, Ic, CH, nch, r0, nrows, 0, (int32_t)my_ratings, local_start.get(), W, X.csr_pk, nullptr,
+                        (uint32_t)std::min<int64_t>((int64_t)P.nnz * 4, 0xFFFFFFFFll)};
             MEpilogue ME{const_cast<float*>(Mshift), ldm, (float)((1.0 - lambda) * (1.0 - lambda)), 1, const_cast<float*>(Bshift), ldb, 1};
             const size_t sp = X.t_cooc->begin(ls);
             const int n_items = nrows * nch;
