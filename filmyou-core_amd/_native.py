@@ -12,7 +12,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libfilmyou_hip.so")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include", "filmyou.h")
-SOURCES = ["fy_api.hip", "fy_prep.hip", "fy_rm2.hip", "fy_itemsim.hip", "fy_itemcf.hip", "fy_cluster.hip", "fy_nmf.hip", "fy_rccl.hip"]
+SOURCES = ["fy_api.hip", "fy_prep.hip", "fy_rm2.hip", "fy_itemsim.hip", "fy_itemcf.hip", "fy_cluster.hip", "fy_nmf.hip", "fy_rccl.hip", "fy_seqfile.cpp"]
 HEADERS = ["fy_common.hpp", "fy_prep.hpp", "fy_cooc.hpp", "fy_rm2.hpp", "fy_rm2_kernels.hpp", "fy_rm2_coop.hpp"]  # fy_itemcf.hip uses fy_prep.hpp / fy_rm2.hpp
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics", "-Wall",
                "-Wno-unused-result", "-ldl"]
@@ -25,6 +25,8 @@ SYMBOLS = [
     "fy_itemsim_build", "fy_itemsim_run", "fy_itemcf_recommend", "fy_cluster_assign", "fy_nmf_factorize", "fy_result_size", "fy_result_key0", "fy_result_key1", "fy_result_value",
     "fy_result_aux", "fy_result_n_users", "fy_result_user_id", "fy_result_user_sum", "fy_result_n_items",
     "fy_result_item_id", "fy_result_item_coll", "fy_result_total_sum", "fy_result_free", "fy_result_stats",
+    "fy_seqfile_read_int_int", "fy_seqfile_read_int_double", "fy_seqfile_read_intpair_float", "fy_seqfile_write_int_int",
+    "fy_seqfile_write_int_double", "fy_seqfile_write_intpair_float", "fy_mapfile_write_int_double", "fy_buffer_free",
 ]
 
 
@@ -106,7 +108,7 @@ class Stats(C.Structure):
                 ("ms_prepare", C.c_double), ("ms_cooc", C.c_double), ("ms_score", C.c_double),
                 ("ms_topn", C.c_double), ("ms_total", C.c_double), ("score_launches", C.c_int64),
                 ("cooc_launches", C.c_int64), ("blocks_total", C.c_int64), ("blocks_survived", C.c_int64),
-                ("log_terms_evaluated", C.c_int64), ("prune_fallbacks", C.c_int64), ("ms_tables", C.c_double)]
+                ("log_terms_evaluated", C.c_int64), ("prune_fallbacks", C.c_int64), ("ms_tables", C.c_double), ("topn_select_users", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -176,5 +178,15 @@ def load():
     L.fy_result_free.argtypes = [vp]
     L.fy_result_free.restype = None
     L.fy_result_stats.argtypes = [vp, C.POINTER(Stats)]
+    cp, pi64 = C.c_char_p, C.POINTER(i64)
+    L.fy_seqfile_read_int_int.argtypes = [cp, pi64, pvp, pvp]
+    L.fy_seqfile_read_int_double.argtypes = [cp, pi64, pvp, pvp]
+    L.fy_seqfile_read_intpair_float.argtypes = [cp, pi64, pvp, pvp, pvp]
+    L.fy_seqfile_write_int_int.argtypes = [cp, i64, vp, vp]
+    L.fy_seqfile_write_int_double.argtypes = [cp, i64, vp, vp]
+    L.fy_seqfile_write_intpair_float.argtypes = [cp, i64, vp, vp, vp]
+    L.fy_mapfile_write_int_double.argtypes = [cp, i64, vp, vp]
+    L.fy_buffer_free.argtypes = [vp]
+    L.fy_buffer_free.restype = None
     _lib = L
     return L

@@ -602,6 +602,16 @@ static void launch_cooc_rm2(Context* ctx, const ScoreTune& tune, bool use_pk, co
     FY_KERNEL_CHECK();
 }
 
+// user slices (workgroups per column chunk) of a scoring launch over `nb` users and `chunks` column chunks: a wave walks up to
+// users_per_wave users, but a small batch (one cluster of many: 3 250 users at 50 clusters) is cut finer so that the launch
+// still has ~8 workgroups per CU -- with 16 users per wave such a launch had 102 workgroups for 256 CUs (1.4 ms per cluster
+// for work that takes 0.14 ms of the one-cluster job)
+static int score_slices(const Context* ctx, const ScoreTune& tune, int64_t nb, int chunks) {
+    const int64_t coarse = ceil_div(nb, 4 * (int64_t)tune.users_per_wave), finest = ceil_div(nb, 4);
+    const int64_t fill = ceil_div(8 * (int64_t)ctx->num_cus, std::max(1, chunks));
+    return (int)std::max<int64_t>(1, std::min<int64_t>(tune.max_slices, std::min(finest, std::max(coarse, fill))));
+}
+
 // one cluster's launch plan
 struct Plan {
     int c;
@@ -905,7 +915,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 L.item_seg.alloc(ctx, is_el);
             }
         }
-        DevBuf<unsigned long long> prune_counters(ctx, 2);   // [0] surviving blocks, [1] log terms evaluated by the three pruned passes
+        DevBuf<unsigned long long> prune_counters(ctx, 3);   // [0] surviving blocks, [1] log terms evaluated by the three pruned passes, [2] users sent to k_topn_select
         prune_counters.zero();
         int64_t prune_blocks_total = 0, prune_seed_terms_cols = 0, coop_survived = 0, fallback_survived = 0;
         for (auto& p : plans) any_coop = any_coop || p.coop;
@@ -1008,7 +1018,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             };
             // the plain full pass over a range of users: every log term, like the reference's loop (AbstractRM2Reducer.java:332-356)
             auto full_pass = [&](int32_t s0, int32_t nb, float* Sx) {
-                const int n_slices = (int)std::max<int64_t>(1, std::min<int64_t>(tune.max_slices, ceil_div(nb, 4 * tune.users_per_wave)));
+                const int n_slices = score_slices(ctx, tune, nb, n_chunks);
                 ScoreArgs SA = score_args(L.M.get(), ldm, Ic, a_rank.get() + pbase, s0, nb, Sx, ldS, n_slices, n_chunks);
                 const size_t ss = t_score.begin(ls);
                 if (pack24) k_score<4, true, 8><<<n_chunks * n_slices, 256, 0, ls>>>(SA.M, SA.a_rank, SA.rb_off, SA.csr_idx, SA.csr_e, SA.csr_q, SA.pvpi, SA.n_out, SA.S, SA);
@@ -1022,16 +1032,16 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 FY_HIP(hipMemsetAsync(L.any_overflow.get(), 0, sizeof(int32_t), ls));
                 k_topn_fast<<<nb, 256, 0, ls>>>(TA, L.overflow.get(), L.any_overflow.get(), tune.force_select);
                 FY_KERNEL_CHECK();
-                k_topn_select<<<nb, 256, 0, ls>>>(TA, L.overflow.get(), L.any_overflow.get());
+                k_topn_select<<<nb, 256, 0, ls>>>(TA, L.overflow.get(), L.any_overflow.get(), prune_counters.get() + 2);
                 FY_KERNEL_CHECK();
                 t_topn.end(tt, ls);
             };
             for (int32_t s0 = a; s0 < b; s0 += (int32_t)B) {
                 const int32_t nb = (int32_t)std::min<int64_t>(B, b - s0);
                 if (!p.prune) { full_pass(s0, nb, L.S.get()); continue; }
-                const int n_slices = (int)std::max<int64_t>(1, std::min<int64_t>(tune.max_slices, ceil_div(nb, 4 * tune.users_per_wave)));
-                size_t ss = t_score.begin(ls);
                 const int seed_chunks = std::min(n_chunks, tune.seed_chunks);
+                const int n_slices = score_slices(ctx, tune, nb, seed_chunks + (int)(p.ldb / 256));
+                size_t ss = t_score.begin(ls);
                 const int seed_blocks = seed_chunks;
                 const int64_t SC = (int64_t)seed_chunks * 256;   // pitch of the compact score rows: seed columns only
                 // only the seed columns and the surviving blocks of a score row are ever written or read
@@ -1107,7 +1117,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 FY_HIP(hipMemsetAsync(L.any_overflow.get(), 0, sizeof(int32_t), ls));
                 k_topn_fast<<<nb, 256, 0, ls>>>(TA, L.overflow.get(), L.any_overflow.get(), tune.force_select);
                 FY_KERNEL_CHECK();
-                k_topn_select<<<nb, 256, 0, ls>>>(TA, L.overflow.get(), L.any_overflow.get());
+                k_topn_select<<<nb, 256, 0, ls>>>(TA, L.overflow.get(), L.any_overflow.get(), prune_counters.get() + 2);
                 FY_KERNEL_CHECK();
                 t_topn.end(tt, ls);
             }
@@ -1123,9 +1133,10 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
         }
         // (the guard's destructor drains the lanes and the main stream before any buffer of this scope is released)
         {
-            unsigned long long hc[2];
-            d2h(ctx, hc, prune_counters.get(), 2);
+            unsigned long long hc[3];
+            d2h(ctx, hc, prune_counters.get(), 3);
             sync(ctx);
+            R->st.topn_select_users = (int64_t)hc[2];
             R->st.blocks_survived = (int64_t)hc[0] + coop_survived + fallback_survived;
             R->st.blocks_total = prune_blocks_total;
             R->st.log_terms_evaluated = prune_blocks_total ? (int64_t)hc[1] + prune_seed_terms_cols : 0;

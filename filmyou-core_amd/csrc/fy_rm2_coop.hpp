@@ -156,7 +156,7 @@ static void score_cluster_coop(const CoopShared& X, const Plan& p, hipStream_t l
     if (me != 0) FY_HIP(hipMemsetAsync(pv_all.get(), 0, (size_t)Uc * sizeof(double), ls));   // pvpi enters the sum once
 
     size_t ss = X.t_score->begin(ls);   // the spans of ms_score cover this rank's kernels, not the waits inside the collectives
-    auto slices_for = [&](int32_t nb) { return (int)std::max<int64_t>(1, std::min<int64_t>(tune.max_slices, ceil_div(nb, 4 * tune.users_per_wave))); };
+    auto slices_for = [&](int32_t nb) { return score_slices(ctx, tune, nb, seed_chunks + bchunks); };
     // ---- (1) partial seed scores AND partial block bounds of every user in one launch per owner (one grid tail, see
     // rm2_score); (2) two reduce-scatters; (3) tau + the speculative lists; (5) the owner keeps the blocks that reach tau
     for (int k = 0; k < W; k++) {
@@ -244,7 +244,7 @@ static void score_cluster_coop(const CoopShared& X, const Plan& p, hipStream_t l
         FY_HIP(hipMemsetAsync(any_overflow.get(), 0, sizeof(int32_t), ls));
         k_topn_fast<<<n_mine, 256, 0, ls>>>(TA, overflow.get(), any_overflow.get(), tune.force_select);
         FY_KERNEL_CHECK();
-        k_topn_select<<<n_mine, 256, 0, ls>>>(TA, overflow.get(), any_overflow.get());
+        k_topn_select<<<n_mine, 256, 0, ls>>>(TA, overflow.get(), any_overflow.get(), X.prune_counters + 2);
         FY_KERNEL_CHECK();
         X.t_topn->end(tt, ls);
     }

@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256) void k_topn_fast(TopNArgs A, int32_t* __restri
 
 // Fallback: exact radix select (three histogram passes + collect).  Runs only for users k_topn_fast flagged.
 __global__ __launch_bounds__(256) void k_topn_select(TopNArgs A, const int32_t* __restrict__ overflow,
-                                                     const int32_t* __restrict__ any_overflow) {
+                                                     const int32_t* __restrict__ any_overflow, unsigned long long* __restrict__ n_selected = nullptr) {
     __shared__ uint32_t hist[TOPN_BINS];
     __shared__ uint64_t cand[TOPN_MAX];
     __shared__ uint32_t sh_prefix, sh_need, sh_count, sh_eq_taken;
@@ -370,6 +370,7 @@ __global__ __launch_bounds__(256) void k_topn_select(TopNArgs A, const int32_t* 
     if (K == 0) return;
     const float* __restrict__ row = A.S + (int64_t)u * A.ldS;
     const int tid = threadIdx.x;
+    if (tid == 0 && n_selected) atomicAdd(n_selected, 1ull);
     // pruned rows: only the seed columns and the surviving 256-column blocks were ever written
     __shared__ uint32_t live[2048];
     __shared__ uint16_t live_pre[2048];   // cooperative ranks: surviving blocks in front of word w (position in the packed scores)

@@ -393,7 +393,7 @@ int fy_mapfile_write_int_double(const char* dir, int64_t n, const int32_t* key, 
     FY_SEQ_TRY
     for (int64_t i = 1; i < n; i++)
         if (key[i] <= key[i - 1]) throw Fail{"MapFile keys must be strictly ascending (key out of order: " + std::to_string(key[i]) + ")"};
-    mkdirs(std::string(dir) + "/x");
+    mkdirs(dir);
     Writer D(std::string(dir) + "/data", K_INT, K_DOUBLE), I(std::string(dir) + "/index", K_INT, K_LONG);
     for (int64_t i = 0; i < n; i++) {
         std::vector<uint8_t> k, v;

@@ -9,6 +9,7 @@ The reference's Cassandra / HDFS readers and writers stay on the Java side (nort
 the rating triples they produce and returns the rows they consume.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -317,6 +318,49 @@ class RM2Job:
             return prepared.score()
         finally:
             prepared.close()
+
+
+    def run_from_files(self, rank=0, world=1, **kw):
+        """RM2Job.run on the reference's own file layout (M/rm/RM2Job.java:76-100, useCassandraInput/Output = false):
+        ratings         <mapred.input.dir>                     SequenceFile<IntPairWritable(user,item), FloatWritable>
+        clustering      <directory>/<clustering>               SequenceFile<IntWritable, IntWritable>
+        clusteringCount <directory>/<clusteringCount>          SequenceFile<IntWritable, IntWritable>
+        and writes      <directory>/rm2/userSum/part-r-00000   SequenceFile<IntWritable, DoubleWritable>
+                        <directory>/rm2/itemColl/part-r-00000  MapFile<IntWritable, DoubleWritable> (data + index)
+                        <mapred.output.dir>/part-r-00000       SequenceFile<IntPairWritable(user,item), FloatWritable>
+        <directory>/rm2 is wiped first, like HadoopUtils.removeData (RM2Job.java:84).  Returns 0 (the Tool contract); a
+        failure raises RuntimeError("RM2 failed!: ...").  Files: filmyou-core_amd/seqfile.py (layout parity unpinned)."""
+        import shutil
+
+        from . import seqfile
+        conf = self.conf
+        inp, outp = conf.get("mapred.input.dir"), conf.get("mapred.output.dir")
+        base = conf.get("directory", "recommendation")
+        if not inp or not outp:
+            raise ValueError("mapred.input.dir and mapred.output.dir must be set (HadoopUtils.getInputPath / getOutputPath)")
+        try:
+            user, item, score = seqfile.read_intpair_float(inp)
+            cu, cc = seqfile.read_int_int(os.path.join(base, conf.get("clustering", "clustering")))
+            ck, cv = seqfile.read_int_int(os.path.join(base, conf.get("clusteringCount", "clusteringCount")))
+        except seqfile.SeqFileError as e:
+            raise RuntimeError("%s failed!: %s" % (self.JOB_NAME, e)) from e
+        K = conf.getInt("numberOfClusters", -1)
+        count = np.zeros(max(K, 1), dtype=np.int32)
+        ok = (ck >= 0) & (ck < len(count))
+        count[ck[ok]] = cv[ok]
+        rm2 = os.path.join(base, "rm2")
+        shutil.rmtree(rm2, ignore_errors=True)
+        rec = self.run((user, item, score), clustering=(cu, cc), clustering_count=count, rank=rank, world=world, **kw)
+        try:
+            rows, sums = rec.rows(), rec.sums()
+            suffix = "part-r-%05d" % rank
+            seqfile.write_int_double(os.path.join(rm2, "userSum", suffix), sums["user_id"], sums["user_sum"])
+            seqfile.write_mapfile_int_double(os.path.join(rm2, "itemColl", suffix), sums["item_id"], sums["item_coll"])
+            shutil.rmtree(outp, ignore_errors=True)
+            seqfile.write_intpair_float(os.path.join(outp, suffix), rows["user"], rows["item"], rows["score"])
+        finally:
+            rec.close()
+        return 0
 
 
 class PreparedRM2:

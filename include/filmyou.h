@@ -42,7 +42,8 @@ typedef enum {
     FY_ERR_NEGATIVE_ID = -8,     /* user / item ids must be >= 0 */
     FY_ERR_STATE = -9,           /* calls made out of order */
     FY_ERR_UNSUPPORTED = -10,
-    FY_ERR_COLLECTIVE = -11      /* a fy_collectives callback returned non-zero */
+    FY_ERR_COLLECTIVE = -11,     /* a fy_collectives callback returned non-zero */
+    FY_ERR_IO = -12              /* fy_seqfile_* / fy_mapfile_*: missing, truncated, compressed or foreign-typed file */
 } fy_status;
 
 typedef struct fy_context fy_context;
@@ -229,6 +230,7 @@ typedef struct {
     int64_t log_terms_evaluated; /* log terms actually evaluated (seed + bound + survivor passes); 0 = no pruning: log_terms */
     int64_t prune_fallbacks;     /* user batches whose bound did not bite (e.g. lambda = 0) and that were redone with the full pass */
     double ms_tables;            /* RM2: p(i|C), per-rating values, packed CSR, chunk offsets and segment tables (between prepare and the M build) */
+    int64_t topn_select_users;   /* users whose list needed the radix-select fallback of the top-N kernel (more than 2048 candidates reached the lower bound) */
 } fy_stats;
 int fy_result_stats(fy_result*, fy_stats* out);
 
@@ -251,6 +253,22 @@ typedef struct {
                                           reference's unset key, -1, normalises every iteration); 0 = never */
 } fy_nmf_params;
 int fy_nmf_factorize(fy_context*, const fy_nmf_params*, const fy_ratings*, double* H_inout, double* W_inout, fy_stats* stats_or_null);
+
+/* ------------------------------------------------------------------ the Hadoop files on either side of the RM2 job
+ * (csrc/fy_seqfile.cpp).  Hadoop 1.2.1 SequenceFile, version 6, uncompressed record format, as the
+ * reference's jobs and fixture writers produce it (M/util/DataInitialization.java:155-222, M/rm/RM2HDFSReducer.java:44-50,
+ * M/rm/RM2Job.java:110-205).  `path` may be a file, a job output directory (every part file, hidden files skipped) or a
+ * MapFile directory.  Readers return malloc'ed arrays: release them with fy_buffer_free.  Host-only: no GPU is touched.
+ * PARITY UNPINNED at the byte level (the reference holds no binary fixture); IntPairWritable is Mahout 0.8's, restated as two
+ * big-endian int32 -- see the header of csrc/fy_seqfile.cpp. */
+int fy_seqfile_read_int_int(const char* path, int64_t* n, int32_t** key, int32_t** value);           /* clustering, clusteringCount */
+int fy_seqfile_read_int_double(const char* path, int64_t* n, int32_t** key, double** value);         /* rm2/userSum, rm2/itemColl */
+int fy_seqfile_read_intpair_float(const char* path, int64_t* n, int32_t** first, int32_t** second, float** value);   /* ratings, recommendations */
+int fy_seqfile_write_int_int(const char* file, int64_t n, const int32_t* key, const int32_t* value);
+int fy_seqfile_write_int_double(const char* file, int64_t n, const int32_t* key, const double* value);
+int fy_seqfile_write_intpair_float(const char* file, int64_t n, const int32_t* first, const int32_t* second, const float* value);
+int fy_mapfile_write_int_double(const char* dir, int64_t n, const int32_t* key, const double* value);   /* rm2/itemColl: data + index */
+void fy_buffer_free(void*);
 
 #ifdef __cplusplus
 }

@@ -160,3 +160,45 @@ def test_one_call_host_entry_point(rm_golden):
     assert rc == 0, L.fy_last_error()
     assert L.fy_result_size(out) == 507
     P._native.load().fy_result_free(out)
+
+
+def test_job_from_the_references_file_layout(rm_golden, tmp_path):
+    """RM2Job.run as the reference's test drives it (T/rm/TestHDFSRM2.java:39-75): ratings / clustering / clusteringCount
+    written as SequenceFiles the way DataInitialization does, the job run from the Configuration's paths, rm2/userSum,
+    rm2/itemColl and the recommendations read back from the files and compared with the golden vectors (:70-72)."""
+    import importlib
+    P = pkg()
+    sf = importlib.import_module("filmyou-core_amd.seqfile")
+    base = str(tmp_path / "recommendation")
+    user, item, score = rm_golden["coo"]
+    keep = score > 0                                             # createIntPairFloatFile writes only data[i][j] > 0
+    sf.write_intpair_float(str(tmp_path / "input" / "ratings" / "data"), user[keep], item[keep], score[keep])
+    sf.write_int_int(os.path.join(base, "clustering", "data"), rm_golden["map_user"], rm_golden["map_cluster"])
+    cc = rm_golden["cluster_count"]
+    sf.write_int_int(os.path.join(base, "clusteringCount", "data"), np.arange(len(cc), dtype=np.int32), cc)
+    conf = P.Configuration()
+    conf.setFloat("lambda", 0.5)
+    conf.setInt("numberOfItems", rm_golden["numberOfItems"])
+    conf.setInt("numberOfClusters", rm_golden["numberOfClusters"])
+    conf.setInt("numberOfRecommendations", 1000)
+    conf.set("directory", base)
+    conf.set("mapred.input.dir", str(tmp_path / "input" / "ratings"))
+    conf.set("mapred.output.dir", str(tmp_path / "output"))
+    ctx = P.Context(0)
+    os.makedirs(os.path.join(base, "rm2", "stale"))              # RM2Job.run wipes <directory>/rm2 first (RM2Job.java:84)
+    assert P.RM2Job(conf, ctx).run_from_files() == 0
+    assert not os.path.exists(os.path.join(base, "rm2", "stale"))
+    ku, vu = sf.read_int_double(os.path.join(base, "rm2", "userSum"))
+    np.testing.assert_array_equal(ku, np.arange(1, 31))
+    np.testing.assert_array_equal(vu, np.asarray(rm_golden["userSum"]))
+    ki, vi = sf.read_int_double(os.path.join(base, "rm2", "itemColl"))
+    np.testing.assert_array_equal(ki, np.arange(1, 101))
+    np.testing.assert_allclose(vi, np.asarray(rm_golden["itemColl"]), rtol=1e-15)
+    ru, ri, rs = sf.read_intpair_float(str(tmp_path / "output"))
+    exp = np.asarray(rm_golden["recommendations"])
+    assert len(ru) == len(exp) == 507                             # exact row count (HadoopIntegrationTest.java:434-436)
+    got = {(int(a), int(b)): float(c) for a, b, c in zip(ru, ri, rs)}
+    for a, b, c in exp:
+        assert abs(got[(int(a), int(b))] - c) <= 1e-4             # the reference's own tolerance (:53)
+        assert abs(got[(int(a), int(b))] - c) <= 1e-5 * abs(c)
+    ctx.close()
