@@ -50,6 +50,10 @@ struct CoocArgs {
     // one load instead of the rank_pair -> pair_start -> seg_ptr chain in front of every (row, chunk) item
     const int2* __restrict__ item_seg;
     uint32_t pk_bytes;   // size of csr_pk in bytes (< 4 GiB): record count of the buffer descriptor the packed walk loads through
+    // RM2 row kernel: explicit item list, item t = (row of the launch << 8) | chunk, with item_seg[t] its segment range.  In
+    // the symmetric (half) walk a row has items only for its own chunk and the chunks behind it.
+    const int32_t* __restrict__ item_id;
+    int32_t half;        // 1: symmetric walk -- row i holds only the columns j > i, the mirror pass fills the rest
 };
 
 #ifndef FY_COOC_NB
@@ -255,7 +259,7 @@ __device__ __forceinline__ void cooc_accumulate_row(const CoocArgs& A, int row, 
 }
 
 // segment range of every (row, chunk) item of a launch (CoocArgs::item_seg)
-static __global__ void k_item_segments(CoocArgs A, int2* __restrict__ out) {
+__attribute__((unused)) static __global__ void k_item_segments(CoocArgs A, int2* __restrict__ out) {
     const int n = A.nrows * A.nch;
     const int stride = A.row_stride ? A.row_stride : 1;
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
@@ -268,14 +272,49 @@ static __global__ void k_item_segments(CoocArgs A, int2* __restrict__ out) {
     }
 }
 
+// item list of the RM2 row kernel (CoocArgs::item_id / item_seg): rows ascending, inside a row chunks ascending.  Full walk:
+// t = row * nch + ch.  Half walk: the rows of chunk c have nch - c items (chunks c .. nch - 1), so
+// t = sum_{c' < c} rows(c') * (nch - c') + (row - c * CH) * (nch - c) + (ch - c), rows(c') = CH (the last chunk may be short,
+// but nothing follows it).  One thread per (row, chunk) pair; pairs in front of the row's own chunk are skipped.
+__host__ __device__ inline int64_t cooc_half_item_index(int32_t row, int32_t ch, int32_t CH, int32_t nch) {
+    const int64_t c = row / CH;
+    // sum_{c' < c} CH * (nch - c') = CH * (c * nch - c (c - 1) / 2)
+    return (int64_t)CH * (c * nch - c * (c - 1) / 2) + (int64_t)(row - c * CH) * (nch - c) + (ch - c);
+}
+inline int64_t cooc_item_count(int32_t nrows, int32_t CH, int32_t nch, bool half) {
+    if (!half) return (int64_t)nrows * nch;
+    return nrows > 0 ? cooc_half_item_index(nrows - 1, nch - 1, CH, nch) + 1 : 0;
+}
+__attribute__((unused)) static __global__ void k_item_list(CoocArgs A, int2* __restrict__ seg_out, int32_t* __restrict__ id_out) {
+    const int n = A.nrows * A.nch;
+    const int stride = A.row_stride ? A.row_stride : 1;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+        const int lrow = t / A.nch, ch = t % A.nch;
+        const int row = A.row0 + lrow * stride;
+        int64_t at = t;
+        if (A.half) {
+            if (ch < row / A.CH) continue;
+            at = cooc_half_item_index(row, ch, A.CH, A.nch);
+        }
+        const int pair = A.rank_pair[A.pbase + row];
+        int e0 = A.pair_start[pair], e1 = A.pair_start[pair + 1];
+        if (A.local_start) { e0 = A.local_start[lrow]; e1 = A.local_start[lrow + 1]; }
+        const int32_t* __restrict__ sp = A.seg_ptr + (int64_t)ch * (A.nq + 1) - A.q0;
+        seg_out[at] = make_int2(sp[e0], sp[e1]);
+        id_out[at] = (lrow << 8) | ch;
+    }
+}
+
 // segment table of one cluster from its chunk_off table; returns the number of segments (synchronises once)
 struct SegTable {
     DevBuf<int32_t> ptr;   // nch * (nq + 1)
     DevBuf<int2> seg;
     DevBuf<float> w;
 };
+// half_row_of_entry != nullptr: symmetric walk (only the columns behind the entry's own row; fy_rm2.hip, struct Half)
 void build_segments(Context* ctx, const int32_t* csc_slot, const float* csc_w, const int32_t* chunk_off, int32_t slot_base,
-                    int32_t q0, int32_t nq, int32_t nch, SegTable& out, hipStream_t st = nullptr);
+                    int32_t q0, int32_t nq, int32_t nch, SegTable& out, hipStream_t st = nullptr,
+                    const int32_t* half_row_of_entry = nullptr, const int32_t* csr_idx = nullptr, int32_t CH = 0);
 
 // chunk_off table for one cluster: one thread per (slot, boundary)
 void build_chunk_offsets(Context* ctx, const int32_t* rowptr, const int32_t* csr_idx, int32_t slot_base, int32_t n_slots,

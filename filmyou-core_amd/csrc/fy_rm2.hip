@@ -173,6 +173,11 @@ __global__ void k_csc_x(int64_t nnz, const int32_t* __restrict__ csc_slot, const
     }
 }
 
+// row (popularity rank inside its cluster) of every CSC entry: the symmetric walk cuts a rater's slice behind it
+__global__ void k_csc_rank(int64_t nnz, const int32_t* __restrict__ csc_pair, const int32_t* __restrict__ pair_rank, int32_t* __restrict__ out) {
+    for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < nnz; q += (int64_t)gridDim.x * blockDim.x) out[q] = pair_rank[csc_pair[q]];
+}
+
 // packed CSR of one cluster for the row kernel (fy_cooc.hpp): column index relative to its chunk | fp16 raw rating
 __global__ void k_pack_csr(int32_t f0, int32_t f1, int32_t CH, const int32_t* __restrict__ csr_idx, const float* __restrict__ csr_r,
                            uint32_t* __restrict__ pk) {
@@ -265,18 +270,41 @@ void build_chunk_offsets(Context* ctx, const int32_t* rowptr, const int32_t* csr
 }
 
 // ---- segment table (fy_cooc.hpp): counts, exclusive prefix, fill
+// HALF mode (symmetric walk): the co-rating Gram is symmetric, so row i accumulates only the columns j > i and a mirror pass
+// fills the lower triangle (k_mirror_*).  For the CSC entry (rater v, row i) the chunks in front of i's own chunk have no
+// segments, and in i's chunk the rater's slice starts behind the position of i in the rater's CSR row (`Half::start`,
+// found once by a binary search in k_seg_counts and re-used by k_seg_fill).
+struct Half {
+    const int32_t* __restrict__ row_of_entry;   // [q0 + q]: the row (rank inside the cluster) of CSC entry q; nullptr = full walk
+    const int32_t* __restrict__ csr_idx;
+    int32_t CH;
+    int32_t* __restrict__ start;                // [q]: first CSR entry behind (v, i) (scratch, nq entries)
+};
 __global__ void k_seg_counts(const int32_t* __restrict__ csc_slot, const int32_t* __restrict__ chunk_off, int32_t slot_base,
-                             int32_t q0, int32_t nq, int32_t nch, int32_t* __restrict__ cnt) {
+                             int32_t q0, int32_t nq, int32_t nch, int32_t* __restrict__ cnt, Half H) {
     // one thread per CSC entry: the rater's nch + 1 chunk offsets are one contiguous gather
     for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q <= nq; q += (int64_t)gridDim.x * blockDim.x) {
         const bool live = q < nq;
         const int32_t* co = live ? chunk_off + (int64_t)(csc_slot[q0 + q] - slot_base) * (nch + 1) : nullptr;
         int32_t prev = live ? co[0] : 0;
+        int32_t own = -1, behind = 0;
+        if (live && H.row_of_entry) {
+            const int32_t r = H.row_of_entry[q0 + q];
+            own = r / H.CH;
+            int32_t lo = co[own], hi = co[own + 1];          // first entry with idx > r (r itself is in this range)
+            while (lo < hi) {
+                const int32_t mid = (lo + hi) >> 1;
+                if (H.csr_idx[mid] <= r) lo = mid + 1; else hi = mid;
+            }
+            behind = lo;
+            H.start[q] = lo;
+        }
         for (int32_t ch = 0; ch < nch; ch++) {
             int32_t n = 0;
             if (live) {
                 const int32_t next = co[ch + 1];
-                n = (next - prev + 63) >> 6;
+                const int32_t first = ch == own ? behind : prev;
+                n = ch < own ? 0 : (next - first + 63) >> 6;
                 prev = next;
             }
             cnt[(int64_t)ch * (nq + 1) + q] = n;
@@ -290,7 +318,7 @@ __global__ void k_seg_counts(const int32_t* __restrict__ csc_slot, const int32_t
 // coalesced (one thread per entry writing its own run of segments reached 1.1 TB/s).
 __global__ void k_seg_fill(const int32_t* __restrict__ csc_slot, const float* __restrict__ csc_w, const int32_t* __restrict__ chunk_off,
                            int32_t slot_base, int32_t q0, int32_t nq, int32_t nch, const int32_t* __restrict__ ptr,
-                           int2* __restrict__ seg, float* __restrict__ seg_w) {
+                           int2* __restrict__ seg, float* __restrict__ seg_w, Half H) {
     const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
     const int64_t n_groups = ((int64_t)nq + 63) >> 6;
     const int64_t total_work = n_groups * nch;
@@ -305,6 +333,11 @@ __global__ void k_seg_fill(const int32_t* __restrict__ csc_slot, const float* __
             const int32_t* co = chunk_off + (int64_t)(csc_slot[q0 + q] - slot_base) * (nch + 1) + ch;
             f0 = co[0];
             len = co[1] - f0;
+            if (H.row_of_entry) {
+                const int32_t own = H.row_of_entry[q0 + q] / H.CH;
+                if (ch < own) len = 0;
+                else if (ch == own) { f0 = H.start[q]; len = co[1] - f0; }
+            }
             w = csc_w[q0 + q];
             start = pp[q];
         }
@@ -335,12 +368,15 @@ __global__ void k_seg_fill(const int32_t* __restrict__ csc_slot, const float* __
 }
 
 void build_segments(Context* ctx, const int32_t* csc_slot, const float* csc_w, const int32_t* chunk_off, int32_t slot_base,
-                    int32_t q0, int32_t nq, int32_t nch, SegTable& out, hipStream_t st) {
+                    int32_t q0, int32_t nq, int32_t nch, SegTable& out, hipStream_t st, const int32_t* half_row_of_entry,
+                    const int32_t* csr_idx, int32_t CH) {
     if (!st) st = ctx->stream;
     const size_t np = (size_t)nch * ((size_t)nq + 1);
     out.ptr.alloc(ctx, np);
     DevBuf<int32_t> cnt(ctx, np);
-    k_seg_counts<<<grid_for((int64_t)nq + 1), 256, 0, st>>>(csc_slot, chunk_off, slot_base, q0, nq, nch, cnt.get());
+    DevBuf<int32_t> half_start(ctx, half_row_of_entry ? (size_t)nq + 1 : 1);
+    const Half H{half_row_of_entry, csr_idx, CH, half_start.get()};
+    k_seg_counts<<<grid_for((int64_t)nq + 1), 256, 0, st>>>(csc_slot, chunk_off, slot_base, q0, nq, nch, cnt.get(), H);
     FY_KERNEL_CHECK();
     exclusive_scan_i32(ctx, cnt.get(), out.ptr.get(), np, st);
     int32_t total = 0;   // the last count is 0 by construction: the last prefix is the total
@@ -350,9 +386,10 @@ void build_segments(Context* ctx, const int32_t* csc_slot, const float* csc_w, c
     out.w.alloc(ctx, (size_t)total);
     if ((int64_t)nch * nq > 0) {
         k_seg_fill<<<grid_for((((int64_t)nq + 63) >> 6) * nch * 64, 256, 256 * 64), 256, 0, st>>>(csc_slot, csc_w, chunk_off, slot_base, q0, nq, nch, out.ptr.get(),
-                                                                 out.seg.get(), out.w.get());
+                                                                 out.seg.get(), out.w.get(), H);
         FY_KERNEL_CHECK();
     }
+    FY_HIP(hipStreamSynchronize(st));     // half_start is scratch of this call
 }
 
 // ================================================================ G build: co-rating row kernel + RM2 epilogue
@@ -383,7 +420,7 @@ struct MEpilogue {
 template <bool PK, class ACC>
 __global__ void k_cooc_rm2(CoocArgs A, MEpilogue E, int n_items, int* __restrict__ next_item) {
     ACC* __restrict__ acc = reinterpret_cast<ACC*>(fy_cooc_acc);
-    __shared__ int sh_item, sh_s0, sh_s1;
+    __shared__ int sh_item, sh_s0, sh_s1, sh_id;
     const int CHp = cooc_lds_columns(A.CH);   // allocated (and zeroed) columns: the epilogue reads whole 256-column blocks
     for (int t = threadIdx.x; t < CHp; t += blockDim.x) acc[t] = (ACC)0;
     // items are handed out by a global counter: the chunks of a row differ a lot in weight (chunk 0 holds the popular
@@ -396,9 +433,10 @@ __global__ void k_cooc_rm2(CoocArgs A, MEpilogue E, int n_items, int* __restrict
         sh_item = first;
         sh_s0 = se.x;
         sh_s1 = se.y;
+        sh_id = first < n_items ? A.item_id[first] : 0;
     }
     __syncthreads();
-    int item = sh_item, s0 = sh_s0, s1 = sh_s1;
+    int item = sh_item, s0 = sh_s0, s1 = sh_s1, id = sh_id;
     // Every wave must have read the first item before thread 0 publishes the second one (it does so as soon as ITS share of
     // the first item is accumulated).  Inside the loop the barrier behind the epilogue separates the two; here nothing did:
     // with other kernels competing for the CU a delayed wave read the second item as its first -- thousands of wrong matrix
@@ -407,30 +445,36 @@ __global__ void k_cooc_rm2(CoocArgs A, MEpilogue E, int n_items, int* __restrict
     SegBatch batch = cooc_first_batch(A, s0, s1);
     while (item < n_items) {     // block-uniform
         int2 se_next = make_int2(0, 0);
+        int id_next = 0;
         if (threadIdx.x == 0) {
             next2 = atomicAdd(next_item, 1);                         // arrives during this item's work
-            if (next < n_items) se_next = A.item_seg[next];          // address known since the previous item
+            if (next < n_items) { se_next = A.item_seg[next]; id_next = A.item_id[next]; }   // address known since the previous item
         }
-        const int lrow = item / A.nch;
+        const int lrow = id >> 8;
         const int row = A.row0 + lrow * (A.row_stride ? A.row_stride : 1);
         const int mrow = E.local_rows ? lrow : row;
-        const int ch = item - lrow * A.nch;
+        const int ch = id & 255;
         const int c0 = ch * A.CH;
         if constexpr (PK) cooc_accumulate_pk<ACC>(A, acc, s0, s1, batch);
         else cooc_accumulate_segments<false, ACC>(A, acc, s0, s1, c0, batch);
         // (every thread read sh_* of THIS item before the barrier that ended the previous epilogue)
-        if (threadIdx.x == 0) { sh_item = next; sh_s0 = se_next.x; sh_s1 = se_next.y; }
+        if (threadIdx.x == 0) { sh_item = next; sh_s0 = se_next.x; sh_s1 = se_next.y; sh_id = id_next; }
         __syncthreads();     // all atomics of this item are done; the next item is published
         const int nitem = sh_item;
         s0 = sh_s0;
         s1 = sh_s1;
+        const int nid = sh_id;
         batch = cooc_first_batch(A, s0, s1);     // in flight during the epilogue
         // the last chunk also writes the padding columns [Ic, ldm) so the scoring kernel may load whole 256-wide chunks
         const int c1 = (ch == A.nch - 1) ? (int)E.ldm : min(c0 + A.CH, (int)E.ldm);
+        // symmetric walk: in the row's own chunk nothing in front of its 256-column diagonal block was accumulated (and the
+        // mirror pass writes that part of the row); the block maxima of the diagonal block are the mirror pass's too
+        const int cb = (A.half && c0 <= row) ? (row & ~255) : c0;
+        const int first_bmax_block = A.half ? (row >> 8) + 1 : 0;
         if (E.pack24) {
             // four columns -> three dwords (c0 and c1 are multiples of 64)
             uint32_t* __restrict__ out3 = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(E.M) + (int64_t)mrow * E.ldm * 3);
-            for (int c4 = (c0 >> 2) + threadIdx.x; 4 * c4 < c1; c4 += blockDim.x) {
+            for (int c4 = (cb >> 2) + threadIdx.x; 4 * c4 < c1; c4 += blockDim.x) {
                 uint32_t v[4];
                 ACC* ap = acc + (4 * c4 - c0);
 #pragma unroll
@@ -448,7 +492,7 @@ __global__ void k_cooc_rm2(CoocArgs A, MEpilogue E, int n_items, int* __restrict
                     uint32_t m = max(max(v[0], v[1]), max(v[2], v[3]));     // non-negative floats order like their bit patterns
 #pragma unroll
                     for (int o = 1; o < 64; o <<= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
-                    if ((threadIdx.x & 63) == 0 && m) {
+                    if ((threadIdx.x & 63) == 0 && m && (c4 >> 6) >= first_bmax_block) {
                         // the maximum of 24-bit values is itself one: Bmax is stored in the same packed format (3 bytes per
                         // block, byte stores: the four blocks of a packed group belong to different waves or chunks), so
                         // the bound pass streams 768 instead of 1024 bytes per rated item.  (Zero maxima are not stored:
@@ -462,15 +506,136 @@ __global__ void k_cooc_rm2(CoocArgs A, MEpilogue E, int n_items, int* __restrict
             }
         } else {
             float* __restrict__ out = E.M + (int64_t)mrow * E.ldm;
-            for (int col = c0 + threadIdx.x; col < c1; col += blockDim.x) {
+            for (int col = cb + threadIdx.x; col < c1; col += blockDim.x) {
                 out[col] = E.w2 * (float)acc[col - c0];
                 acc[col - c0] = (ACC)0;
             }
         }
         item = nitem;
+        id = nid;
         if (threadIdx.x == 0) next = next2;
         __syncthreads();   // the accumulators are clean again before the next item's atomics
     }
+}
+
+// ================================================================ mirror pass of the symmetric (half) walk
+// After k_cooc_rm2 with CoocArgs::half, row i of the packed matrix holds the columns j >= 256 * (i / 256) (exact for j > i,
+// zero elsewhere in the diagonal block) and Bmax holds the blocks behind the diagonal block.  G is symmetric, so the rest is
+// a transposition: 24-bit elements, 256 x 128 source tiles through LDS (k_mirror_tiles: reads 256 row segments of 384 B,
+// writes 128 row segments of 768 B -- one whole 256-column block of the destination rows, whose maximum is the missing
+// Bmax entry), and the 256 x 256 diagonal blocks thread by thread (k_mirror_diag: 1 / 231 of the matrix).
+__device__ __forceinline__ void fy_unpack24_raw(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t* v) {
+    v[0] = d0 & 0xFFFFFFu;
+    v[1] = (d0 >> 24) | ((d1 & 0xFFFFu) << 8);
+    v[2] = (d1 >> 16) | ((d2 & 0xFFu) << 16);
+    v[3] = d2 >> 8;
+}
+__device__ __forceinline__ uint32_t fy_load24(const uint32_t* __restrict__ row3, int e) {   // element e of a packed row
+    const int g = e >> 2;
+    uint32_t v[4];
+    fy_unpack24_raw(row3[3 * g], row3[3 * g + 1], row3[3 * g + 2], v);
+    return v[e & 3];
+}
+constexpr int MIRROR_PITCH = 772;    // bytes per LDS row: 768 + 4 (an odd number of dwords spreads the rows over the banks)
+
+__global__ __launch_bounds__(1024) void k_mirror_tiles(float* __restrict__ M_, int64_t ldm, int32_t Ic, float* __restrict__ Bmax_, int64_t ldb) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char fy_mirror_lds[];   // [128][MIRROR_PITCH]: the destination rows, packed
+    __shared__ uint32_t rowmax[128];
+    const int tj = blockIdx.x, B = blockIdx.y;
+    if (tj < 2 * (B + 1)) return;                         // only tiles strictly behind the diagonal block are sources
+    const int dst_row0 = 128 * tj;
+    if (dst_row0 >= Ic) return;                           // destination rows are real rows (the padding columns have none)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int64_t pitch = ldm * 3;
+    unsigned char* __restrict__ Mb = reinterpret_cast<unsigned char*>(M_);
+    if (threadIdx.x < 128) rowmax[threadIdx.x] = 0;
+    __syncthreads();
+    // ---- load: a wave takes two source rows per step (32 lanes x 12 bytes = 128 elements each)
+    const int m = lane & 31, h = lane >> 5;
+    uint32_t mx[4] = {0, 0, 0, 0};
+    for (int r = 2 * wave + h; r < 256; r += 2 * nwaves) {
+        const int src_row = 256 * B + r;
+        uint32_t v[4] = {0, 0, 0, 0};
+        if (src_row < Ic) {
+            const uint32_t* __restrict__ p = reinterpret_cast<const uint32_t*>(Mb + (int64_t)src_row * pitch + (int64_t)dst_row0 * 3) + 3 * m;
+            fy_unpack24_raw(p[0], p[1], p[2], v);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            unsigned char* d = fy_mirror_lds + (4 * m + q) * MIRROR_PITCH + 3 * r;    // destination row 4m + q, element r
+            d[0] = (unsigned char)v[q];
+            d[1] = (unsigned char)(v[q] >> 8);
+            d[2] = (unsigned char)(v[q] >> 16);
+            mx[q] = max(mx[q], v[q]);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        if (mx[q]) atomicMax(&rowmax[4 * m + q], mx[q]);
+    __syncthreads();
+    // ---- store: one destination row (768 bytes = one 256-column block) per wave step
+    for (int c = wave; c < 128; c += nwaves) {
+        const int dst_row = dst_row0 + c;
+        if (dst_row >= Ic) break;
+        const uint32_t* __restrict__ sp = reinterpret_cast<const uint32_t*>(fy_mirror_lds + c * MIRROR_PITCH) + 3 * lane;
+        uint32_t* __restrict__ dp = reinterpret_cast<uint32_t*>(Mb + (int64_t)dst_row * pitch + (int64_t)256 * B * 3) + 3 * lane;
+        dp[0] = sp[0];
+        dp[1] = sp[1];
+        dp[2] = sp[2];
+    }
+    if (Bmax_ && threadIdx.x < 128 && dst_row0 + (int)threadIdx.x < Ic) {
+        const uint32_t pv = rowmax[threadIdx.x];
+        uint8_t* bp = reinterpret_cast<uint8_t*>(Bmax_) + ((int64_t)(dst_row0 + threadIdx.x) * ldb + B) * 3;
+        bp[0] = (uint8_t)pv;
+        bp[1] = (uint8_t)(pv >> 8);
+        bp[2] = (uint8_t)(pv >> 16);
+    }
+}
+
+// diagonal blocks: thread c owns row 256 B + c; element (c, r) for r < c is element (r, c) of a row above (a 3-byte gather),
+// the rest of the row's segment is its own; the maximum over the completed segment is Bmax[row][B]
+__global__ __launch_bounds__(256) void k_mirror_diag(float* __restrict__ M_, int64_t ldm, int32_t Ic, float* __restrict__ Bmax_, int64_t ldb) {
+    const int B = blockIdx.x, c = threadIdx.x;
+    const int row = 256 * B + c;
+    if (row >= Ic) return;
+    const int64_t pitch = ldm * 3;
+    unsigned char* __restrict__ Mb = reinterpret_cast<unsigned char*>(M_);
+    uint32_t* __restrict__ own = reinterpret_cast<uint32_t*>(Mb + (int64_t)row * pitch + (int64_t)256 * B * 3);
+    uint32_t best = 0;
+    for (int g = 0; g < 64; g++) {
+        uint32_t v[4];
+        if (4 * g >= c) {                                  // untouched part of the own row (columns >= c)
+            fy_unpack24_raw(own[3 * g], own[3 * g + 1], own[3 * g + 2], v);
+        } else {
+            if (4 * g + 3 >= c) fy_unpack24_raw(own[3 * g], own[3 * g + 1], own[3 * g + 2], v);   // the group that straddles the diagonal
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int r = 4 * g + q;
+                if (r < c) v[q] = fy_load24(reinterpret_cast<const uint32_t*>(Mb + (int64_t)(256 * B + r) * pitch + (int64_t)256 * B * 3), c);
+            }
+            own[3 * g + 0] = v[0] | (v[1] << 24);
+            own[3 * g + 1] = (v[1] >> 8) | (v[2] << 16);
+            own[3 * g + 2] = (v[2] >> 16) | (v[3] << 8);
+        }
+        best = max(max(best, max(v[0], v[1])), max(v[2], v[3]));
+    }
+    if (Bmax_) {
+        uint8_t* bp = reinterpret_cast<uint8_t*>(Bmax_) + ((int64_t)row * ldb + B) * 3;
+        bp[0] = (uint8_t)best;
+        bp[1] = (uint8_t)(best >> 8);
+        bp[2] = (uint8_t)(best >> 16);
+    }
+}
+
+static void launch_mirror(Context* ctx, float* M, int64_t ldm, int32_t Ic, float* Bmax, int64_t ldb, hipStream_t st) {
+    const int nblk = (int)(ldm / 256), ntile = (int)(ldm / 128);
+    if (nblk > 1) {
+        FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mirror_tiles), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * MIRROR_PITCH));
+        k_mirror_tiles<<<dim3(ntile, nblk - 1), 1024, 128 * MIRROR_PITCH, st>>>(M, ldm, Ic, Bmax, ldb);
+        FY_KERNEL_CHECK();
+    }
+    k_mirror_diag<<<nblk, 256, 0, st>>>(M, ldm, Ic, Bmax, ldb);
+    FY_KERNEL_CHECK();
 }
 
 static void cooc_rm2_allow_lds() {
@@ -557,6 +722,7 @@ struct ScoreTune {
     int coop_force = 0;                // cooperative path also with world == 1 (identity collectives)
     int cooc_pk = 1;                   // packed 4-byte CSR entries for the row kernel when the ratings are fp16-exact
     int cooc_f32 = 0;                  // row kernel accumulators in fp32 (ds_add_f32): MEASUREMENT ONLY -- 4x slower, see fy_cooc.hpp
+    int cooc_half = 1;                 // symmetric walk (upper triangle + mirror pass) for clusters with packed rows
     double max_surv_frac = 0.25;       // a pruned batch whose surviving blocks exceed this fraction falls back to the full pass
 };
 static ScoreTune score_tune() {
@@ -570,6 +736,7 @@ static ScoreTune score_tune() {
     if (const char* e = getenv("FY_COOP_FORCE")) t.coop_force = atoi(e) != 0;
     if (const char* e = getenv("FY_COOC_PK")) t.cooc_pk = atoi(e) != 0;
     if (const char* e = getenv("FY_COOC_F32")) t.cooc_f32 = atoi(e) != 0;
+    if (const char* e = getenv("FY_COOC_HALF")) t.cooc_half = atoi(e) != 0;
     if (const char* e = getenv("FY_PRUNE_MIN_ITEMS")) t.prune_min_items = atoi(e);
     if (const char* e = getenv("FY_SEED_CHUNKS")) { int v = atoi(e); if (v >= 0 && v <= 4) { t.seed_chunks = v; t.seed_forced = v > 0; } }
     if (const char* e = getenv("FY_WORKSPACE_GB")) { long v = atol(e); if (v >= 1) t.workspace_default = (int64_t)v << 30; }
@@ -617,7 +784,7 @@ struct Plan {
     int c;
     int32_t Uc, sbase, pbase, Ic, a, b, CH, nch, q0, nq;
     int64_t ldm, B;
-    bool pack24, prune, coop;
+    bool pack24, prune, coop, half;
     int32_t nblk;
     int64_t ldb;
 };
@@ -712,7 +879,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
     R->st.n_users = P.nU;
     R->st.n_items = P.nI;
     R->st.ms_prepare = J->ms_prepare;
-    EventTimer t_total(ctx), t_cooc(ctx), t_score(ctx), t_topn(ctx), t_tables(ctx);
+    EventTimer t_total(ctx), t_cooc(ctx), t_score(ctx), t_topn(ctx), t_tables(ctx), t_mirror(ctx);
     const size_t span_total = t_total.begin();
     size_t span_tables = t_tables.begin();
     if (P.nnz == 0) {
@@ -855,6 +1022,9 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                     if (std::max(lo_k, p.sbase) >= std::min(hi_k, p.sbase + p.Uc)) p.coop = false;
                 }
             }
+            // symmetric walk: packed rows only (small clusters keep exact fp32 rows and the plain walk); a cooperative rank
+            // owns whole rows of the matrix, so it walks them whole
+            p.half = tune.cooc_half && p.pack24 && !p.coop && p.nch < 256;
             plans.push_back(p);
         }
         const int NS = (int)std::min<size_t>(plans.size() > 1 ? (size_t)tune.lanes : 1, plans.size());
@@ -867,6 +1037,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             DevBuf<uint16_t> surv;
             DevBuf<int32_t> n_quads, quad_prefix;
             DevBuf<int2> item_seg;
+            DevBuf<int32_t> item_id;
             DevBuf<float> Ssurv;   // packed scores of the surviving blocks (pruned clusters)
         };
         std::vector<Lane> lanes((size_t)NS);
@@ -913,6 +1084,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 L.n_quads.alloc(ctx, ov_el + 1);
                 L.quad_prefix.alloc(ctx, ov_el + 1);
                 L.item_seg.alloc(ctx, is_el);
+                L.item_id.alloc(ctx, is_el);
             }
         }
         DevBuf<unsigned long long> prune_counters(ctx, 3);   // [0] surviving blocks, [1] log terms evaluated by the three pruned passes, [2] users sent to k_topn_select
@@ -924,8 +1096,14 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
         span_tables = t_tables.begin();
         {
             size_t co_all = 1;
-            for (auto& p : plans) co_all = std::max(co_all, (size_t)p.Uc * (p.nch + 1));
+            bool any_half = false;
+            for (auto& p : plans) { co_all = std::max(co_all, (size_t)p.Uc * (p.nch + 1)); any_half = any_half || p.half; }
             DevBuf<int32_t> co_tmp(ctx, co_all);
+            DevBuf<int32_t> csc_rank(ctx, any_half ? (size_t)P.nnz : 1);     // row (rank inside its cluster) of every CSC entry
+            if (any_half) {
+                k_csc_rank<<<grid_for(P.nnz), 256, 0, st>>>(P.nnz, P.csc_pair.get(), P.pair_rank.get(), csc_rank.get());
+                FY_KERNEL_CHECK();
+            }
             for (size_t pi = 0; pi < plans.size(); pi++) {
                 const Plan& p = plans[pi];
                 if (use_pk) {   // the cluster's CSR range (slots are cluster-major), chunk-relative indices for its CH
@@ -940,7 +1118,8 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 }
                 if (p.coop) continue;
                 build_chunk_offsets(ctx, P.rowptr.get(), P.csr_idx.get(), p.sbase, p.Uc, p.CH, p.nch, co_tmp.get());
-                build_segments(ctx, P.csc_slot.get(), use_pk ? csc_x_over_s.get() : csc_x.get(), co_tmp.get(), p.sbase, p.q0, p.nq, p.nch, segs[pi]);
+                build_segments(ctx, P.csc_slot.get(), use_pk ? csc_x_over_s.get() : csc_x.get(), co_tmp.get(), p.sbase, p.q0, p.nq, p.nch, segs[pi], nullptr,
+                               p.half ? csc_rank.get() : nullptr, P.csr_idx.get(), p.CH);
             }
         }
         t_tables.end(span_tables);
@@ -992,16 +1171,22 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             }
             const size_t sp = t_cooc.begin(ls);
             {
-                const int n_items = Ic * nch;
-                k_item_segments<<<grid_for(n_items), 256, 0, ls>>>(CA, L.item_seg.get());
+                CA.half = p.half ? 1 : 0;
+                const int n_items = (int)cooc_item_count(Ic, CH, nch, p.half);
+                k_item_list<<<grid_for((int64_t)Ic * nch), 256, 0, ls>>>(CA, L.item_seg.get(), L.item_id.get());
                 FY_KERNEL_CHECK();
                 CA.item_seg = L.item_seg.get();
+                CA.item_id = L.item_id.get();
                 FY_HIP(hipMemsetAsync(L.any_overflow.get(), 0, sizeof(int32_t), ls));   // reused as the item counter
                 launch_cooc_rm2(ctx, tune, use_pk, CA, ME, n_items, L.any_overflow.get(), ls);
             }
-            FY_KERNEL_CHECK();
             t_cooc.end(sp, ls);
             R->st.cooc_launches++;
+            if (p.half) {    // lower triangle + the block maxima in front of / on the diagonal
+                const size_t sm = t_mirror.begin(ls);
+                launch_mirror(ctx, L.M.get(), ldm, Ic, p.prune ? L.Bmax.get() : nullptr, p.ldb, ls);
+                t_mirror.end(sm, ls);
+            }
 
             // -- scoring + top-N in user batches that fit the score scratch
             const int64_t ldS = ldm, B = p.B;
@@ -1159,6 +1344,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
     R->st.ms_topn = t_topn.total_ms();
     R->st.ms_total = t_total.total_ms();
     R->st.ms_tables = t_tables.total_ms();
+    R->st.ms_mirror = t_mirror.total_ms();
     return R.release();
 }
 

@@ -108,6 +108,7 @@ static void score_cluster_coop(const CoopShared& X, const Plan& p, hipStream_t l
         DevBuf<int32_t> co_tmp(ctx, (size_t)Uc * (nch + 1));
         SegTable seg;
         DevBuf<int2> item_seg(ctx, (size_t)std::max<int64_t>(1, (int64_t)nrows * nch));
+        DevBuf<int32_t> item_id(ctx, (size_t)std::max<int64_t>(1, (int64_t)nrows * nch));
         build_chunk_offsets(ctx, P.rowptr.get(), P.csr_idx.get(), sbase, Uc, CH, nch, co_tmp.get(), ls);
         std::vector<int32_t> hls((size_t)nrows + 1, 0);
         for (int32_t i = 0; i < nrows; i++) hls[i + 1] = hls[i] + hcnt[r0 + (int64_t)i * W];
@@ -130,9 +131,10 @@ static void score_cluster_coop(const CoopShared& X, const Plan& p, hipStream_t l
             MEpilogue ME{const_cast<float*>(Mshift), ldm, (float)((1.0 - lambda) * (1.0 - lambda)), 1, const_cast<float*>(Bshift), ldb, 1};
             const size_t sp = X.t_cooc->begin(ls);
             const int n_items = nrows * nch;
-            k_item_segments<<<grid_for(n_items), 256, 0, ls>>>(CA, item_seg.get());
+            k_item_list<<<grid_for(n_items), 256, 0, ls>>>(CA, item_seg.get(), item_id.get());
             FY_KERNEL_CHECK();
             CA.item_seg = item_seg.get();
+            CA.item_id = item_id.get();
             FY_HIP(hipMemsetAsync(item_counter.get(), 0, sizeof(int32_t), ls));
             launch_cooc_rm2(ctx, tune, X.csr_pk != nullptr, CA, ME, n_items, item_counter.get(), ls);
             X.t_cooc->end(sp, ls);

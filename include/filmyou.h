@@ -230,6 +230,7 @@ typedef struct {
     int64_t log_terms_evaluated; /* log terms actually evaluated (seed + bound + survivor passes); 0 = no pruning: log_terms */
     int64_t prune_fallbacks;     /* user batches whose bound did not bite (e.g. lambda = 0) and that were redone with the full pass */
     double ms_tables;            /* RM2: p(i|C), per-rating values, packed CSR, chunk offsets and segment tables (between prepare and the M build) */
+    double ms_mirror;            /* RM2: mirror pass of the symmetric walk (lower triangle of the co-rating matrix + its block maxima) */
     int64_t topn_select_users;   /* users whose list needed the radix-select fallback of the top-N kernel (more than 2048 candidates reached the lower bound) */
 } fy_stats;
 int fy_result_stats(fy_result*, fy_stats* out);

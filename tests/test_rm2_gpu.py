@@ -4,6 +4,8 @@ Reads like the reference's src/test/java/.../rm/TestHDFSRM2.java: build a Config
 fixture, compare userSum, itemColl and the recommendations -- with the reference's 1e-4 absolute bound AND the
 1e-5 relative bound of north_star.
 """
+import os
+
 import numpy as np
 import pytest
 
