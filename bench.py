@@ -254,6 +254,11 @@ def main():
                 "algorithmic_bytes_per_launch": 8.0 * unordered_pairs / max(1, st["cooc_launches"]),
                 "share_of_step": ms_cooc / ms_per_step if ms_per_step > 0 else None}
     roofline["frac"] = roofline["achieved"] / HBM_PEAK_GBS
+    # the symmetric walk leaves the lower triangle to the mirror pass (k_mirror_tiles / k_mirror_diag): the matrix build as a whole
+    ms_mirror = mean("ms_mirror")
+    roofline["with_mirror_pass"] = {"ms": ms_cooc + ms_mirror, "achieved": 8.0 * unordered_pairs / ((ms_cooc + ms_mirror) * 1e-3) / 1e9 if ms_cooc > 0 else 0.0,
+                                    "frac": 8.0 * unordered_pairs / ((ms_cooc + ms_mirror) * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_cooc > 0 else 0.0,
+                                    "traffic": (traffic.get("k_cooc_rm2", {}).get("hbm_bytes_per_launch") or 0) + (traffic.get("k_mirror", {}).get("hbm_bytes_per_launch") or 0) or None}
     # The scoring family is NOT priced against HBM: the branch and bound evaluates ~1.4 % of the reference's log terms and
     # the column panels it reads (seed columns, block maxima) live in L2 / Infinity Cache, so an HBM fraction means nothing
     # there (round 1 printed 1.09).  Its bound is the L2: 4 B per EVALUATED log term against the aggregate L2 bandwidth.
