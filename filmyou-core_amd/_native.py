@@ -93,7 +93,7 @@ class NMFParams(C.Structure):
 class ItemSimParams(C.Structure):
     _fields_ = [("similarity", C.c_int32), ("max_similarities_per_item", C.c_int32), ("exclude_self", C.c_int32),
                 ("has_threshold", C.c_int32), ("threshold", C.c_double), ("rank", C.c_int32), ("world", C.c_int32),
-                ("flags", C.c_uint32)]
+                ("flags", C.c_uint32), ("min_prefs_per_user", C.c_int32), ("max_prefs_per_user", C.c_int32)]
 
 
 class ItemCFParams(C.Structure):

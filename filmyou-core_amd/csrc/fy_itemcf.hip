@@ -165,8 +165,14 @@ __global__ void k_icf_finalize(int32_t n_users, int32_t n_cols, int64_t ld, cons
         if (i < n_cols) {
             const int64_t o = (int64_t)u * ld + i;
             const int32_t c = cnt[o];
-            if (boolean_data) { if (c > 0) v = (float)num[o]; }
-            else if (c > 1) v = (float)(num[o] / den[o]);
+            // The reducer walks numerators.nonZeroes() and recommendationVector.nonZeroes()
+            // (BaselineAggregateAndRecommendReducer.java:148, 195): a cell whose numerator is exactly 0 (similarities of both
+            // signs that cancel, or 0-valued preferences) never reaches the top-N queue.
+            const double nm = num[o];
+            if (nm != 0.0) {
+                if (boolean_data) { if (c > 0) v = (float)nm; }
+                else if (c > 1) v = (float)(nm / den[o]);
+            }
         }
         S[(int64_t)u * ld + i] = v;
         valid += (v == v);

@@ -398,7 +398,83 @@ __global__ void k_isim_compact(int32_t rows_mine, int32_t K, int32_t rank, int32
     }
 }
 
-fy_result* itemsim_build(Context* ctx, const fy_itemsim_params* prm, const fy_ratings* R) {
+// ---- input preparation: minPrefsPerUser / maxPrefsPerUser (BaselinePreparePreferenceMatrixJob.java:104, 126-129; filmyou.h)
+__global__ void k_pref_keys(int64_t n, const int32_t* __restrict__ user, const int32_t* __restrict__ item, uint64_t* __restrict__ key, uint32_t* __restrict__ val) {
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        key[t] = ((uint64_t)(uint32_t)user[t] << 32) | (uint32_t)item[t];
+        val[t] = (uint32_t)t;
+    }
+}
+__global__ void k_pref_heads(int64_t n, const uint64_t* __restrict__ key, uint32_t* __restrict__ head) {
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x)
+        head[p] = (p == 0 || (key[p] >> 32) != (key[p - 1] >> 32)) ? 1u : 0u;
+}
+__global__ void k_pref_head_pos(int64_t n, const uint32_t* __restrict__ head, const uint32_t* __restrict__ useq, uint32_t* __restrict__ head_pos) {
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p <= n; p += (int64_t)gridDim.x * blockDim.x) {
+        if (p == n) head_pos[useq[n - 1]] = (uint32_t)n;          // sentinel behind the last user
+        else if (head[p]) head_pos[useq[p] - 1] = (uint32_t)p;
+    }
+}
+__global__ void k_pref_keep(int64_t n, const uint32_t* __restrict__ useq, const uint32_t* __restrict__ head_pos, int32_t min_prefs, int32_t max_prefs,
+                            uint32_t* __restrict__ keep) {
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t u = useq[p] - 1;
+        const int64_t first = head_pos[u], deg = (int64_t)head_pos[u + 1] - first, k = p - first;
+        bool ok = deg >= min_prefs;
+        if (ok && max_prefs > 0 && deg > max_prefs) ok = ((k + 1) * max_prefs) / deg > (k * max_prefs) / deg;
+        keep[p] = ok ? 1u : 0u;
+    }
+}
+__global__ void k_pref_emit(int64_t n, const uint32_t* __restrict__ keep, const uint32_t* __restrict__ off, const uint32_t* __restrict__ src,
+                            const int32_t* __restrict__ user, const int32_t* __restrict__ item, const float* __restrict__ score,
+                            int32_t* __restrict__ ou, int32_t* __restrict__ oi, float* __restrict__ os) {
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+        if (!keep[p]) continue;
+        const uint32_t t = src[p], o = off[p] - 1;
+        ou[o] = user[t];
+        oi[o] = item[t];
+        os[o] = score[t];
+    }
+}
+// a filtered copy of the ratings, or nullptr when neither option changes anything
+static std::unique_ptr<fy_ratings> filter_user_prefs(Context* ctx, const fy_ratings* R, int32_t min_prefs, int32_t max_prefs) {
+    if ((min_prefs <= 1 && max_prefs <= 0) || R->nnz == 0) return nullptr;
+    if (R->nnz >= ((int64_t)1 << 32)) FY_FAIL(FY_ERR_UNSUPPORTED, "minPrefsPerUser / maxPrefsPerUser with more than 2^32 ratings");
+    hipStream_t st = ctx->stream;
+    const int64_t n = R->nnz;
+    DevBuf<uint64_t> ka(ctx, n), kb(ctx, n);
+    DevBuf<uint32_t> va(ctx, n), vb(ctx, n), head(ctx, n), useq(ctx, n), keep(ctx, n), off(ctx, n), head_pos(ctx, (size_t)n + 1);
+    k_pref_keys<<<grid_for(n), 256, 0, st>>>(n, R->user.get(), R->item.get(), ka.get(), va.get());
+    FY_KERNEL_CHECK();
+    sort_pairs_u64_u32(ctx, ka.get(), kb.get(), va.get(), vb.get(), (size_t)n);
+    k_pref_heads<<<grid_for(n), 256, 0, st>>>(n, kb.get(), head.get());
+    FY_KERNEL_CHECK();
+    inclusive_scan_u32(ctx, head.get(), useq.get(), (size_t)n);
+    k_pref_head_pos<<<grid_for(n + 1), 256, 0, st>>>(n, head.get(), useq.get(), head_pos.get());
+    FY_KERNEL_CHECK();
+    k_pref_keep<<<grid_for(n), 256, 0, st>>>(n, useq.get(), head_pos.get(), min_prefs, max_prefs, keep.get());
+    FY_KERNEL_CHECK();
+    inclusive_scan_u32(ctx, keep.get(), off.get(), (size_t)n);
+    const uint32_t kept = fetch(ctx, off.get() + (n - 1));
+    std::unique_ptr<fy_ratings> F(new fy_ratings);
+    F->ctx = ctx;
+    F->nnz = kept;
+    F->max_user = R->max_user;
+    F->max_item = R->max_item;
+    F->user.alloc(ctx, kept);
+    F->item.alloc(ctx, kept);
+    F->score.alloc(ctx, kept);
+    k_pref_emit<<<grid_for(n), 256, 0, st>>>(n, keep.get(), off.get(), vb.get(), R->user.get(), R->item.get(), R->score.get(), F->user.get(),
+                                             F->item.get(), F->score.get());
+    FY_KERNEL_CHECK();
+    sync(ctx);     // the scratch arrays of this function go back to the allocator
+    return F;
+}
+
+fy_result* itemsim_build(Context* ctx, const fy_itemsim_params* prm, const fy_ratings* R_in) {
+    if (prm->min_prefs_per_user < 0 || prm->max_prefs_per_user < 0) FY_FAIL(FY_ERR_INVALID_ARGUMENT, "minPrefsPerUser / maxPrefsPerUser must be >= 0");
+    const std::unique_ptr<fy_ratings> filtered = filter_user_prefs(ctx, R_in, prm->min_prefs_per_user, prm->max_prefs_per_user);
+    const fy_ratings* R = filtered ? filtered.get() : R_in;
     if (prm->similarity != FY_SIMILARITY_COSINE && prm->similarity != FY_SIMILARITY_COOCCURRENCE)
         FY_FAIL(FY_ERR_INVALID_ARGUMENT, "similarity must be FY_SIMILARITY_COSINE or FY_SIMILARITY_COOCCURRENCE");
     if (prm->max_similarities_per_item <= 0) FY_FAIL(FY_ERR_INVALID_ARGUMENT, "maxSimilaritiesPerRow must be > 0");

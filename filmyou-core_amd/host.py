@@ -498,13 +498,19 @@ class RowSimilarityJob:
         self.ctx = ctx
 
     def run(self, ratings, similarityClassname=SIMILARITY_COSINE, maxSimilaritiesPerRow=100,
-            excludeSelfSimilarity=True, threshold=None, rank=0, world=1):
+            excludeSelfSimilarity=True, threshold=None, rank=0, world=1, minPrefsPerUser=1, maxPrefsPerUser=None):
+        """minPrefsPerUser / maxPrefsPerUser: the input preparation in front of the similarity job
+        (BaselinePreparePreferenceMatrixJob.java:104, 126-129).  Users with fewer preferences than minPrefsPerUser are
+        dropped (reference default 1).  maxPrefsPerUser = the reference's maxPrefsPerUserInItemSimilarity (its default 1000 draws
+        a RANDOM sample in Mahout's ToItemVectorsMapper); here None = no cap, a number = a DETERMINISTIC systematic sample
+        (include/filmyou.h) -- no parity with any particular Mahout run."""
         lib = _native.load()
         if similarityClassname not in _SIMILARITY:
             raise ValueError("similarityClassname must be SIMILARITY_COSINE or SIMILARITY_COOCCURRENCE")
         p = _native.ItemSimParams(_SIMILARITY[similarityClassname], int(maxSimilaritiesPerRow),
                                   1 if excludeSelfSimilarity else 0, 0 if threshold is None else 1,
-                                  0.0 if threshold is None else float(threshold), int(rank), int(world), 0)
+                                  0.0 if threshold is None else float(threshold), int(rank), int(world), 0,
+                                  int(minPrefsPerUser), 0 if maxPrefsPerUser is None else int(maxPrefsPerUser))
         ctx = self.ctx or Context(0)
         self.ctx = ctx
         own_ratings = not isinstance(ratings, Ratings)

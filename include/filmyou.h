@@ -155,6 +155,14 @@ typedef struct {
     int32_t rank;                       /* this process builds item-row shard `rank` of `world` */
     int32_t world;
     uint32_t flags;
+    /* input preparation of the preference matrix (M/baselinerecommender/BaselinePreparePreferenceMatrixJob.java:104, 126-129):
+     * users with fewer than min_prefs_per_user preferences are dropped (Mahout ToUserVectorsReducer.MIN_PREFERENCES_PER_USER;
+     * reference default 1 = nobody); users with more than max_prefs_per_user preferences are cut down to that many.  Mahout's
+     * ToItemVectorsMapper draws a RANDOM sample there (no reproducible output exists), this library a DETERMINISTIC systematic
+     * one over the user's preferences in ascending item id: preference k of n is kept iff floor((k+1) m / n) > floor(k m / n)
+     * -- NOT parity with any particular Mahout run, documented as such.  0 = option off. */
+    int32_t min_prefs_per_user;
+    int32_t max_prefs_per_user;
 } fy_itemsim_params;
 int fy_itemsim_build(fy_context*, const fy_itemsim_params*, const fy_ratings*, fy_result** out);
 int fy_itemsim_run(const fy_itemsim_params*, int64_t nnz, const int32_t* user, const int32_t* item,

@@ -34,7 +34,8 @@ class _ICFParams(C.Structure):
 
 class _ISimParams(C.Structure):
     _fields_ = [("similarity", C.c_int32), ("max_similarities_per_item", C.c_int32), ("exclude_self", C.c_int32),
-                ("has_threshold", C.c_int32), ("threshold", C.c_double), ("n_threads", C.c_int32)]
+                ("has_threshold", C.c_int32), ("threshold", C.c_double), ("n_threads", C.c_int32),
+                ("min_prefs_per_user", C.c_int32), ("max_prefs_per_user", C.c_int32)]
 
 
 def _load():
@@ -138,13 +139,14 @@ COSINE, COOCCURRENCE = 0, 1
 
 
 def itemsim(user, item, score, *, similarity=COSINE, max_similarities_per_item=100, exclude_self=True,
-            threshold=None, n_threads=1):
+            threshold=None, n_threads=1, min_prefs_per_user=1, max_prefs_per_user=0):
     """Run the item-item similarity oracle (parity unpinned, see itemsim_oracle.c)."""
     L = _load()
     user, item = _i32(user), _i32(item)
     score = np.ascontiguousarray(score, dtype=np.float32)
     P = _ISimParams(int(similarity), int(max_similarities_per_item), int(bool(exclude_self)),
-                    0 if threshold is None else 1, 0.0 if threshold is None else float(threshold), int(n_threads))
+                    0 if threshold is None else 1, 0.0 if threshold is None else float(threshold), int(n_threads),
+                    int(min_prefs_per_user), int(max_prefs_per_user))
     out = C.c_void_p()
     rc = L.isimo_run(C.byref(P), len(user), user.ctypes.data, item.ctypes.data, score.ctypes.data, C.byref(out))
     if rc != 0:

@@ -140,7 +140,10 @@ int icfo_run(const icfo_params* P, int64_t nnz, const int32_t* user, const int32
         for (int k = 0; k < nt; k++) {
             const int32_t i = touched[k];
             double pred = NAN;
-            if (P->boolean_data) pred = num[i];
+            /* numerators.nonZeroes() / recommendationVector.nonZeroes() (BaselineAggregateAndRecommendReducer.java:148, 195):
+             * an exactly-zero numerator never becomes a candidate */
+            if (num[i] == 0.0) pred = NAN;
+            else if (P->boolean_data) pred = num[i];
             else if (cnt[i] > 1) pred = num[i] / den[i];
             cnt[i] = 0; num[i] = 0.0; den[i] = 0.0;
             const float v = (float)pred;

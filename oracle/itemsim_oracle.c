@@ -13,7 +13,8 @@
  *                       (NO_THRESHOLD = Double.MIN_VALUE: only non-positive values are dropped);
  *   asMatrix          : mirror to the full matrix, keep the top maxSimilaritiesPerRow per item.
  * Mahout's RANDOM down-sampling of users with more than maxPrefsPerUserInItemSimilarity preferences
- * (BaselinePreparePreferenceMatrixJob.java:126-129) is not modelled: it has no reproducible output.
+ * (BaselinePreparePreferenceMatrixJob.java:126-129) has no reproducible output: the option is modelled by a deterministic
+ * systematic sample instead (filter_prefs below), and minPrefsPerUser (:104) as a plain drop.
  * Ties in the top-K (unspecified in Mahout's TopElementsQueue) are broken by ascending item id.
  */
 #include <math.h>
@@ -72,8 +73,47 @@ static int cmp_ent(const void* pa, const void* pb) {
     return (a->j > b->j) - (a->j < b->j);
 }
 
+/* input preparation: drop users with fewer than min_prefs preferences, cut users with more than max_prefs down to max_prefs by
+ * the deterministic systematic sample of include/filmyou.h (preference k of n, in ascending item id, is kept iff
+ * floor((k+1) m / n) > floor(k m / n)).  Mahout's own sampling is random: this models the OPTION, not a Mahout run. */
+typedef struct { int32_t u, i; float s; } pref;
+static int cmp_pref(const void* a, const void* b) {
+    const pref* x = (const pref*)a; const pref* y = (const pref*)b;
+    if (x->u != y->u) return (x->u > y->u) - (x->u < y->u);
+    return (x->i > y->i) - (x->i < y->i);
+}
+static int64_t filter_prefs(int64_t nnz, const int32_t* user, const int32_t* item, const float* score, int min_prefs, int max_prefs,
+                            int32_t* ou, int32_t* oi, float* os) {
+    pref* p = (pref*)malloc(sizeof(pref) * (size_t)(nnz + 1));
+    for (int64_t t = 0; t < nnz; t++) { p[t].u = user[t]; p[t].i = item[t]; p[t].s = score[t]; }
+    qsort(p, (size_t)nnz, sizeof(pref), cmp_pref);
+    int64_t o = 0;
+    for (int64_t a = 0; a < nnz;) {
+        int64_t b = a;
+        while (b < nnz && p[b].u == p[a].u) b++;
+        const int64_t deg = b - a;
+        for (int64_t k = 0; k < deg; k++) {
+            int ok = deg >= min_prefs;
+            if (ok && max_prefs > 0 && deg > max_prefs) ok = ((k + 1) * max_prefs) / deg > (k * max_prefs) / deg;
+            if (ok) { ou[o] = p[a + k].u; oi[o] = p[a + k].i; os[o] = p[a + k].s; o++; }
+        }
+        a = b;
+    }
+    free(p);
+    return o;
+}
+
 int isimo_run(const isimo_params* P, int64_t nnz, const int32_t* user, const int32_t* item, const float* score,
               isimo_result** out) {
+    int32_t *fu = NULL, *fi = NULL;
+    float* fs = NULL;
+    if (P->min_prefs_per_user > 1 || P->max_prefs_per_user > 0) {
+        fu = (int32_t*)malloc(sizeof(int32_t) * (size_t)(nnz + 1));
+        fi = (int32_t*)malloc(sizeof(int32_t) * (size_t)(nnz + 1));
+        fs = (float*)malloc(sizeof(float) * (size_t)(nnz + 1));
+        nnz = filter_prefs(nnz, user, item, score, P->min_prefs_per_user, P->max_prefs_per_user, fu, fi, fs);
+        user = fu; item = fi; score = fs;
+    }
     isimo_result* R = (isimo_result*)calloc(1, sizeof *R);
     int32_t* uid = (int32_t*)malloc(sizeof(int32_t) * (size_t)(nnz + 1));
     int32_t* iid = (int32_t*)malloc(sizeof(int32_t) * (size_t)(nnz + 1));
@@ -164,6 +204,7 @@ int isimo_run(const isimo_params* P, int64_t nnz, const int32_t* user, const int
     }
     free(rows); free(rown); free(uid); free(iid); free(uptr); free(iptr); free(du); free(di); free(norm2);
     free(ucol); free(uval); free(irow); free(ival); free(uf); free(itf);
+    free(fu); free(fi); free(fs);
     *out = R;
     return 0;
 }

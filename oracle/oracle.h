@@ -59,6 +59,8 @@ typedef struct {
     int32_t has_threshold;              /* 0 = RowSimilarityJob.NO_THRESHOLD */
     double threshold;                   /* --threshold */
     int32_t n_threads;
+    int32_t min_prefs_per_user;         /* users with fewer preferences are dropped (BaselinePreparePreferenceMatrixJob.java:104); <= 1: nobody */
+    int32_t max_prefs_per_user;         /* 0 = no cap; else the deterministic systematic sample of include/filmyou.h (Mahout samples at RANDOM) */
 } isimo_params;
 typedef struct isimo_result isimo_result;
 int isimo_run(const isimo_params* P, int64_t nnz, const int32_t* user, const int32_t* item, const float* score,

@@ -81,3 +81,22 @@ def test_user_shards_partition_the_result(ctx):
     key = lambda rows: sorted(zip(rows["user"].tolist(), rows["item"].tolist(), rows["score"].tolist()))
     merged = {k: np.concatenate([p[k] for p in parts]) for k in ("user", "item", "score")}
     assert key(merged) == key(whole.rows())
+
+
+def test_zero_numerators_are_not_candidates(ctx):
+    """The reducer iterates numerators.nonZeroes() / recommendationVector.nonZeroes()
+    (BaselineAggregateAndRecommendReducer.java:148, 195): a candidate whose numerator is exactly 0 -- here: every contributing
+    preference has the value 0.0 -- never reaches the top-N queue.  A third of the ratings are set to 0."""
+    u, i, s, _ = synth().generate("tiny")
+    u, i, s = u.numpy(), i.numpy(), s.numpy().copy()
+    s[::3] = 0.0
+    rows, ref = run_both(ctx, u, i, s, 10, 10, 15)
+    check(rows, ref, 10)
+    assert np.all(rows["score"] != 0.0) and np.all(ref["score"] != 0.0)
+    # and they really occur in this data: with the old rule (count > 1 only) the oracle had more candidates
+    P = pkg()
+    rec, sims = P.BaselineRecommenderJob(ctx).run((u, i, s), numRecommendations=1 << 20, maxPrefsPerUser=10, maxSimilaritiesPerItem=15)
+    n_all = len(rec.rows()["user"])
+    s2 = np.where(s == 0.0, 1e-30, s).astype(np.float32)                 # the same structure without exact zeros
+    rec2, _ = P.BaselineRecommenderJob(ctx).run((u, i, s2), numRecommendations=1 << 20, maxPrefsPerUser=10, maxSimilaritiesPerItem=15)
+    assert len(rec2.rows()["user"]) > n_all

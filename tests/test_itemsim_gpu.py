@@ -100,3 +100,23 @@ def test_bad_arguments(ctx):
         job.run((u, u, u.astype(np.float32)), similarityClassname="class org.apache.mahout...CooccurrenceCountSimilarity")
     with pytest.raises(RuntimeError, match="RowSimilarityJob failed!"):
         job.run((u, u, u.astype(np.float32)), maxSimilaritiesPerRow=0)
+
+
+@pytest.mark.parametrize("min_prefs,max_prefs", [(60, None), (1, 40), (80, 120)])
+def test_input_preparation_options(ctx, min_prefs, max_prefs):
+    """minPrefsPerUser (users below it are dropped) and the cap of maxPrefsPerUserInItemSimilarity
+    (BaselinePreparePreferenceMatrixJob.java:104, 126-129).  The cap is a DETERMINISTIC systematic sample here (Mahout samples at
+    random: no parity with a particular Mahout run is claimed), the same rule in the library and in the oracle."""
+    u, i, s, _ = synth().generate("ml100k")
+    u, i, s = u.numpy(), i.numpy(), s.numpy()
+    res = pkg().RowSimilarityJob(ctx).run((u, i, s), maxSimilaritiesPerRow=25, minPrefsPerUser=min_prefs, maxPrefsPerUser=max_prefs)
+    ref = oracle.itemsim(u, i, s, max_similarities_per_item=1 << 30, n_threads=8, min_prefs_per_user=min_prefs,
+                         max_prefs_per_user=max_prefs or 0)
+    check(res.rows(), ref, 25)
+    deg = np.bincount(u)
+    deg = deg[deg > 0]
+    kept = deg[deg >= min_prefs]
+    if max_prefs:
+        kept = np.minimum(kept, max_prefs)
+    assert res.stats["nnz"] == int(kept.sum()) < len(u)               # the options really removed preferences
+    assert res.stats["unordered_pairs"] == int((kept.astype(np.int64) * (kept - 1) // 2).sum()) == ref["pairs"]

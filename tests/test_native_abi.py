@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_the_header():
     P = pkg()
     assert C.sizeof(P._native.RM2Params) == 48
-    assert C.sizeof(P._native.ItemSimParams) == 40
+    assert C.sizeof(P._native.ItemSimParams) == 48
     assert C.sizeof(P._native.ItemCFParams) == 24
     assert C.sizeof(P._native.Stats) == 23 * 8
 

@@ -58,3 +58,18 @@ def test_threshold_and_sparse_random():
     assert len(exp) == len(r["item"])
     assert np.all(r["sim"] >= 0.2)
     np.testing.assert_allclose(r["sim"], [e[2] for e in exp], rtol=1e-12)
+
+
+def test_input_preparation_of_the_oracle():
+    """minPrefsPerUser drops users, the cap keeps exactly max preferences of a heavy user, evenly spread over its items."""
+    user = np.array([1] * 2 + [2] * 10 + [3] * 5, dtype=np.int32)
+    item = np.concatenate([np.arange(1, 3), np.arange(1, 11), np.arange(3, 8)]).astype(np.int32)
+    score = np.ones(len(user), dtype=np.float32)
+    full = oracle.itemsim(user, item, score, similarity=oracle.COOCCURRENCE, max_similarities_per_item=100)
+    assert full["pairs"] == 1 + 45 + 10
+    no_small = oracle.itemsim(user, item, score, similarity=oracle.COOCCURRENCE, max_similarities_per_item=100, min_prefs_per_user=3)
+    assert no_small["pairs"] == 45 + 10                                  # user 1 (2 preferences) is gone
+    capped = oracle.itemsim(user, item, score, similarity=oracle.COOCCURRENCE, max_similarities_per_item=100, max_prefs_per_user=5)
+    assert capped["pairs"] == 1 + 10 + 10                                # user 2 keeps 5 of its 10: items 2, 4, 6, 8, 10
+    pairs = {(int(a), int(b)): float(c) for a, b, c in zip(capped["item"], capped["other"], capped["sim"])}
+    assert pairs[(2, 4)] == 1.0 and (1, 3) not in pairs and pairs[(4, 6)] == 2.0      # (4, 6): users 2 and 3
