@@ -111,7 +111,114 @@ class RM2Job {
         return 0;
     }
 
+    // One rank of a multi-GPU job (one process per GPU): the staged entry points with the library's compiled RCCL transport
+    // (fy_rccl_*, csrc/fy_rccl.hip).  `rccl_id` = the 128 bytes rank 0 got from fy_rccl_unique_id and handed to the other
+    // ranks through the host's own channel (a Hadoop Configuration entry, a file, ...).  Emits this rank's users only.
+    int runRank(const Ratings& r, const Clustering& c, const PreferenceSink& sink, int device, int rank, int world, const char* rccl_id) {
+        fy_rm2_params p = params();
+        p.rank = rank;
+        p.world = world;
+        fy_context* ctx = nullptr;
+        fy_ratings* rt = nullptr;
+        fy_rm2_job* job = nullptr;
+        fy_rccl* comm = nullptr;
+        fy_result* res = nullptr;
+        auto fail = [&](const char* what) {
+            const std::string msg = std::string("RM2 failed!: ") + what + ": " + fy_last_error();
+            if (job) fy_rm2_job_destroy(job);
+            if (comm) fy_rccl_destroy(comm);
+            if (rt) fy_ratings_destroy(rt);
+            if (ctx) fy_context_destroy(ctx);
+            throw std::runtime_error(msg);
+        };
+        std::vector<int32_t> cc = counts(c, p.number_of_clusters);
+        if (fy_context_create(device, &ctx) != FY_OK) fail("context");
+        if (fy_ratings_create(ctx, (int64_t)r.user.size(), r.user.data(), r.item.data(), r.score.data(), FY_HOST, &rt) != FY_OK) fail("ratings");
+        if (fy_rm2_prepare(ctx, &p, rt, (int64_t)c.user.size(), c.user.data(), c.cluster.data(), cc.empty() ? nullptr : cc.data(), &job) != FY_OK) fail("prepare");
+        if (fy_rccl_create(ctx, rank, world, rccl_id, &comm) != FY_OK) fail("rccl");
+        fy_collectives coll{};
+        if (fy_rccl_collectives(comm, &coll) != FY_OK || fy_rm2_set_collectives(job, &coll) != FY_OK) fail("collectives");
+        if (fy_rm2_score(job, &res) != FY_OK) fail("score");
+        collect(res, sink);
+        fy_rccl_counters(comm, &allGathers, &reduceScatters, &collectiveBytes);
+        fy_result_free(res);
+        fy_rm2_job_destroy(job);
+        fy_rccl_destroy(comm);
+        fy_ratings_destroy(rt);
+        fy_context_destroy(ctx);
+        return 0;
+    }
+    int64_t allGathers = 0, reduceScatters = 0, collectiveBytes = 0;   // of the last runRank
+
+    // RM2Job.run on the reference's own files (M/rm/RM2Job.java:76-100 with useCassandraInput / Output = false): ratings from
+    // <mapred.input.dir>, <directory>/<clustering>, <directory>/<clusteringCount>; writes <directory>/rm2/userSum,
+    // <directory>/rm2/itemColl (MapFile) and the recommendations under <mapred.output.dir>.  Files: fy_seqfile_* (layout
+    // parity unpinned, see csrc/fy_seqfile.cpp).  <directory>/rm2 is NOT wiped here (no filesystem walk in this header).
+    int runFiles() {
+        const std::string in = conf_.get("mapred.input.dir"), out = conf_.get("mapred.output.dir"), base = conf_.get("directory");
+        if (in.empty() || out.empty()) throw std::invalid_argument("mapred.input.dir and mapred.output.dir are required");
+        Ratings r;
+        Clustering c;
+        int64_t n = 0;
+        int32_t *a = nullptr, *b = nullptr;
+        float* v = nullptr;
+        if (fy_seqfile_read_intpair_float(in.c_str(), &n, &a, &b, &v) != FY_OK) throw std::runtime_error(std::string("RM2 failed!: ") + fy_last_error());
+        r.user.assign(a, a + n); r.item.assign(b, b + n); r.score.assign(v, v + n);
+        fy_buffer_free(a); fy_buffer_free(b); fy_buffer_free(v);
+        if (fy_seqfile_read_int_int((base + "/" + conf_.get("clustering")).c_str(), &n, &a, &b) != FY_OK)
+            throw std::runtime_error(std::string("RM2 failed!: ") + fy_last_error());
+        c.user.assign(a, a + n); c.cluster.assign(b, b + n);
+        fy_buffer_free(a); fy_buffer_free(b);
+        if (fy_seqfile_read_int_int((base + "/" + conf_.get("clusteringCount")).c_str(), &n, &a, &b) != FY_OK)
+            throw std::runtime_error(std::string("RM2 failed!: ") + fy_last_error());
+        const long K = conf_.getInt("numberOfClusters", -1);
+        c.count.assign((size_t)(K > 0 ? K : 1), 0);
+        for (int64_t k = 0; k < n; k++)
+            if (a[k] >= 0 && a[k] < (int32_t)c.count.size()) c.count[(size_t)a[k]] = b[k];
+        fy_buffer_free(a); fy_buffer_free(b);
+        std::vector<int32_t> ou, oi;
+        std::vector<float> os;
+        run(r, c, [&](int32_t user, int32_t item, float score, int32_t) { ou.push_back(user); oi.push_back(item); os.push_back(score); });
+        if (fy_seqfile_write_int_double((base + "/rm2/userSum/part-r-00000").c_str(), (int64_t)userSum.size(), userSumKeys.data(), userSum.data()) != FY_OK ||
+            fy_mapfile_write_int_double((base + "/rm2/itemColl/part-r-00000").c_str(), (int64_t)itemColl.size(), itemCollKeys.data(), itemColl.data()) != FY_OK ||
+            fy_seqfile_write_intpair_float((out + "/part-r-00000").c_str(), (int64_t)ou.size(), ou.data(), oi.data(), os.data()) != FY_OK)
+            throw std::runtime_error(std::string("RM2 failed!: ") + fy_last_error());
+        return 0;
+    }
+
    private:
+    fy_rm2_params params() const {
+        fy_rm2_params p{};
+        p.lambda = std::stod(conf_.get("lambda"));
+        p.number_of_items = (int32_t)conf_.getInt("numberOfItems", -1);
+        p.number_of_clusters = (int32_t)conf_.getInt("numberOfClusters", -1);
+        if (p.number_of_items <= 0 || p.number_of_clusters <= 0) throw std::invalid_argument("numberOfItems and numberOfClusters are required");
+        p.number_of_recommendations = (int32_t)conf_.getInt("numberOfRecommendations", 1000);
+        p.filter_users = (int32_t)conf_.getInt("filterUsers", 0);
+        p.world = 1;
+        return p;
+    }
+    static std::vector<int32_t> counts(const Clustering& c, int32_t K) {
+        std::vector<int32_t> cc;
+        if (!c.count.empty()) {
+            cc.assign((size_t)K, 0);
+            for (size_t k = 0; k < c.count.size() && k < cc.size(); k++) cc[k] = c.count[k];
+        }
+        return cc;
+    }
+    void collect(fy_result* res, const PreferenceSink& sink) {
+        const int64_t n = fy_result_size(res);
+        const int32_t *u = fy_result_key0(res), *i = fy_result_key1(res), *cl = fy_result_aux(res);
+        const float* s = fy_result_value(res);
+        for (int64_t k = 0; k < n; k++) sink(u[k], i[k], s[k], cl[k]);
+        const int64_t nu = fy_result_n_users(res), ni = fy_result_n_items(res);
+        userSumKeys.assign(fy_result_user_id(res), fy_result_user_id(res) + nu);
+        userSum.assign(fy_result_user_sum(res), fy_result_user_sum(res) + nu);
+        itemCollKeys.assign(fy_result_item_id(res), fy_result_item_id(res) + ni);
+        itemColl.assign(fy_result_item_coll(res), fy_result_item_coll(res) + ni);
+        totalSum = fy_result_total_sum(res);
+        fy_result_stats(res, &stats);
+    }
     Configuration conf_;
 };
 

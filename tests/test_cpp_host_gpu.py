@@ -40,3 +40,54 @@ def test_cpp_job_failure_is_a_runtime_error(tmp_path, rm_golden):
     out = subprocess.run([exe, str(tmp_path / "ratings.txt"), str(tmp_path / "clustering.txt"), "0.5", "100", "3", "10"],
                          capture_output=True, text=True, timeout=300)       # clusters 3 and 4 are out of range
     assert out.returncode == 1 and "RM2 failed!" in out.stderr
+
+
+def test_cpp_rank_through_the_compiled_rccl_transport(tmp_path, rm_golden):
+    """RM2Job::runRank: the staged entry points (context, ratings, prepare, fy_rccl_create, fy_rm2_set_collectives, score) as
+    rank 0 of a world of one -- the statistics all-gather of jobs RM2-1 / RM2-2 goes through ncclAllGather of the compiled
+    transport (csrc/fy_rccl.hip); same 507 rows."""
+    P = pkg()
+    exe = P._native.build_host_driver()
+    g = rm_golden
+    u, i, s = g["coo"]
+    np.savetxt(tmp_path / "ratings.txt", np.c_[u, i, s], fmt=["%d", "%d", "%.1f"])
+    np.savetxt(tmp_path / "clustering.txt", np.c_[g["map_user"], g["map_cluster"]], fmt="%d")
+    out = subprocess.run([exe, "--rccl", str(tmp_path / "ratings.txt"), str(tmp_path / "clustering.txt"), "0.5", "100", "10", "1000"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    rows = [l.split() for l in out.stdout.strip().splitlines()]
+    got = {(int(a), int(b)): float(c) for a, b, c, _ in rows}
+    exp = np.asarray(g["recommendations"])
+    assert len(rows) == len(got) == 507
+    for a, b, c in exp:
+        assert abs(got[(int(a), int(b))] - c) <= RTOL * abs(c)
+    assert "rccl all_gathers" in out.stderr and "totalSum 7577" in out.stderr
+
+
+def test_cpp_job_on_the_references_files(tmp_path, rm_golden):
+    """RM2Job::runFiles: SequenceFiles in (written like DataInitialization does), SequenceFiles / MapFile out, all through the
+    library's codec from C++; read back here."""
+    import importlib
+    P = pkg()
+    sf = importlib.import_module("filmyou-core_amd.seqfile")
+    exe = P._native.build_host_driver()
+    g = rm_golden
+    u, i, s = g["coo"]
+    keep = s > 0
+    base = str(tmp_path / "recommendation")
+    sf.write_intpair_float(str(tmp_path / "in" / "data"), u[keep], i[keep], s[keep])
+    sf.write_int_int(os.path.join(base, "clustering", "data"), g["map_user"], g["map_cluster"])
+    sf.write_int_int(os.path.join(base, "clusteringCount", "data"), np.arange(len(g["cluster_count"]), dtype=np.int32), g["cluster_count"])
+    out = subprocess.run([exe, "--files", str(tmp_path / "in"), str(tmp_path / "out"), base, "0.5", "100", "10", "1000"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    ru, ri, rs = sf.read_intpair_float(str(tmp_path / "out"))
+    exp = np.asarray(g["recommendations"])
+    got = {(int(a), int(b)): float(c) for a, b, c in zip(ru, ri, rs)}
+    assert len(ru) == 507
+    for a, b, c in exp:
+        assert abs(got[(int(a), int(b))] - c) <= RTOL * abs(c)
+    ku, vu = sf.read_int_double(os.path.join(base, "rm2", "userSum"))
+    np.testing.assert_array_equal(vu, np.asarray(g["userSum"]))
+    ki, vi = sf.read_int_double(os.path.join(base, "rm2", "itemColl"))
+    np.testing.assert_allclose(vi, np.asarray(g["itemColl"]), rtol=1e-15)

@@ -95,8 +95,8 @@ def test_zero_numerators_are_not_candidates(ctx):
     assert np.all(rows["score"] != 0.0) and np.all(ref["score"] != 0.0)
     # and they really occur in this data: with the old rule (count > 1 only) the oracle had more candidates
     P = pkg()
-    rec, sims = P.BaselineRecommenderJob(ctx).run((u, i, s), numRecommendations=1 << 20, maxPrefsPerUser=10, maxSimilaritiesPerItem=15)
+    rec, sims = P.BaselineRecommenderJob(ctx).run((u, i, s), numRecommendations=300, maxPrefsPerUser=10, maxSimilaritiesPerItem=15)
     n_all = len(rec.rows()["user"])
     s2 = np.where(s == 0.0, 1e-30, s).astype(np.float32)                 # the same structure without exact zeros
-    rec2, _ = P.BaselineRecommenderJob(ctx).run((u, i, s2), numRecommendations=1 << 20, maxPrefsPerUser=10, maxSimilaritiesPerItem=15)
+    rec2, _ = P.BaselineRecommenderJob(ctx).run((u, i, s2), numRecommendations=300, maxPrefsPerUser=10, maxSimilaritiesPerItem=15)
     assert len(rec2.rows()["user"]) > n_all
