@@ -48,19 +48,44 @@ struct PairPass {
     double* __restrict__ b_rank;       // by rank position
     long long* __restrict__ walk_rank; // by rank position: sum of the raters' degrees
     int32_t* __restrict__ cnt_rank;    // by rank position: raters
+    float* __restrict__ fx_rank;       // by rank position, 3 floats: sum and maximum of r / s_v^2 over the column, maximum rating
+};                                     // (bounds of the fixed-point scale of the row kernel, fx_exponent)
+struct PairAcc {   // (no member initialisers: instances live in __shared__ memory too)
+    double ps, b, ws;
+    long long w;
+    float wm, rm;
 };
-__device__ __forceinline__ void fy_pair_entry(const PairPass& A, int32_t q, double& ps, double& b, long long& w) {
+__device__ __forceinline__ PairAcc fy_pair_zero() { return PairAcc{0.0, 0.0, 0.0, 0, 0.0f, 0.0f}; }
+__device__ __forceinline__ void fy_pair_entry(const PairPass& A, int32_t q, PairAcc& a) {
     const int32_t slot = A.csc_slot[q];
     const double r = (double)A.csc_r[q];
-    if (slot >= A.lo && slot < A.hi) ps += r;
-    b += r / A.usum_slot[slot];
-    w += A.deg_slot[slot];
+    if (slot >= A.lo && slot < A.hi) a.ps += r;
+    const double s = A.usum_slot[slot];
+    a.b += r / s;
+    a.w += A.deg_slot[slot];
+    const double wt = r / (s * s);
+    a.ws += wt;
+    a.wm = fmaxf(a.wm, (float)wt);
+    a.rm = fmaxf(a.rm, (float)r);
 }
-__device__ __forceinline__ void fy_pair_store(const PairPass& A, int32_t pos, int32_t pr, int32_t n, double ps, double b, long long w) {
-    if (ps != 0.0) atomicAdd(&A.partial[A.pair_di[pr]], ps);
-    A.b_rank[pos] = b;
-    A.walk_rank[pos] = w;
+__device__ __forceinline__ void fy_pair_reduce(PairAcc& a) {
+    for (int o = 32; o > 0; o >>= 1) {
+        a.ps += __shfl_down(a.ps, o, 64);
+        a.b += __shfl_down(a.b, o, 64);
+        a.ws += __shfl_down(a.ws, o, 64);
+        a.w += __shfl_down(a.w, o, 64);
+        a.wm = fmaxf(a.wm, __shfl_down(a.wm, o, 64));
+        a.rm = fmaxf(a.rm, __shfl_down(a.rm, o, 64));
+    }
+}
+__device__ __forceinline__ void fy_pair_store(const PairPass& A, int32_t pos, int32_t pr, int32_t n, const PairAcc& a) {
+    if (a.ps != 0.0) atomicAdd(&A.partial[A.pair_di[pr]], a.ps);
+    A.b_rank[pos] = a.b;
+    A.walk_rank[pos] = a.w;
     A.cnt_rank[pos] = n;
+    A.fx_rank[3 * (int64_t)pos + 0] = (float)(a.ws * 1.000001);      // rounded up: these are upper bounds
+    A.fx_rank[3 * (int64_t)pos + 1] = a.wm * 1.000001f;
+    A.fx_rank[3 * (int64_t)pos + 2] = a.rm;
 }
 __global__ void k_pair_pass(int32_t nP, PairPass A, int32_t* __restrict__ heavy, int32_t* __restrict__ n_heavy) {
     const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
@@ -71,41 +96,32 @@ __global__ void k_pair_pass(int32_t nP, PairPass A, int32_t* __restrict__ heavy,
             if (lane == 0) heavy[atomicAdd(n_heavy, 1)] = pos;
             continue;
         }
-        double ps = 0.0, b = 0.0;
-        long long w = 0;
-        for (int32_t q = q0 + lane; q < q1; q += 64) fy_pair_entry(A, q, ps, b, w);
-        for (int o = 32; o > 0; o >>= 1) {
-            ps += __shfl_down(ps, o, 64);
-            b += __shfl_down(b, o, 64);
-            w += __shfl_down(w, o, 64);
-        }
-        if (lane == 0) fy_pair_store(A, pos, pr, q1 - q0, ps, b, w);
+        PairAcc a = fy_pair_zero();
+        for (int32_t q = q0 + lane; q < q1; q += 64) fy_pair_entry(A, q, a);
+        fy_pair_reduce(a);
+        if (lane == 0) fy_pair_store(A, pos, pr, q1 - q0, a);
     }
 }
 __global__ __launch_bounds__(1024) void k_pair_pass_heavy(PairPass A, const int32_t* __restrict__ heavy, const int32_t* __restrict__ n_heavy) {
-    __shared__ double sh_ps[16], sh_b[16];
-    __shared__ long long sh_w[16];
+    __shared__ PairAcc sh_a[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = *n_heavy;
     for (int k = blockIdx.x; k < n; k += gridDim.x) {
         const int32_t pos = heavy[k];
         const int32_t pr = A.rank_pair[pos];
         const int32_t q0 = A.pair_start[pr], q1 = A.pair_start[pr + 1];
-        double ps = 0.0, b = 0.0;
-        long long w = 0;
-        for (int32_t q = q0 + threadIdx.x; q < q1; q += 1024) fy_pair_entry(A, q, ps, b, w);
-        for (int o = 32; o > 0; o >>= 1) {
-            ps += __shfl_down(ps, o, 64);
-            b += __shfl_down(b, o, 64);
-            w += __shfl_down(w, o, 64);
-        }
-        if (lane == 0) { sh_ps[wave] = ps; sh_b[wave] = b; sh_w[wave] = w; }
+        PairAcc a = fy_pair_zero();
+        for (int32_t q = q0 + threadIdx.x; q < q1; q += 1024) fy_pair_entry(A, q, a);
+        fy_pair_reduce(a);
+        if (lane == 0) sh_a[wave] = a;
         __syncthreads();
         if (threadIdx.x == 0) {
-            double tps = 0.0, tb = 0.0;
-            long long tw = 0;
-            for (int x = 0; x < 16; x++) { tps += sh_ps[x]; tb += sh_b[x]; tw += sh_w[x]; }
-            fy_pair_store(A, pos, pr, q1 - q0, tps, tb, tw);
+            PairAcc t = fy_pair_zero();
+            for (int x = 0; x < 16; x++) {
+                t.ps += sh_a[x].ps; t.b += sh_a[x].b; t.ws += sh_a[x].ws; t.w += sh_a[x].w;
+                t.wm = fmaxf(t.wm, sh_a[x].wm); t.rm = fmaxf(t.rm, sh_a[x].rm);
+            }
+            fy_pair_store(A, pos, pr, q1 - q0, t);
         }
         __syncthreads();
     }
@@ -118,6 +134,26 @@ __global__ void k_slot_user_arrays(int32_t nU, const int32_t* __restrict__ slot2
         usum_slot[s] = usum[du];
         deg_slot[s] = udeg[du];
     }
+}
+
+// per cluster: maxima over its items of (sum of r / s^2, largest r / s^2, largest rating) -> bounds of a Gram entry and of one contribution
+__global__ void k_cluster_fx_bounds(const int32_t* __restrict__ pcstart, const float* __restrict__ fx_rank, float* __restrict__ out) {
+    const int c = blockIdx.x;
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f;
+    for (int32_t pos = pcstart[c] + threadIdx.x; pos < pcstart[c + 1]; pos += blockDim.x) {
+        m0 = fmaxf(m0, fx_rank[3 * (int64_t)pos]);
+        m1 = fmaxf(m1, fx_rank[3 * (int64_t)pos + 1]);
+        m2 = fmaxf(m2, fx_rank[3 * (int64_t)pos + 2]);
+    }
+    __shared__ float sh[3][256];
+    sh[0][threadIdx.x] = m0; sh[1][threadIdx.x] = m1; sh[2][threadIdx.x] = m2;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o)
+            for (int k = 0; k < 3; k++) sh[k][threadIdx.x] = fmaxf(sh[k][threadIdx.x], sh[k][threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x < 3) out[3 * c + threadIdx.x] = sh[threadIdx.x][0];
 }
 
 // quirk Q1: the Hadoop counter adds (long) s_u * 100 per user and is divided by 100 afterwards
@@ -399,6 +435,7 @@ struct MEpilogue {
     float* __restrict__ M;
     int64_t ldm;
     float w2;     // (1-l)^2
+    double fx_inv;   // fixed-point accumulators: (1-l)^2 / fx_scale
     int pack24;   // 3 bytes per element: 8 exponent + 16 mantissa bits of the (non-negative) fp32, rounded to nearest
     float* __restrict__ Bmax;   // optional [row][ldb] in the 24-bit packed format (3 bytes per entry): maximum of the (rounded) row
                                 // over every 256-column block
@@ -479,7 +516,9 @@ __global__ void k_cooc_rm2(CoocArgs A, MEpilogue E, int n_items, int* __restrict
                 ACC* ap = acc + (4 * c4 - c0);
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    const float f = E.w2 * (float)ap[q];          // columns >= Ic were never touched: 0
+                    float f;                                      // columns >= Ic were never touched: 0
+                    if constexpr (std::is_same<ACC, unsigned long long>::value) f = (float)((double)ap[q] * E.fx_inv);
+                    else f = E.w2 * (float)ap[q];
                     ap[q] = (ACC)0;
                     v[q] = ((__float_as_uint(f) << 1) + 0x80u) >> 8;   // G >= 0: drop the sign, keep 8 exponent + 16 mantissa bits, round to nearest
                 }
@@ -507,7 +546,8 @@ __global__ void k_cooc_rm2(CoocArgs A, MEpilogue E, int n_items, int* __restrict
         } else {
             float* __restrict__ out = E.M + (int64_t)mrow * E.ldm;
             for (int col = cb + threadIdx.x; col < c1; col += blockDim.x) {
-                out[col] = E.w2 * (float)acc[col - c0];
+                if constexpr (std::is_same<ACC, unsigned long long>::value) out[col] = (float)((double)acc[col - c0] * E.fx_inv);
+                else out[col] = E.w2 * (float)acc[col - c0];
                 acc[col - c0] = (ACC)0;
             }
         }
@@ -644,6 +684,7 @@ static void cooc_rm2_allow_lds() {
     FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cooc_rm2<true, double>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cooc_rm2<false, float>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cooc_rm2<true, float>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cooc_rm2<true, unsigned long long>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
 }
 
 #include "fy_rm2_kernels.hpp"   // scoring, top-N, branch-and-bound and cooperative-rank kernels (part of this translation unit)
@@ -685,6 +726,8 @@ struct fy_rm2_job {
     DevBuf<double> b_rank, usum_slot;
     DevBuf<long long> walk_rank;
     DevBuf<int32_t> cnt_rank, deg_slot;
+    DevBuf<float> fx_rank;              // 3 per (cluster, item): see PairPass
+    std::vector<float> fx_bounds;       // 3 per cluster (host): max sum of weights, max weight, max rating
     bool count_balanced = false;   // scoring ownership of the users: equal counts instead of equal work (see owner_range)
 };
 
@@ -723,6 +766,7 @@ struct ScoreTune {
     int cooc_pk = 1;                   // packed 4-byte CSR entries for the row kernel when the ratings are fp16-exact
     int cooc_f32 = 0;                  // row kernel accumulators in fp32 (ds_add_f32): MEASUREMENT ONLY -- 4x slower, see fy_cooc.hpp
     int cooc_half = 1;                 // symmetric walk (upper triangle + mirror pass) for clusters with packed rows
+    int cooc_fx = 1;                   // fixed-point (ds_add_u64) accumulation in the packed walk
     double max_surv_frac = 0.25;       // a pruned batch whose surviving blocks exceed this fraction falls back to the full pass
 };
 static ScoreTune score_tune() {
@@ -737,6 +781,7 @@ static ScoreTune score_tune() {
     if (const char* e = getenv("FY_COOC_PK")) t.cooc_pk = atoi(e) != 0;
     if (const char* e = getenv("FY_COOC_F32")) t.cooc_f32 = atoi(e) != 0;
     if (const char* e = getenv("FY_COOC_HALF")) t.cooc_half = atoi(e) != 0;
+    if (const char* e = getenv("FY_COOC_FX")) t.cooc_fx = atoi(e) != 0;
     if (const char* e = getenv("FY_PRUNE_MIN_ITEMS")) t.prune_min_items = atoi(e);
     if (const char* e = getenv("FY_SEED_CHUNKS")) { int v = atoi(e); if (v >= 0 && v <= 4) { t.seed_chunks = v; t.seed_forced = v > 0; } }
     if (const char* e = getenv("FY_WORKSPACE_GB")) { long v = atol(e); if (v >= 1) t.workspace_default = (int64_t)v << 30; }
@@ -746,6 +791,17 @@ static ScoreTune score_tune() {
     if (const char* e = getenv("FY_TOPN_FORCE_SELECT")) t.force_select = atoi(e) != 0;
     if (const char* e = getenv("FY_MAX_SURV_FRAC")) { double v = atof(e); if (v >= 0.0) t.max_surv_frac = v; }
     return t;
+}
+
+// Exponent k of the fixed-point scale 2^k of a cluster (CoocArgs::fx_scale): the largest k with (largest contribution) * 2^k < 2^51
+// and (largest possible Gram entry) * 2^k < 2^62, from the cluster's bounds (sum and maximum of the segment weights r / s^2 per
+// item, largest rating).  Returns a negative number when the bounds are unusable (the fp64 path is taken then).
+static int fx_exponent(const float* bounds3) {
+    const double wsum = bounds3[0], wmax = bounds3[1], rmax = bounds3[2];
+    if (!(wsum > 0.0) || !(wmax > 0.0) || !(rmax > 0.0) || !std::isfinite(wsum * rmax)) return -1;
+    const int k1 = 51 - (std::ilogb(wmax * rmax) + 1), k2 = 62 - (std::ilogb(wsum * rmax) + 1);
+    const int k = std::min(std::min(k1, k2), 1000);
+    return k >= 24 ? k : -1;
 }
 
 // launch shape of the RM2 row kernel: as many workgroups per CU as the LDS accumulators allow (fp32: two for ML-25M's
@@ -759,7 +815,9 @@ static void launch_cooc_rm2(Context* ctx, const ScoreTune& tune, bool use_pk, co
     if (!block) block = by_lds >= 4 ? 256 : (by_lds >= 2 ? 512 : 1024);
     const int per_cu = std::max(1, std::min(by_lds, 2048 / block));
     const int grid = std::min(n_items, ctx->num_cus * per_cu);
-    if (!tune.cooc_f32) {
+    if (use_pk && CA.fx_scale > 0.0 && !tune.cooc_f32) {
+        k_cooc_rm2<true, unsigned long long><<<grid, block, lds, st>>>(CA, ME, n_items, counter);
+    } else if (!tune.cooc_f32) {
         if (use_pk) k_cooc_rm2<true, double><<<grid, block, lds, st>>>(CA, ME, n_items, counter);
         else k_cooc_rm2<false, double><<<grid, block, lds, st>>>(CA, ME, n_items, counter);
     } else {
@@ -825,10 +883,11 @@ fy_rm2_job* fy::rm2_prepare(Context* ctx, const fy_rm2_params* prm, const fy_rat
         J->b_rank.alloc(ctx, (size_t)P.nP);
         J->walk_rank.alloc(ctx, (size_t)P.nP);
         J->cnt_rank.alloc(ctx, (size_t)P.nP);
+        J->fx_rank.alloc(ctx, 3 * (size_t)P.nP);
         DevBuf<int32_t> heavy(ctx, (size_t)P.nP), n_heavy(ctx, 1);
         n_heavy.zero();
         const PairPass PA{P.rank_pair.get(), P.pair_start.get(), P.pair_di.get(), P.csc_slot.get(), P.csc_r.get(), J->usum_slot.get(),
-                          J->deg_slot.get(), J->slot_lo, J->slot_hi, J->partial.get(), J->b_rank.get(), J->walk_rank.get(), J->cnt_rank.get()};
+                          J->deg_slot.get(), J->slot_lo, J->slot_hi, J->partial.get(), J->b_rank.get(), J->walk_rank.get(), J->cnt_rank.get(), J->fx_rank.get()};
         k_pair_pass<<<grid_for((int64_t)P.nP * 64, 256), 256, 0, ctx->stream>>>(P.nP, PA, heavy.get(), n_heavy.get());
         FY_KERNEL_CHECK();
         k_pair_pass_heavy<<<ctx->num_cus * 2, 1024, 0, ctx->stream>>>(PA, heavy.get(), n_heavy.get());
@@ -840,6 +899,15 @@ fy_rm2_job* fy::rm2_prepare(Context* ctx, const fy_rm2_params* prm, const fy_rat
         }
         k_store_total<<<1, 1, 0, ctx->stream>>>(counter.get(), J->partial.get() + P.nI);
         FY_KERNEL_CHECK();
+        DevBuf<float> d_fx(ctx, 3 * (size_t)P.K);
+        k_cluster_fx_bounds<<<P.K, 256, 0, ctx->stream>>>(P.d_pcstart.get(), J->fx_rank.get(), d_fx.get());
+        FY_KERNEL_CHECK();
+        J->fx_bounds.resize(3 * (size_t)P.K);
+        d2h(ctx, J->fx_bounds.data(), d_fx.get(), 3 * (size_t)P.K);
+        tm.end(span);
+        sync(ctx);
+        J->ms_prepare = tm.total_ms();
+        return J.release();
     }
     tm.end(span);
     sync(ctx);
@@ -1163,7 +1231,10 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             CoocArgs CA{P.rank_pair.get(), P.pair_start.get(), segs[pi].ptr.get(), segs[pi].seg.get(), segs[pi].w.get(), P.csr_idx.get(),
                         csr_x.get(), pbase, sbase, Ic, CH, nch, 0, Ic, p.q0, p.nq, nullptr, 0, use_pk ? csr_pk.get() : nullptr, nullptr,
                         (uint32_t)std::min<int64_t>((int64_t)P.nnz * 4, 0xFFFFFFFFll)};
-            MEpilogue ME{L.M.get(), ldm, (float)((1.0 - lambda) * (1.0 - lambda)), pack24 ? 1 : 0, p.prune ? L.Bmax.get() : nullptr, p.ldb, 0};
+            const int fxk = (use_pk && tune.cooc_fx && !J->fx_bounds.empty()) ? fx_exponent(&J->fx_bounds[3 * (size_t)c]) : -1;
+            CA.fx_scale = fxk >= 0 ? std::ldexp(1.0, fxk) : 0.0;
+            MEpilogue ME{L.M.get(), ldm, (float)((1.0 - lambda) * (1.0 - lambda)), fxk >= 0 ? std::ldexp((1.0 - lambda) * (1.0 - lambda), -fxk) : 0.0,
+                         pack24 ? 1 : 0, p.prune ? L.Bmax.get() : nullptr, p.ldb, 0};
             if (p.prune) {
                 FY_HIP(hipMemsetAsync(L.Bmax.get(), 0, (size_t)Ic * p.ldb * 3, ls));
                 k_block_amax<<<grid_for(p.ldb), 256, 0, ls>>>(Ic, (int32_t)p.ldb, a_rank.get() + pbase, b_rank32.get() + pbase, L.amax.get(), L.bmax.get());

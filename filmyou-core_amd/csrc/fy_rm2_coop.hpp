@@ -128,7 +128,10 @@ static void score_cluster_coop(const CoopShared& X, const Plan& p, hipStream_t l
             CoocArgs CA{P.rank_pair.get(), P.pair_start.get(), seg.ptr.get(), seg.seg.get(), seg.w.get(), P.csr_idx.get(),
                         X.csr_x, pbase, sbase, Ic, CH, nch, r0, nrows, 0, (int32_t)my_ratings, local_start.get(), W, X.csr_pk, nullptr,
                         (uint32_t)std::min<int64_t>((int64_t)P.nnz * 4, 0xFFFFFFFFll)};
-            MEpilogue ME{const_cast<float*>(Mshift), ldm, (float)((1.0 - lambda) * (1.0 - lambda)), 1, const_cast<float*>(Bshift), ldb, 1};
+            const int fxk = (X.csr_pk && tune.cooc_fx && !J->fx_bounds.empty()) ? fx_exponent(&J->fx_bounds[3 * (size_t)p.c]) : -1;
+            CA.fx_scale = fxk >= 0 ? std::ldexp(1.0, fxk) : 0.0;
+            MEpilogue ME{const_cast<float*>(Mshift), ldm, (float)((1.0 - lambda) * (1.0 - lambda)), fxk >= 0 ? std::ldexp((1.0 - lambda) * (1.0 - lambda), -fxk) : 0.0,
+                         1, const_cast<float*>(Bshift), ldb, 1};
             const size_t sp = X.t_cooc->begin(ls);
             const int n_items = nrows * nch;
             k_item_list<<<grid_for(n_items), 256, 0, ls>>>(CA, item_seg.get(), item_id.get());

@@ -204,3 +204,27 @@ def test_job_from_the_references_file_layout(rm_golden, tmp_path):
         assert abs(got[(int(a), int(b))] - c) <= 1e-4             # the reference's own tolerance (:53)
         assert abs(got[(int(a), int(b))] - c) <= 1e-5 * abs(c)
     ctx.close()
+
+
+def test_two_runs_give_bit_identical_rows():
+    """The packed walk accumulates in fixed point (ds_add_u64): integer sums do not depend on the order in which the waves'
+    atomics land, so the co-rating matrix -- and with it every score -- is bit-reproducible from run to run."""
+    P = pkg()
+    S = synth()
+    u, i, s, facts = S.generate("ml100k", seed_offset=5)
+    u, i, s = u.numpy(), i.numpy(), (np.round(s.numpy() * 2) / 2).astype(np.float32)       # half stars: the packed walk
+    uu = np.unique(u)
+    conf = P.Configuration()
+    conf.set("lambda", "0.1")
+    conf.setInt("numberOfItems", facts["n_items"])
+    conf.setInt("numberOfClusters", 4)
+    conf.setInt("numberOfRecommendations", 25)
+    ctx = P.Context(0)
+    clustering = (uu, S.hash_clustering(uu, 4))
+    a = P.RM2Job(conf, ctx).run((u, i, s), clustering=clustering).rows()
+    for _ in range(3):
+        b = P.RM2Job(conf, ctx).run((u, i, s), clustering=clustering).rows()
+        for k in ("user", "item", "cluster"):
+            np.testing.assert_array_equal(a[k], b[k])
+        assert a["score"].tobytes() == b["score"].tobytes()
+    ctx.close()
