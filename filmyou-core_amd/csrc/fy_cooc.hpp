@@ -62,6 +62,9 @@ struct CoocArgs {
     // instruction at random addresses) and integer sums do not depend on the order of the atomics: the matrix is
     // bit-reproducible from run to run and from rank to rank.
     double fx_scale;
+    // column-panel mode (fy_rm2.hip): the rows from tail_row0 on have items only for their first tail_chunks chunks
+    // (tail_chunks = 0: every row has all its chunks)
+    int32_t tail_row0, tail_chunks;
 };
 
 #ifndef FY_COOC_NB
@@ -75,12 +78,22 @@ struct SegBatch {
     int2 d;
     float w;
 };
+// Which segment of an item's range a lane's descriptor slot holds.  The range is dealt out in GROUPS of 8 consecutive segments
+// (the unit of the walk: 8 slice loads, then 8 LDS atomics), group G to wave G mod nwaves; a wave's `batch`-th vector load
+// fetches the descriptors of 8 of its groups (lane l: group 8 batch + l / 8, segment l mod 8 of it).  Round 2 handed a wave 64
+// CONSECUTIVE segments: fine for rows with thousands of segments, but in a cluster of 3 000 users (50 clusters at ML-25M shape)
+// 83 % of the (row, chunk) items have at most 64 -- ONE wave of the workgroup walked them, eight groups one after the other,
+// while the others waited at the barrier (13 us per item).  The valid slots of a batch are still a prefix of the lanes.
+static_assert(FY_COOC_NB == 8, "the segment groups of cooc_seg_slot are 8 segments long");
+__device__ __forceinline__ int cooc_seg_slot(int s_begin, int batch, int wave, int nwaves, int lane) {
+    return s_begin + ((((batch << 3) + (lane >> 3)) * nwaves + wave) << 3) + (lane & 7);
+}
 __device__ __forceinline__ SegBatch cooc_first_batch(const CoocArgs& A, int s_begin, int s_end) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     SegBatch B{make_int2(0, 0), 0.0f};
-    const int sb = s_begin + wave * 64;
-    if (sb + lane < s_end) { B.d = A.seg[sb + lane]; B.w = A.seg_w[sb + lane]; }
+    const int s = cooc_seg_slot(s_begin, 0, wave, blockDim.x >> 6, lane);
+    if (s < s_end) { B.d = A.seg[s]; B.w = A.seg_w[s]; }
     return B;
 }
 
@@ -139,16 +152,16 @@ __device__ __forceinline__ void cooc_accumulate_segments(const CoocArgs& A, ACC*
         for (int q = 0; q < NB; q++)
             if (lane < G.L[q]) atomicAdd(&acc[G.idx[q]], (ACC)G.W[q] * (ACC)G.x[q]);   // ds_add_f64 / ds_add_f32
     };
-    int sb = s_begin + wave * 64;
-    if (sb >= s_end) return;
+    int batch = 0;
+    if (cooc_seg_slot(s_begin, 0, wave, nwaves, 0) >= s_end) return;
     int2 d = first.d;
     float w = first.w;
-    while (sb < s_end) {   // wave-uniform
-        const int nloc = min(64, s_end - sb);
-        const int sb_next = sb + nwaves * 64;
+    while (true) {   // wave-uniform
+        const int nloc = __popcll(__ballot(cooc_seg_slot(s_begin, batch, wave, nwaves, lane) < s_end));
+        const int s_next = cooc_seg_slot(s_begin, batch + 1, wave, nwaves, lane);
         int2 dn = make_int2(0, 0);
         float wn = 0.0f;
-        if (sb_next + lane < s_end) { dn = A.seg[sb_next + lane]; wn = A.seg_w[sb_next + lane]; }
+        if (s_next < s_end) { dn = A.seg[s_next]; wn = A.seg_w[s_next]; }
         // Two groups of NB loads are in flight at any time.  The body is STRAIGHT-LINE code (one wave-uniform exit test per
         // pair of groups, no conditional issue): with `if (has_b) issue(...)` in the loop the compiler's wait-count pass merged
         // the two paths and waited for ALL outstanding loads (s_waitcnt vmcnt(0)) in front of every group of atomics, i.e. only
@@ -166,7 +179,8 @@ __device__ __forceinline__ void cooc_accumulate_segments(const CoocArgs& A, ACC*
         }
         d = dn;
         w = wn;
-        sb = sb_next;
+        batch++;
+        if (cooc_seg_slot(s_begin, batch, wave, nwaves, 0) >= s_end) break;
     }
 }
 
@@ -217,16 +231,16 @@ __device__ __forceinline__ void cooc_accumulate_pk(const CoocArgs& A, ACC* __res
             }
         }
     };
-    int sb = s_begin + wave * 64;
-    if (sb >= s_end) return;
+    int batch = 0;
+    if (cooc_seg_slot(s_begin, 0, wave, nwaves, 0) >= s_end) return;
     int2 d = first.d;
     float w = first.w;
-    while (sb < s_end) {   // wave-uniform
-        const int nloc = min(64, s_end - sb);
-        const int sb_next = sb + nwaves * 64;
+    while (true) {   // wave-uniform
+        const int nloc = __popcll(__ballot(cooc_seg_slot(s_begin, batch, wave, nwaves, lane) < s_end));
+        const int s_next = cooc_seg_slot(s_begin, batch + 1, wave, nwaves, lane);
         int2 dn = make_int2(0, 0);
         float wn = 0.0f;
-        if (sb_next + lane < s_end) { dn = A.seg[sb_next + lane]; wn = A.seg_w[sb_next + lane]; }
+        if (s_next < s_end) { dn = A.seg[s_next]; wn = A.seg_w[s_next]; }
         Group GA, GB;      // two groups of NB loads in flight; straight-line body (see cooc_accumulate_segments)
         issue(GA, d, w, 0);
 #pragma unroll 1
@@ -239,7 +253,8 @@ __device__ __forceinline__ void cooc_accumulate_pk(const CoocArgs& A, ACC* __res
         }
         d = dn;
         w = wn;
-        sb = sb_next;
+        batch++;
+        if (cooc_seg_slot(s_begin, batch, wave, nwaves, 0) >= s_end) break;
     }
 }
 
@@ -311,6 +326,9 @@ __attribute__((unused)) static __global__ void k_item_list(CoocArgs A, int2* __r
         if (A.half) {
             if (ch < row / A.CH) continue;
             at = cooc_half_item_index(row, ch, A.CH, A.nch);
+        } else if (A.tail_chunks > 0 && lrow >= A.tail_row0) {
+            if (ch >= A.tail_chunks) continue;
+            at = (int64_t)A.tail_row0 * A.nch + (int64_t)(lrow - A.tail_row0) * A.tail_chunks + ch;
         }
         const int pair = A.rank_pair[A.pbase + row];
         int e0 = A.pair_start[pair], e1 = A.pair_start[pair + 1];
@@ -328,9 +346,11 @@ struct SegTable {
     DevBuf<float> w;
 };
 // half_row_of_entry != nullptr: symmetric walk (only the columns behind the entry's own row; fy_rm2.hip, struct Half)
+// only_rows_of_entry != nullptr: CSC entries of the rows in front of only_rows_from get no segments (tail-row launches)
 void build_segments(Context* ctx, const int32_t* csc_slot, const float* csc_w, const int32_t* chunk_off, int32_t slot_base,
                     int32_t q0, int32_t nq, int32_t nch, SegTable& out, hipStream_t st = nullptr,
-                    const int32_t* half_row_of_entry = nullptr, const int32_t* csr_idx = nullptr, int32_t CH = 0);
+                    const int32_t* half_row_of_entry = nullptr, const int32_t* csr_idx = nullptr, int32_t CH = 0,
+                    const int32_t* only_rows_of_entry = nullptr, int32_t only_rows_from = 0);
 
 // chunk_off table for one cluster: one thread per (slot, boundary)
 void build_chunk_offsets(Context* ctx, const int32_t* rowptr, const int32_t* csr_idx, int32_t slot_base, int32_t n_slots,

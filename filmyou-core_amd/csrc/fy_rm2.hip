@@ -221,6 +221,43 @@ __global__ void k_pack_csr(int32_t f0, int32_t f1, int32_t CH, const int32_t* __
         pk[f] = (uint32_t)(csr_idx[f] % CH) | ((uint32_t)__half_as_ushort(__float2half(csr_r[f])) << 16);
 }
 
+// Column-panel mode, tail rows (rows >= p_eff, few raters each): their co-ratings with the columns behind p_eff are needed only
+// as upper bounds of the 64-column block maxima.  For a row i and a block B
+//     max_{j in B} sum_v x_vi x_vj  <=  sum_v x_vi max_{j in B} x_vj ,
+// and the right-hand side is the row kernel's own sum over a CSR compressed to ONE entry per (rater, block): the block index
+// relative to p_eff | the largest raw rating of the rater in the block, in the packed format of k_pack_csr.  With 2-17 raters
+// per tail row the sum of maxima is within ~14 % of the exact maximum (measured at ML-25M shape in 50 clusters: 1088
+// surviving blocks instead of 1080), a row needs ONE item with (I_c - p_eff) / 64 accumulators instead of one item per
+// 8192-column chunk, and no matrix element behind the panel is ever formed.
+// One wave per user; the user's compressed entries are written in place of the first entries of its CSR range (y_pk is as long
+// as the CSR), co2[2 k] / co2[2 k + 1] = their range: the "chunk offsets" of a one-chunk segment table.
+__global__ void k_tail_blocks(int32_t slot_base, int32_t n_slots, int32_t p_eff, const int32_t* __restrict__ rowptr,
+                              const int32_t* __restrict__ csr_idx, const float* __restrict__ csr_r, uint32_t* __restrict__ y_pk,
+                              int32_t* __restrict__ co2) {
+    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    for (int32_t k = blockIdx.x * wpb + (threadIdx.x >> 6); k < n_slots; k += gridDim.x * wpb) {
+        const int32_t base = rowptr[slot_base + k], end = rowptr[slot_base + k + 1];
+        int count = 0, carry = -1;
+        for (int32_t f0 = base; f0 < end; f0 += 64) {       // (a user's CSR row is sorted by column)
+            const int32_t f = f0 + lane;
+            const int32_t col = f < end ? csr_idx[f] : -1;
+            const int blk = col >= p_eff ? (col - p_eff) >> 6 : -1;
+            int prev = __shfl_up(blk, 1, 64);
+            if (lane == 0) prev = carry;
+            const bool start = blk >= 0 && blk != prev;
+            const unsigned long long bal = __ballot(start);
+            if (start) {
+                float m = csr_r[f];
+                for (int32_t g = f + 1; g < end && ((csr_idx[g] - p_eff) >> 6) == blk; g++) m = fmaxf(m, csr_r[g]);
+                y_pk[base + count + __popcll(bal & ((1ull << lane) - 1ull))] = (uint32_t)blk | ((uint32_t)__half_as_ushort(__float2half(m)) << 16);
+            }
+            count += __popcll(bal);
+            carry = __shfl(blk, 63, 64);
+        }
+        if (lane == 0) { co2[2 * k] = base; co2[2 * k + 1] = base + count; }
+    }
+}
+
 // one wave per user row: x = r / s_u and e = (1-l)(b_j - x) + l (U_c - 1) p_j  (all fp64, rounded once)
 __global__ void k_csr_values(int32_t nU, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ csr_idx,
                              const float* __restrict__ csr_r, const int32_t* __restrict__ slot2du,
@@ -315,12 +352,15 @@ struct Half {
     const int32_t* __restrict__ csr_idx;
     int32_t CH;
     int32_t* __restrict__ start;                // [q]: first CSR entry behind (v, i) (scratch, nq entries)
+    // tail-row launches (column-panel mode): entries of the rows in front of only_from get no segments
+    const int32_t* __restrict__ only_rows;      // [q0 + q]: row of the entry; nullptr = all rows
+    int32_t only_from;
 };
 __global__ void k_seg_counts(const int32_t* __restrict__ csc_slot, const int32_t* __restrict__ chunk_off, int32_t slot_base,
                              int32_t q0, int32_t nq, int32_t nch, int32_t* __restrict__ cnt, Half H) {
     // one thread per CSC entry: the rater's nch + 1 chunk offsets are one contiguous gather
     for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q <= nq; q += (int64_t)gridDim.x * blockDim.x) {
-        const bool live = q < nq;
+        const bool live = q < nq && !(H.only_rows && H.only_rows[q0 + q] < H.only_from);
         const int32_t* co = live ? chunk_off + (int64_t)(csc_slot[q0 + q] - slot_base) * (nch + 1) : nullptr;
         int32_t prev = live ? co[0] : 0;
         int32_t own = -1, behind = 0;
@@ -374,6 +414,7 @@ __global__ void k_seg_fill(const int32_t* __restrict__ csc_slot, const float* __
                 if (ch < own) len = 0;
                 else if (ch == own) { f0 = H.start[q]; len = co[1] - f0; }
             }
+            if (H.only_rows && H.only_rows[q0 + q] < H.only_from) len = 0;
             w = csc_w[q0 + q];
             start = pp[q];
         }
@@ -405,13 +446,13 @@ __global__ void k_seg_fill(const int32_t* __restrict__ csc_slot, const float* __
 
 void build_segments(Context* ctx, const int32_t* csc_slot, const float* csc_w, const int32_t* chunk_off, int32_t slot_base,
                     int32_t q0, int32_t nq, int32_t nch, SegTable& out, hipStream_t st, const int32_t* half_row_of_entry,
-                    const int32_t* csr_idx, int32_t CH) {
+                    const int32_t* csr_idx, int32_t CH, const int32_t* only_rows_of_entry, int32_t only_rows_from) {
     if (!st) st = ctx->stream;
     const size_t np = (size_t)nch * ((size_t)nq + 1);
     out.ptr.alloc(ctx, np);
     DevBuf<int32_t> cnt(ctx, np);
     DevBuf<int32_t> half_start(ctx, half_row_of_entry ? (size_t)nq + 1 : 1);
-    const Half H{half_row_of_entry, csr_idx, CH, half_start.get()};
+    const Half H{half_row_of_entry, csr_idx, CH, half_start.get(), only_rows_of_entry, only_rows_from};
     k_seg_counts<<<grid_for((int64_t)nq + 1), 256, 0, st>>>(csc_slot, chunk_off, slot_base, q0, nq, nch, cnt.get(), H);
     FY_KERNEL_CHECK();
     exclusive_scan_i32(ctx, cnt.get(), out.ptr.get(), np, st);
@@ -441,6 +482,15 @@ struct MEpilogue {
                                 // over every 256-column block
     int64_t ldb;
     int local_rows;   // 1: M / Bmax hold only this launch's rows, k-th row of the launch at index k (cooperative ranks)
+    // column-panel mode (fy_rm2_kernels.hpp, "many clusters"): only the first panel_cols columns of a row are stored (row pitch
+    // panel_cols), and the block maxima are taken over 64-column sub-blocks of the WHOLE row
+    int32_t panel_cols;          // 0 = off
+    float* __restrict__ Bmax64;  // [row][ldb64], 3 bytes per entry
+    int64_t ldb64;
+    // tail-bound launches of panel mode (k_tail_blocks below): the "matrix" is a column range of Bmax64 -- ldm columns are
+    // written per row, the rows are `pitch` elements apart (0: the pitch is the row length) and the 24-bit rounding goes up
+    int64_t pitch;
+    int ceil24;
 };
 
 // Persistent workgroups pull (row, chunk) items from a global counter (rows are in popularity order: heavy items first);
@@ -454,7 +504,8 @@ struct MEpilogue {
 // also fetches the segment range of the next item while the current one is accumulated; after the barrier every wave issues
 // the load of its first 64 segment descriptors of the NEXT item, and only then runs the epilogue: of the three round
 // trips in front of an item's first slice load none is exposed any more.  (3) The epilogue no longer reads b and p.
-template <bool PK, class ACC>
+// ROLE only names the instantiation (kernel traces): 0 = matrix rows, 1 = the tail rows' block bounds of panel mode (k_tail_blocks)
+template <bool PK, class ACC, int ROLE = 0>
 __global__ void k_cooc_rm2(CoocArgs A, MEpilogue E, int n_items, int* __restrict__ next_item) {
     ACC* __restrict__ acc = reinterpret_cast<ACC*>(fy_cooc_acc);
     __shared__ int sh_item, sh_s0, sh_s1, sh_id;
@@ -510,7 +561,9 @@ __global__ void k_cooc_rm2(CoocArgs A, MEpilogue E, int n_items, int* __restrict
         const int first_bmax_block = A.half ? (row >> 8) + 1 : 0;
         if (E.pack24) {
             // four columns -> three dwords (c0 and c1 are multiples of 64)
-            uint32_t* __restrict__ out3 = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(E.M) + (int64_t)mrow * E.ldm * 3);
+            const int64_t row_cols = E.pitch ? E.pitch : (E.panel_cols ? E.panel_cols : E.ldm);
+            const uint32_t radd = E.ceil24 ? 0xFFu : 0x80u;
+            uint32_t* __restrict__ out3 = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(E.M) + (int64_t)mrow * row_cols * 3);
             for (int c4 = (cb >> 2) + threadIdx.x; 4 * c4 < c1; c4 += blockDim.x) {
                 uint32_t v[4];
                 ACC* ap = acc + (4 * c4 - c0);
@@ -520,11 +573,25 @@ __global__ void k_cooc_rm2(CoocArgs A, MEpilogue E, int n_items, int* __restrict
                     if constexpr (std::is_same<ACC, unsigned long long>::value) f = (float)((double)ap[q] * E.fx_inv);
                     else f = E.w2 * (float)ap[q];
                     ap[q] = (ACC)0;
-                    v[q] = ((__float_as_uint(f) << 1) + 0x80u) >> 8;   // G >= 0: drop the sign, keep 8 exponent + 16 mantissa bits, round to nearest
+                    v[q] = ((__float_as_uint(f) << 1) + radd) >> 8;    // G >= 0: drop the sign, keep 8 exponent + 16 mantissa bits, round to nearest
                 }
-                out3[3 * c4 + 0] = v[0] | (v[1] << 24);
-                out3[3 * c4 + 1] = (v[1] >> 8) | (v[2] << 16);
-                out3[3 * c4 + 2] = (v[2] >> 16) | (v[3] << 8);
+                if (!E.panel_cols || 4 * c4 < E.panel_cols) {
+                    out3[3 * c4 + 0] = v[0] | (v[1] << 24);
+                    out3[3 * c4 + 1] = (v[1] >> 8) | (v[2] << 16);
+                    out3[3 * c4 + 2] = (v[2] >> 16) | (v[3] << 8);
+                }
+                if (E.Bmax64) {
+                    // 16 lanes = one 64-column sub-block
+                    uint32_t m = max(max(v[0], v[1]), max(v[2], v[3]));
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+                    if ((threadIdx.x & 15) == 0 && m) {
+                        uint8_t* bp = reinterpret_cast<uint8_t*>(E.Bmax64) + ((int64_t)mrow * E.ldb64 + (c4 >> 4)) * 3;
+                        bp[0] = (uint8_t)m;
+                        bp[1] = (uint8_t)(m >> 8);
+                        bp[2] = (uint8_t)(m >> 16);
+                    }
+                }
                 if (E.Bmax) {
                     // maximum of the values exactly as the scoring kernel will unpack them; one wave = one 256-column
                     // block (c0 and c1 are multiples of 256 when the bound matrix is requested, see pick_chunks)
@@ -767,6 +834,10 @@ struct ScoreTune {
     int cooc_f32 = 0;                  // row kernel accumulators in fp32 (ds_add_f32): MEASUREMENT ONLY -- 4x slower, see fy_cooc.hpp
     int cooc_half = 1;                 // symmetric walk (upper triangle + mirror pass) for clusters with packed rows
     int cooc_fx = 1;                   // fixed-point (ds_add_u64) accumulation in the packed walk
+    int panel_min_clusters = 4;        // column-panel mode when at least this many clusters of the rank are pruned ones
+    int panel_cols = 4096;             // columns of a row kept in panel mode (the seed columns and the popular blocks)
+    int panel_lanes = 2;               // job lanes when clusters run in panel mode (measured, 50 clusters: 1 lane 300 ms, 2: 213, 3: 230, 4: 240)
+    int panel_max_ch = 6144;           // chunk width of the row kernel in panel mode: three workgroups per CU (measured, 50 clusters: 8192 -> 138 ms, 6144 -> 89, 4096 -> 93)
     double max_surv_frac = 0.25;       // a pruned batch whose surviving blocks exceed this fraction falls back to the full pass
 };
 static ScoreTune score_tune() {
@@ -782,6 +853,10 @@ static ScoreTune score_tune() {
     if (const char* e = getenv("FY_COOC_F32")) t.cooc_f32 = atoi(e) != 0;
     if (const char* e = getenv("FY_COOC_HALF")) t.cooc_half = atoi(e) != 0;
     if (const char* e = getenv("FY_COOC_FX")) t.cooc_fx = atoi(e) != 0;
+    if (const char* e = getenv("FY_PANEL_MIN_CLUSTERS")) { int v = atoi(e); if (v >= 1) t.panel_min_clusters = v; }
+    if (const char* e = getenv("FY_PANEL_COLS")) { int v = atoi(e); if (v >= 256) t.panel_cols = v; }
+    if (const char* e = getenv("FY_PANEL_MAX_CH")) { int v = atoi(e); if (v >= 256) t.panel_max_ch = v; }
+    if (const char* e = getenv("FY_PANEL_LANES")) { int v = atoi(e); if (v >= 1 && v <= 8) t.panel_lanes = v; }
     if (const char* e = getenv("FY_PRUNE_MIN_ITEMS")) t.prune_min_items = atoi(e);
     if (const char* e = getenv("FY_SEED_CHUNKS")) { int v = atoi(e); if (v >= 0 && v <= 4) { t.seed_chunks = v; t.seed_forced = v > 0; } }
     if (const char* e = getenv("FY_WORKSPACE_GB")) { long v = atol(e); if (v >= 1) t.workspace_default = (int64_t)v << 30; }
@@ -816,7 +891,8 @@ static void launch_cooc_rm2(Context* ctx, const ScoreTune& tune, bool use_pk, co
     const int per_cu = std::max(1, std::min(by_lds, 2048 / block));
     const int grid = std::min(n_items, ctx->num_cus * per_cu);
     if (use_pk && CA.fx_scale > 0.0 && !tune.cooc_f32) {
-        k_cooc_rm2<true, unsigned long long><<<grid, block, lds, st>>>(CA, ME, n_items, counter);
+        if (ME.ceil24) k_cooc_rm2<true, unsigned long long, 1><<<grid, block, lds, st>>>(CA, ME, n_items, counter);
+        else k_cooc_rm2<true, unsigned long long><<<grid, block, lds, st>>>(CA, ME, n_items, counter);
     } else if (!tune.cooc_f32) {
         if (use_pk) k_cooc_rm2<true, double><<<grid, block, lds, st>>>(CA, ME, n_items, counter);
         else k_cooc_rm2<false, double><<<grid, block, lds, st>>>(CA, ME, n_items, counter);
@@ -842,7 +918,12 @@ struct Plan {
     int c;
     int32_t Uc, sbase, pbase, Ic, a, b, CH, nch, q0, nq;
     int64_t ldm, B;
-    bool pack24, prune, coop, half;
+    bool pack24, prune, coop, half, panel;
+    int32_t panel_cols, nsub;
+    int64_t ldb64;
+    // panel mode: the rows from p_eff on ("tail rows") are walked only over their first tail_chunks chunks (= the columns in
+    // front of p_eff, a chunk boundary behind the panel); their block bounds behind p_eff come from k_tail_blocks' CSR
+    int32_t tail_chunks, p_eff, tail_width;
     int32_t nblk;
     int64_t ldb;
 };
@@ -1093,16 +1174,47 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             // symmetric walk: packed rows only (small clusters keep exact fp32 rows and the plain walk); a cooperative rank
             // owns whole rows of the matrix, so it walks them whole
             p.half = tune.cooc_half && p.pack24 && !p.coop && p.nch < 256;
+            p.panel = false;
+            p.panel_cols = 0;
+            p.tail_chunks = 0;
+            p.p_eff = p.Ic;
+            p.tail_width = 0;
+            p.nsub = (int32_t)ceil_div(p.Ic, 64);
+            p.ldb64 = round_up(p.nsub, 256);
             plans.push_back(p);
         }
-        const int NS = (int)std::min<size_t>(plans.size() > 1 ? (size_t)tune.lanes : 1, plans.size());
+        {   // column-panel mode: many pruned clusters on this rank (the reference's regime: numberOfClusters ~ 50)
+            int n_pruned = 0;
+            for (auto& p : plans) n_pruned += (p.prune && !p.coop) ? 1 : 0;
+            if (n_pruned >= tune.panel_min_clusters)
+                for (auto& p : plans)
+                    if (p.prune && !p.coop && use_pk && p.nch < 256 && p.nsub < 0xFFFF && p.Uc <= STRAY_UCAP) {
+                        p.panel = true;
+                        p.half = false;      // a row's block maxima need the whole row
+                        // (the item ids of the row kernel hold the chunk in 8 bits)
+                        pick_chunks(p.Ic, std::min<int>(max_ch_lds, std::max<int>(tune.panel_max_ch, (int)round_up(ceil_div(p.Ic, 255), 256))), p.CH, p.nch);
+                        p.panel_cols = (int32_t)std::min<int64_t>(p.ldm, std::max<int64_t>(round_up(tune.panel_cols, 256), (int64_t)tune.seed_chunks * 256));
+                        p.tail_chunks = (int32_t)ceil_div(p.panel_cols, p.CH);
+                        p.p_eff = (int32_t)std::min<int64_t>((int64_t)p.tail_chunks * p.CH, p.Ic);
+                        if (p.p_eff % 256 != 0 || p.tail_chunks >= p.nch) { p.p_eff = p.Ic; p.tail_chunks = 0; }   // one chunk, or a ragged one: no tail rows
+                        p.tail_width = (int32_t)(p.ldb64 - p.p_eff / 64);
+                    }
+        }
+        bool any_panel = false;
+        for (auto& p : plans) any_panel = any_panel || p.panel;
+        const int want_lanes = any_panel && !getenv("FY_LANES") ? std::min(tune.lanes, tune.panel_lanes) : tune.lanes;
+        const int NS = (int)std::min<size_t>(plans.size() > 1 ? (size_t)want_lanes : 1, plans.size());
         struct Lane {
             hipStream_t st;
             DevBuf<float> M, S;
             DevBuf<int32_t> overflow, any_overflow;
             // branch and bound
             DevBuf<float> Bmax, amax, bmax, UB, tau;
+            DevBuf<float> Gp, Bmax64, amax64, bmax64;    // column-panel mode
             DevBuf<uint16_t> surv;
+            DevBuf<uint8_t> surv_mask;     // panel mode: which 64-column sub-blocks of a surviving block passed the bound
+            DevBuf<int2> strayT;           // co-rater tables of k_score_stray
+            DevBuf<int2> stray_items;
             DevBuf<int32_t> n_quads, quad_prefix;
             DevBuf<int2> item_seg;
             DevBuf<int32_t> item_id;
@@ -1112,7 +1224,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
         {
             size_t is_el = 1;
             for (auto& p : plans) is_el = std::max(is_el, (size_t)p.Ic * p.nch);
-            size_t m_el = 1, s_el = 1, ov_el = 1, bm_el = 1, ub_el = 1, am_el = 1;
+            size_t m_el = 1, s_el = 1, ov_el = 1, bm_el = 1, ub_el = 1, am_el = 1, gp_el = 1, b64_el = 1, a64_el = 1;
             for (auto& p : plans) {
                 p.B = std::min<int64_t>(std::max<int64_t>(1, (ws / NS) / (p.ldm * 4)), p.b - p.a);
                 // pruned clusters keep only the seed columns of a score row (the survivors' scores are packed, see below):
@@ -1120,6 +1232,15 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 const int64_t seed_cols = (int64_t)std::min<int64_t>(ceil_div(p.Ic, 256), tune.seed_chunks) * 256;
                 if (p.prune) p.B = p.b - p.a;
                 if (p.coop) continue;   // allocates for itself
+                if (p.panel) {
+                    gp_el = std::max(gp_el, (size_t)p.Ic * p.panel_cols * 3 / 4 + 4);
+                    b64_el = std::max(b64_el, (size_t)p.Ic * p.ldb64 * 3 / 4 + 4);
+                    a64_el = std::max(a64_el, (size_t)p.ldb64);
+                    s_el = std::max(s_el, (size_t)(p.B * seed_cols));
+                    ov_el = std::max(ov_el, (size_t)p.B);
+                    ub_el = std::max(ub_el, (size_t)(p.B * p.ldb64));
+                    continue;
+                }
                 m_el = std::max(m_el, (size_t)(p.Ic * p.ldm));
                 s_el = std::max(s_el, (size_t)(p.B * (p.prune ? seed_cols : p.ldm)));
                 ov_el = std::max(ov_el, (size_t)p.B);
@@ -1146,26 +1267,34 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 L.Bmax.alloc(ctx, bm_el);
                 L.amax.alloc(ctx, am_el);
                 L.bmax.alloc(ctx, am_el);
+                L.Gp.alloc(ctx, gp_el);
+                L.Bmax64.alloc(ctx, b64_el);
+                L.amax64.alloc(ctx, a64_el);
+                L.bmax64.alloc(ctx, a64_el);
                 L.UB.alloc(ctx, ub_el);
                 L.tau.alloc(ctx, ov_el);
                 L.surv.alloc(ctx, ub_el);
+                L.surv_mask.alloc(ctx, gp_el > 1 ? ub_el : 1);
                 L.n_quads.alloc(ctx, ov_el + 1);
                 L.quad_prefix.alloc(ctx, ov_el + 1);
                 L.item_seg.alloc(ctx, is_el);
                 L.item_id.alloc(ctx, is_el);
             }
         }
-        DevBuf<unsigned long long> prune_counters(ctx, 3);   // [0] surviving blocks, [1] log terms evaluated by the three pruned passes, [2] users sent to k_topn_select
+        DevBuf<unsigned long long> prune_counters(ctx, 4);   // [0] surviving blocks, [1] log terms evaluated by the three pruned passes, [2] users sent to k_topn_select, [3] stray blocks (panel mode)
         prune_counters.zero();
         int64_t prune_blocks_total = 0, prune_seed_terms_cols = 0, coop_survived = 0, fallback_survived = 0;
         for (auto& p : plans) any_coop = any_coop || p.coop;
         // segment tables of the row kernel, one per cluster, built on the main stream before the lanes fork
-        std::vector<SegTable> segs(plans.size());
+        std::vector<SegTable> segs(plans.size()), segs_tail(plans.size());
+        bool any_tail = false;
+        for (auto& p : plans) any_tail = any_tail || p.p_eff < p.Ic;
+        DevBuf<uint32_t> y_pk(ctx, any_tail ? (size_t)P.nnz : 1);     // k_tail_blocks
         span_tables = t_tables.begin();
         {
             size_t co_all = 1;
             bool any_half = false;
-            for (auto& p : plans) { co_all = std::max(co_all, (size_t)p.Uc * (p.nch + 1)); any_half = any_half || p.half; }
+            for (auto& p : plans) { co_all = std::max(co_all, (size_t)p.Uc * (p.nch + 1)); any_half = any_half || p.half || p.p_eff < p.Ic; }
             DevBuf<int32_t> co_tmp(ctx, co_all);
             DevBuf<int32_t> csc_rank(ctx, any_half ? (size_t)P.nnz : 1);     // row (rank inside its cluster) of every CSC entry
             if (any_half) {
@@ -1188,6 +1317,13 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 build_chunk_offsets(ctx, P.rowptr.get(), P.csr_idx.get(), p.sbase, p.Uc, p.CH, p.nch, co_tmp.get());
                 build_segments(ctx, P.csc_slot.get(), use_pk ? csc_x_over_s.get() : csc_x.get(), co_tmp.get(), p.sbase, p.q0, p.nq, p.nch, segs[pi], nullptr,
                                p.half ? csc_rank.get() : nullptr, P.csr_idx.get(), p.CH);
+                if (p.p_eff < p.Ic) {   // panel mode: the tail rows' one-chunk table over the block-compressed CSR
+                    k_tail_blocks<<<grid_for((int64_t)p.Uc * 64), 256, 0, st>>>(p.sbase, p.Uc, p.p_eff, P.rowptr.get(), P.csr_idx.get(), P.csr_r.get(),
+                                                                              y_pk.get(), co_tmp.get());
+                    FY_KERNEL_CHECK();
+                    build_segments(ctx, P.csc_slot.get(), csc_x_over_s.get(), co_tmp.get(), p.sbase, p.q0, p.nq, 1, segs_tail[pi], nullptr, nullptr, nullptr, 0,
+                                   csc_rank.get(), p.p_eff);
+                }
             }
         }
         t_tables.end(span_tables);
@@ -1234,16 +1370,41 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             const int fxk = (use_pk && tune.cooc_fx && !J->fx_bounds.empty()) ? fx_exponent(&J->fx_bounds[3 * (size_t)c]) : -1;
             CA.fx_scale = fxk >= 0 ? std::ldexp(1.0, fxk) : 0.0;
             MEpilogue ME{L.M.get(), ldm, (float)((1.0 - lambda) * (1.0 - lambda)), fxk >= 0 ? std::ldexp((1.0 - lambda) * (1.0 - lambda), -fxk) : 0.0,
-                         pack24 ? 1 : 0, p.prune ? L.Bmax.get() : nullptr, p.ldb, 0};
-            if (p.prune) {
+                         pack24 ? 1 : 0, (p.prune && !p.panel) ? L.Bmax.get() : nullptr, p.ldb, 0,
+                         p.panel ? p.panel_cols : 0, p.panel ? L.Bmax64.get() : nullptr, p.ldb64};
+            if (p.panel) {
+                R->st.panel_clusters++;
+                ME.M = L.Gp.get();
+                FY_HIP(hipMemsetAsync(L.Bmax64.get(), 0, (size_t)Ic * p.ldb64 * 3, ls));
+                k_block_amax<<<grid_for(p.ldb64), 256, 0, ls>>>(Ic, (int32_t)p.ldb64, a_rank.get() + pbase, b_rank32.get() + pbase, L.amax64.get(),
+                                                               L.bmax64.get(), 64);
+                FY_KERNEL_CHECK();
+            } else if (p.prune) {
                 FY_HIP(hipMemsetAsync(L.Bmax.get(), 0, (size_t)Ic * p.ldb * 3, ls));
                 k_block_amax<<<grid_for(p.ldb), 256, 0, ls>>>(Ic, (int32_t)p.ldb, a_rank.get() + pbase, b_rank32.get() + pbase, L.amax.get(), L.bmax.get());
                 FY_KERNEL_CHECK();
             }
             const size_t sp = t_cooc.begin(ls);
+            if (p.p_eff < Ic) {   // panel mode: bounds of the tail rows behind p_eff (one item per row, see k_tail_blocks)
+                CoocArgs CB{P.rank_pair.get(), P.pair_start.get(), segs_tail[pi].ptr.get(), segs_tail[pi].seg.get(), segs_tail[pi].w.get(), P.csr_idx.get(),
+                            csr_x.get(), pbase, sbase, Ic, p.tail_width, 1, p.p_eff, Ic - p.p_eff, p.q0, p.nq, nullptr, 0, y_pk.get(), nullptr, CA.pk_bytes};
+                CB.fx_scale = CA.fx_scale;
+                MEpilogue MB{reinterpret_cast<float*>(reinterpret_cast<char*>(L.Bmax64.get()) + (size_t)(p.p_eff / 64) * 3), p.tail_width, ME.w2, ME.fx_inv, 1,
+                             nullptr, 0, 0, 0, nullptr, 0, p.ldb64, 1};
+                k_item_list<<<grid_for((int64_t)(Ic - p.p_eff)), 256, 0, ls>>>(CB, L.item_seg.get(), L.item_id.get());
+                FY_KERNEL_CHECK();
+                CB.item_seg = L.item_seg.get();
+                CB.item_id = L.item_id.get();
+                FY_HIP(hipMemsetAsync(L.any_overflow.get(), 0, sizeof(int32_t), ls));
+                launch_cooc_rm2(ctx, tune, use_pk, CB, MB, Ic - p.p_eff, L.any_overflow.get(), ls);
+                R->st.cooc_launches++;
+                CA.tail_row0 = p.p_eff;
+                CA.tail_chunks = p.tail_chunks;
+            }
             {
                 CA.half = p.half ? 1 : 0;
-                const int n_items = (int)cooc_item_count(Ic, CH, nch, p.half);
+                const int n_items = CA.tail_chunks > 0 ? (int)((int64_t)p.p_eff * nch + (int64_t)(Ic - p.p_eff) * p.tail_chunks)
+                                                       : (int)cooc_item_count(Ic, CH, nch, p.half);
                 k_item_list<<<grid_for((int64_t)Ic * nch), 256, 0, ls>>>(CA, L.item_seg.get(), L.item_id.get());
                 FY_KERNEL_CHECK();
                 CA.item_seg = L.item_seg.get();
@@ -1304,29 +1465,37 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 // (1) + (3) ONE launch: exact scores of the seed columns (the most popular candidates) and the upper bounds
                 // of all 256-column blocks (the same kernel on the block-maximum matrix); the grid's tail -- the waves
                 // that walk the heaviest users -- is paid once instead of twice
-                const int bchunks = (int)(p.ldb / 256);
-                ScoreArgs SA = score_args(L.M.get(), ldm, Ic, a_rank.get() + pbase, s0, nb, L.S.get(), SC, n_slices, seed_chunks + bchunks);
+                // panel mode: the stored rows are panel_cols wide and the bound matrix has one column per 64-column sub-block
+                const float* Gmat = p.panel ? L.Gp.get() : L.M.get();
+                const int64_t gld = p.panel ? (int64_t)p.panel_cols : ldm;
+                const int64_t bld = p.panel ? p.ldb64 : p.ldb;           // pitch of the bound matrix, of UB and of the survivor lists
+                const int bchunks = (int)(bld / 256);
+                ScoreArgs SA = score_args(Gmat, gld, Ic, a_rank.get() + pbase, s0, nb, L.S.get(), SC, n_slices, seed_chunks + bchunks);
                 SA.chunks1 = seed_chunks;
-                SA.M2 = L.Bmax.get();
-                SA.ldm2 = p.ldb;
-                SA.Ic2 = p.nblk;
-                SA.a2 = L.amax.get();
-                SA.b2 = L.bmax.get();
+                SA.M2 = p.panel ? L.Bmax64.get() : L.Bmax.get();
+                SA.ldm2 = bld;
+                SA.Ic2 = p.panel ? p.nsub : p.nblk;
+                SA.a2 = p.panel ? L.amax64.get() : L.amax.get();
+                SA.b2 = p.panel ? L.bmax64.get() : L.bmax.get();
                 SA.S2 = L.UB.get();
-                SA.ldS2 = p.ldb;
+                SA.ldS2 = bld;
                 SA.no_mask2 = 1;
                 k_score<4, true, 8><<<(seed_chunks + bchunks) * n_slices, 256, 0, ls>>>(SA.M, SA.a_rank, SA.rb_off, SA.csr_idx, SA.csr_e, SA.csr_q, SA.pvpi, SA.n_out, SA.S, SA);
                 FY_KERNEL_CHECK();
                 // (2) tau_u = N-th best seed score; the sorted seed head is also the user's list unless a block survives
                 TopNArgs T1{L.S.get(), SC, Ic, n_out.get(), out_off.get(), P.rank_item_raw.get() + pbase, P.slot2du.get(), P.uid.get(),
                             lo, s0, c, R->d_key0.get(), R->d_key1.get(), R->d_value.get(), R->d_aux.get(),
-                            1, seed_chunks * 256, L.surv.get(), L.n_quads.get(), p.ldb, L.tau.get()};
+                            1, seed_chunks * 256, L.surv.get(), L.n_quads.get(), bld, L.tau.get()};
                 k_topn_fast<<<nb, 256, 0, ls>>>(T1, L.overflow.get(), L.any_overflow.get(), 0);
                 FY_KERNEL_CHECK();
                 // (4) the blocks whose bound reaches tau_u, in ascending order
                 FY_HIP(hipMemsetAsync(L.n_quads.get(), 0, ((size_t)nb + 1) * sizeof(int32_t), ls));
-                k_bound_select<<<grid_for((int64_t)nb * 64, 256), 256, 0, ls>>>(L.UB.get(), p.ldb, p.nblk, seed_blocks, L.tau.get(), pvpi.get() + (s0 - lo), nb,
-                                                                               L.surv.get(), L.n_quads.get());
+                if (p.panel)
+                    k_bound_select_sub<<<grid_for((int64_t)nb * 64, 256), 256, 0, ls>>>(L.UB.get(), bld, p.nsub, p.nblk, seed_blocks, L.tau.get(),
+                                                                                       pvpi.get() + (s0 - lo), nb, bld, L.surv.get(), L.surv_mask.get(), L.n_quads.get());
+                else
+                    k_bound_select<<<grid_for((int64_t)nb * 64, 256), 256, 0, ls>>>(L.UB.get(), p.ldb, p.nblk, seed_blocks, L.tau.get(), pvpi.get() + (s0 - lo), nb,
+                                                                                   L.surv.get(), L.n_quads.get());
                 FY_KERNEL_CHECK();
                 exclusive_scan_i32(ctx, L.n_quads.get(), L.quad_prefix.get(), (size_t)nb + 1, ls);
                 // (5) exact scores of the survivors, packed: 256 floats per surviving block at entry quad_prefix[u] + k
@@ -1337,7 +1506,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 FY_HIP(hipStreamSynchronize(ls));   // (everything queued on this lane before has finished: Ssurv may be re-sized)
                 const int32_t n_surv_total = hv[0];
                 const int64_t blocks_checked = (int64_t)nb * std::max(0, p.nblk - seed_blocks);
-                if ((double)n_surv_total > tune.max_surv_frac * (double)blocks_checked) {
+                if (!p.panel && (double)n_surv_total > tune.max_surv_frac * (double)blocks_checked) {     // (panel mode has no full matrix to fall back on)
                     // The threshold did not bite (e.g. lambda = 0: a user who rated an item nobody else of the cluster rated has
                     // only -inf scores, tau = -inf keeps every block): the survivor pass would cost more than the plain full pass
                     // and 1 KB of scratch per survivor.  Redo the batch with the full pass, in sub-batches that fit the workspace.
@@ -1355,20 +1524,38 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 }
                 L.Ssurv.alloc(ctx, (size_t)std::max(1, n_surv_total) * PRUNE_BLOCK);
                 if (n_surv_total > 0) {
-                    ScoreArgs SQ = score_args(L.M.get(), ldm, Ic, a_rank.get() + pbase, s0, nb, L.Ssurv.get(), 0, n_slices, n_chunks);
+                    ScoreArgs SQ = score_args(Gmat, gld, Ic, a_rank.get() + pbase, s0, nb, L.Ssurv.get(), 0, n_slices, n_chunks);
+                    const int panel_blocks = p.panel ? p.panel_cols / 256 : 0x7FFFFFFF;
                     k_score_blocks<8><<<std::min(n_surv_total, ctx->num_cus * 16), 256, 0, ls>>>(SQ.M, SQ.a_rank, P.rowptr.get(), SQ.csr_idx, SQ.csr_e, SQ.csr_q, SQ.pvpi,
-                                                                        L.quad_prefix.get(), L.surv.get(), SQ.S, SQ, p.ldb, prune_counters.get());
+                                                                        L.quad_prefix.get(), L.surv.get(), SQ.S, SQ, bld, prune_counters.get(), panel_blocks);
                     FY_KERNEL_CHECK();
+                    if (p.panel && panel_blocks < p.nblk) {     // survivors behind the panel: exact, from the sparse data
+                        const size_t slds = ((size_t)p.Uc + 1) * sizeof(int32_t);
+                        const int sgrid = std::min<int>(n_surv_total, ctx->num_cus * (int)std::max<size_t>(1, std::min<size_t>(6, (150 * 1024) / (slds + 20 * 1024))));
+                        L.strayT.alloc(ctx, (size_t)sgrid * STRAY_TCAP);
+                        L.stray_items.alloc(ctx, (size_t)n_surv_total + 1);      // (a group holds at least one surviving block)
+                        FY_HIP(hipMemsetAsync(L.any_overflow.get(), 0, sizeof(int32_t), ls));   // reused as the item counter
+                        k_stray_items<<<grid_for(nb), 256, 0, ls>>>(L.quad_prefix.get(), L.surv.get(), bld, nb, panel_blocks, L.stray_items.get(),
+                                                                   L.any_overflow.get());
+                        FY_KERNEL_CHECK();
+                        StrayArgs ST{L.quad_prefix.get(), L.surv.get(), L.surv_mask.get(), bld, nb, s0, lo, sbase, p.Uc, panel_blocks, Ic, pbase,
+                                     P.rowptr.get(), P.csr_idx.get(), csr_e.get(), csr_q.get(), P.rank_pair.get(), P.pair_start.get(), P.csc_slot.get(),
+                                     csc_x.get(), a_rank.get() + pbase, b_rank32.get() + pbase, pvpi.get(),
+                                     (float)((1.0 - lambda) * (1.0 - lambda)), L.Ssurv.get(), L.strayT.get(), prune_counters.get(), L.stray_items.get(),
+                                     L.any_overflow.get()};
+                        k_score_stray<<<sgrid, 256, slds, ls>>>(ST);
+                        FY_KERNEL_CHECK();
+                    }
                 }
                 t_score.end(ss, ls);
                 R->st.score_launches += 2;   // the fused seed + bound launch and the survivor pass
                 prune_blocks_total += blocks_checked;
                 // log terms of the seed and bound passes of this batch: (ratings of its users) x (columns walked)
-                prune_seed_terms_cols += (int64_t)(hv[2] - hv[1]) * (seed_chunks * 256 + p.ldb);
+                prune_seed_terms_cols += (int64_t)(hv[2] - hv[1]) * (seed_chunks * 256 + bld);
                 const int32_t seed_cols_p = seed_chunks * 256;
                 TopNArgs TA{L.S.get(), (int64_t)seed_cols_p, Ic, n_out.get(), out_off.get(), P.rank_item_raw.get() + pbase,
                             P.slot2du.get(), P.uid.get(), lo, s0, c, R->d_key0.get(), R->d_key1.get(), R->d_value.get(), R->d_aux.get(),
-                            2, seed_cols_p, L.surv.get(), L.n_quads.get(), p.ldb, L.tau.get(), L.Ssurv.get(), L.quad_prefix.get()};
+                            2, seed_cols_p, L.surv.get(), L.n_quads.get(), bld, L.tau.get(), L.Ssurv.get(), L.quad_prefix.get()};
                 const size_t tt = t_topn.begin(ls);
                 FY_HIP(hipMemsetAsync(L.any_overflow.get(), 0, sizeof(int32_t), ls));
                 k_topn_fast<<<nb, 256, 0, ls>>>(TA, L.overflow.get(), L.any_overflow.get(), tune.force_select);
@@ -1389,10 +1576,11 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
         }
         // (the guard's destructor drains the lanes and the main stream before any buffer of this scope is released)
         {
-            unsigned long long hc[3];
-            d2h(ctx, hc, prune_counters.get(), 3);
+            unsigned long long hc[4];
+            d2h(ctx, hc, prune_counters.get(), 4);
             sync(ctx);
             R->st.topn_select_users = (int64_t)hc[2];
+            R->st.stray_blocks = (int64_t)hc[3];
             R->st.blocks_survived = (int64_t)hc[0] + coop_survived + fallback_survived;
             R->st.blocks_total = prune_blocks_total;
             R->st.log_terms_evaluated = prune_blocks_total ? (int64_t)hc[1] + prune_seed_terms_cols : 0;

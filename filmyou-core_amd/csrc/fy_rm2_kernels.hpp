@@ -523,10 +523,10 @@ constexpr int PRUNE_BLOCK = 256;   // = the column chunk of the scoring kernel: 
 
 // block maxima of a = lambda * p and of b (the rank-one part of a term, q_j b_i + a_i e_uj, is monotone in both)
 __global__ void k_block_amax(int32_t Ic, int32_t ldb, const float* __restrict__ a_rank, const float* __restrict__ b_rank,
-                             float* __restrict__ amax, float* __restrict__ bmax) {
+                             float* __restrict__ amax, float* __restrict__ bmax, int32_t width = PRUNE_BLOCK) {
     for (int32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < ldb; b += gridDim.x * blockDim.x) {
         float m = 0.0f, mb = 0.0f;
-        for (int i = b * PRUNE_BLOCK; i < min(Ic, (b + 1) * PRUNE_BLOCK); i++) { m = fmaxf(m, a_rank[i]); mb = fmaxf(mb, b_rank[i]); }
+        for (int64_t i = (int64_t)b * width; i < min((int64_t)Ic, (int64_t)(b + 1) * width); i++) { m = fmaxf(m, a_rank[i]); mb = fmaxf(mb, b_rank[i]); }
         amax[b] = m;
         bmax[b] = mb;
     }
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(256) void k_score_blocks(const float* __restrict__ 
                                                       const double* __restrict__ pvpi_,
                                                       const int32_t* __restrict__ surv_prefix_, const uint16_t* __restrict__ surv_,
                                                       float* __restrict__ S_, ScoreArgs A, int64_t ldb,
-                                                      unsigned long long* __restrict__ counters) {
+                                                      unsigned long long* __restrict__ counters, int32_t panel_blocks = 0x7FFFFFFF) {
     __shared__ double sh_t[3][64][4];
     __shared__ unsigned sh_mask[3][64];
     const int lane = threadIdx.x & 63;
@@ -561,7 +561,9 @@ __global__ __launch_bounds__(256) void k_score_blocks(const float* __restrict__ 
         }
         const int u = lo;
         const int slot = A.slot0 + u;
-        const int col0 = (int)surv_[(int64_t)u * ldb + (w - surv_prefix_[u])] * PRUNE_BLOCK;
+        const int blk = (int)surv_[(int64_t)u * ldb + (w - surv_prefix_[u])];
+        if (blk >= panel_blocks) continue;             // a block behind the column panel: k_score_stray's (block-uniform)
+        const int col0 = blk * PRUNE_BLOCK;
         const int col = col0 + lane * 4;
         float a[4], bb[4];
 #pragma unroll
@@ -627,6 +629,299 @@ __global__ __launch_bounds__(256) void k_score_blocks(const float* __restrict__ 
         __syncthreads();   // sh_t is free again
     }
     if (wave == 0 && lane == 0 && my_terms) atomicAdd(&counters[1], my_terms);
+}
+
+// ================================================================ column-panel mode (many clusters)
+// With many clusters a dense I_c x I_c matrix per cluster is what the job spends its time on (50 x 7.8 GB written and re-read at
+// ML-25M shape), although only the seed columns, the block bounds and the few blocks that survive the bound are ever read.
+// Panel mode keeps per cluster: Gp = the first `panel_cols` columns of every row (the seed columns and the popular blocks --
+// where, measured, the surviving blocks are), and the block maxima at 64-COLUMN granularity for the whole row (in a sparse
+// cluster the maximum of a 256-column block is almost always a co-rated pair while most of its candidates are not co-rated
+// with most of the user's items: 64-column bounds cut the survivors ~4x).  A 256-column block survives when one of its four
+// sub-blocks does; survivors inside the panel are scored from Gp by k_score_blocks, the rare survivors behind it ("strays":
+// tail blocks of users with a dozen ratings) exactly from the sparse data by k_score_stray.
+__global__ __launch_bounds__(256) void k_bound_select_sub(const float* __restrict__ UB64, int64_t ldb64, int32_t nsub, int32_t nblk, int32_t seed_blocks,
+                                                          const float* __restrict__ tau, const double* __restrict__ pvpi /* [u] */,
+                                                          int32_t n_users, int64_t ldsurv, uint16_t* __restrict__ surv, uint8_t* __restrict__ surv_mask,
+                                                          int32_t* __restrict__ n_surv) {
+    const int lane = threadIdx.x & 63;
+    const int wpb = blockDim.x >> 6;
+    for (int u = blockIdx.x * wpb + (threadIdx.x >> 6); u < n_users; u += gridDim.x * wpb) {
+        const float t = tau[u];
+        const float pv = (float)pvpi[u];
+        int count = 0;
+        for (int b0 = 0; b0 < nblk; b0 += 64) {
+            const int b = b0 + lane;
+            unsigned keep = 0;     // bit q: sub-block q of the block survives
+            if (b < nblk && b >= seed_blocks) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int sb = 4 * b + q;
+                    if (sb < nsub && fy_bound_keeps(UB64[(int64_t)u * ldb64 + sb], t, pv)) keep |= 1u << q;
+                }
+            }
+            const unsigned long long bal = __ballot(keep != 0);
+            if (keep) {
+                const int64_t at = (int64_t)u * ldsurv + count + __popcll(bal & ((1ull << lane) - 1ull));
+                surv[at] = (uint16_t)b;
+                surv_mask[at] = (uint8_t)keep;
+            }
+            count += __popcll(bal);
+        }
+        if (lane == 0) n_surv[u] = count;
+    }
+}
+
+// Exact scores of the surviving blocks that lie behind the column panel ("strays"), from the sparse data alone:
+//     G[j][i] = (1-l)^2 sum_{v in raters(i)} x_vi x_vj     for the user's rated items j and the candidates i of the block.
+// Who they are (measured, ML-25M shape in 50 clusters): blocks of users with 15-50 ratings around the user's OWN rated tail
+// items -- G[j][i0] of a rated tail item i0 holds the user's own large x_ui0 x_uj for every j of the list, so the maxima of
+// i0's 64-column sub-block bound every term high, while the 63 real candidates next to i0 score ~100 below the threshold.
+// One workgroup per user with strays:
+//   (1) the co-rater table T of the user: every (rater v, list position of j, x_vj) over the raters of the user's items j,
+//       grouped by v with a counting sort in LDS (the CSC lists of the j are streamed once, coalesced);
+//   (2) per stray block, per live candidate i (a wave each): for every rater v of i, T's entries of v are exactly the
+//       co-ratings of v with the user's list: x_vi x_vj is added to the accumulator of j's list position (fixed point,
+//       ds_add_u64: the sum does not depend on the order of the lanes), then the log terms are summed over the list.
+// A candidate costs its co-ratings with the list, not the length of its raters' rows.  Lists longer than STRAY_JCAP (or with
+// more than STRAY_TCAP co-raters) are walked in pieces -- the score is a sum over j -- and T is then rebuilt per block.
+constexpr int STRAY_UCAP = 16384;    // users of the cluster (panel mode is for many small clusters: fy_rm2.hip, Plan::panel)
+constexpr int STRAY_JCAP = 256;
+constexpr int STRAY_TCAP = 32768;    // >= STRAY_UCAP: one item's raters always fit
+struct StrayArgs {
+    const int32_t* __restrict__ surv_prefix;
+    const uint16_t* __restrict__ surv;
+    const uint8_t* __restrict__ surv_mask;
+    int64_t ldsurv;
+    int32_t n_users, slot0, slot_lo, slot_base, Uc, panel_blocks, Ic, pbase;
+    const int32_t* __restrict__ rowptr;
+    const int32_t* __restrict__ csr_idx;
+    const float* __restrict__ csr_e;
+    const float* __restrict__ csr_q;
+    const int32_t* __restrict__ rank_pair;
+    const int32_t* __restrict__ pair_start;
+    const int32_t* __restrict__ csc_slot;
+    const float* __restrict__ csc_x;
+    const float* __restrict__ a_rank;
+    const float* __restrict__ b_rank;
+    const double* __restrict__ pvpi;
+    float w2;
+    float* __restrict__ S;
+    int2* __restrict__ T;                 // gridDim.x * STRAY_TCAP entries {list position, x_vj as bits}
+    unsigned long long* __restrict__ counters;
+    const int2* __restrict__ items;       // k_stray_items: {user of the batch, index of its first stray block of this item}
+    const int32_t* __restrict__ n_items;
+};
+// Work items of k_score_stray: a user's stray blocks in groups of STRAY_GROUP (a user has 4 on average and up to ~20: one
+// workgroup per USER left the launch waiting for the users with the most blocks; the co-rater table is rebuilt per group).
+constexpr int STRAY_GROUP = 4;
+__global__ void k_stray_items(const int32_t* __restrict__ surv_prefix, const uint16_t* __restrict__ surv, int64_t ldsurv, int32_t n_users,
+                              int32_t panel_blocks, int2* __restrict__ items, int32_t* __restrict__ n_items) {
+    for (int u = blockIdx.x * blockDim.x + threadIdx.x; u < n_users; u += gridDim.x * blockDim.x) {
+        const int ns = surv_prefix[u + 1] - surv_prefix[u];
+        const uint16_t* __restrict__ mine = surv + (int64_t)u * ldsurv;
+        int first = 0, hi = ns;                                   // the user's blocks are in ascending order: strays are a suffix
+        while (first < hi) { const int mid = (first + hi) >> 1; if ((int)mine[mid] < panel_blocks) first = mid + 1; else hi = mid; }
+        const int groups = (ns - first + STRAY_GROUP - 1) / STRAY_GROUP;
+        if (groups > 0) {
+            const int at = atomicAdd(n_items, groups);
+            for (int g = 0; g < groups; g++) items[at + g] = make_int2(u, first + g * STRAY_GROUP);
+        }
+    }
+}
+extern __shared__ __attribute__((aligned(16))) int32_t fy_stray_off[];      // Uc + 1 rater offsets
+__global__ __launch_bounds__(256) void k_score_stray(StrayArgs A) {
+    int32_t* __restrict__ sh_off = fy_stray_off;
+    __shared__ int32_t sh_col[STRAY_JCAP], sh_pre[STRAY_JCAP + 1], sh_q0[STRAY_JCAP];
+    __shared__ float sh_e[STRAY_JCAP], sh_q[STRAY_JCAP];
+    __shared__ unsigned long long sh_g[4][STRAY_JCAP];
+    __shared__ double sh_t[PRUNE_BLOCK];       // log2 sums of the block's candidates; NaN = no candidate
+    __shared__ int32_t sh_nk, sh_wsum[4];
+    __shared__ int32_t sh_cq0[PRUNE_BLOCK], sh_cnr[PRUNE_BLOCK];      // the candidates' CSC ranges
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double LN2 = 0.69314718055994530942;
+    // x_vi x_vj <= 1/4 (both ratings are part of s_v), so a sum over at most Uc = 2^14 raters stays below 2^12: 50 fraction bits
+    const double fx = 1125899906842624.0, fx_inv = 1.0 / 1125899906842624.0;
+    int2* __restrict__ T = A.T + (int64_t)blockIdx.x * STRAY_TCAP;
+    unsigned long long my_terms = 0, my_blocks = 0;
+    for (int t = threadIdx.x; t < 4 * STRAY_JCAP; t += blockDim.x) (&sh_g[0][0])[t] = 0ull;
+    // entry e of the piece's concatenated rater lists -> (list position, CSC entry); four at a time, loads first
+    auto locate = [&](int e, int nk, int& t, int& q) __attribute__((always_inline)) {
+        int l = 0, h = nk;                                        // last t with sh_pre[t] <= e
+        while (h - l > 1) { const int m = (l + h) >> 1; if (sh_pre[m] <= e) l = m; else h = m; }
+        t = l;
+        q = sh_q0[l] + (e - sh_pre[l]);
+    };
+    const int n_items = *A.n_items;
+    for (int it = blockIdx.x; it < n_items; it += gridDim.x) {     // block-uniform
+        const int u = A.items[it].x, first = A.items[it].y;
+        const int wbase = A.surv_prefix[u], ns = min(A.surv_prefix[u + 1] - wbase, first + STRAY_GROUP);
+        const uint16_t* __restrict__ mine = A.surv + (int64_t)u * A.ldsurv;
+        const int slot = A.slot0 + u;
+        const int r0 = A.rowptr[slot], r1 = A.rowptr[slot + 1];
+        bool built = false, single = false;
+        for (int ks = first; ks < ns; ks++) {
+            const int w = wbase + ks;
+            const int blk = (int)mine[ks];
+            const unsigned sub_mask = A.surv_mask[(int64_t)u * A.ldsurv + ks];
+            __syncthreads();                                        // the previous block's sh_t has been written out
+            {   // candidates: dead (NaN) when out of range, in a sub-block whose bound stayed below the threshold, or rated by the user
+                const int i = blk * PRUNE_BLOCK + threadIdx.x;
+                bool dead = i >= A.Ic || !((sub_mask >> (threadIdx.x >> 6)) & 1u);
+                if (!dead) {
+                    int l = r0, h = r1;
+                    while (l < h) { const int m = (l + h) >> 1; if (A.csr_idx[m] < i) l = m + 1; else h = m; }
+                    dead = l < r1 && A.csr_idx[l] == i;
+                }
+                int cq0 = 0, cnr = 0;
+                if (!dead) {
+                    const int pr = A.rank_pair[A.pbase + i];
+                    cq0 = A.pair_start[pr];
+                    cnr = A.pair_start[pr + 1] - cq0;
+                }
+                sh_cq0[threadIdx.x] = cq0;
+                sh_cnr[threadIdx.x] = cnr;                          // 0 raters: a dead candidate
+                sh_t[threadIdx.x] = dead ? __builtin_nan("") : 0.0;
+            }
+            __syncthreads();                                        // a wave reads the flags of candidates other waves' threads set
+            int k0 = r0;
+            while (k0 < r1) {
+                if (!(built && single)) {
+                    // ---- (1) the piece of the list and its co-rater table
+                    __syncthreads();                                // nobody reads the previous piece any more
+                    const int ntry = min(STRAY_JCAP, r1 - k0);
+                    for (int t = threadIdx.x; t < ntry; t += blockDim.x) {
+                        const int j = A.csr_idx[k0 + t];
+                        const int pr = A.rank_pair[A.pbase + j];
+                        const int q0 = A.pair_start[pr];
+                        sh_col[t] = j;
+                        sh_e[t] = A.csr_e[k0 + t];
+                        sh_q[t] = A.csr_q[k0 + t];
+                        sh_q0[t] = q0;
+                        sh_pre[t + 1] = A.pair_start[pr + 1] - q0;  // rater count; prefix below
+                    }
+                    for (int t = threadIdx.x; t <= A.Uc; t += blockDim.x) sh_off[t] = 0;
+                    __syncthreads();
+                    if (threadIdx.x == 0) {                         // as many items as fit the table (one always does)
+                        int tot = 0, m = 0;
+                        sh_pre[0] = 0;
+                        while (m < ntry && tot + sh_pre[m + 1] <= STRAY_TCAP) { tot += sh_pre[m + 1]; sh_pre[m + 1] = tot; m++; }
+                        sh_nk = m;
+                    }
+                    __syncthreads();
+                    const int nk_ = sh_nk, tot = sh_pre[nk_];
+                    for (int e0 = threadIdx.x; e0 < tot; e0 += 4 * 256) {          // count
+                        int v[4];
+#pragma unroll
+                        for (int x = 0; x < 4; x++) {
+                            const int e = e0 + x * 256;
+                            v[x] = -1;
+                            if (e < tot) { int t, q; locate(e, nk_, t, q); v[x] = A.csc_slot[q] - A.slot_base; }
+                        }
+#pragma unroll
+                        for (int x = 0; x < 4; x++)
+                            if (v[x] >= 0) atomicAdd(&sh_off[v[x] + 1], 1);
+                    }
+                    __syncthreads();
+                    {   // inclusive scan of sh_off[1 .. Uc]: afterwards sh_off[v] = first entry of rater v, sh_off[Uc] = total
+                        const int per = (A.Uc + (int)blockDim.x - 1) / (int)blockDim.x;
+                        const int b0 = 1 + threadIdx.x * per, b1 = min(A.Uc + 1, b0 + per);
+                        int sum = 0;
+                        for (int t = b0; t < b1; t++) sum += sh_off[t];
+                        int incl = sum;
+                        for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(incl, o, 64); if (lane >= o) incl += y; }
+                        if (lane == 63) sh_wsum[wave] = incl;
+                        __syncthreads();
+                        int before = incl - sum;
+                        for (int x = 0; x < wave; x++) before += sh_wsum[x];
+                        for (int t = b0; t < b1; t++) { before += sh_off[t]; sh_off[t] = before; }
+                    }
+                    __syncthreads();
+                    // fill: the cursor of rater v is sh_off[v] (its start); afterwards sh_off[v] is its END and its start is
+                    // sh_off[v - 1] (0 for the first)
+                    for (int e0 = threadIdx.x; e0 < tot; e0 += 4 * 256) {
+                        int v[4], tt[4];
+                        float xv[4];
+#pragma unroll
+                        for (int x = 0; x < 4; x++) {
+                            const int e = e0 + x * 256;
+                            v[x] = -1;
+                            tt[x] = 0;
+                            xv[x] = 0.f;
+                            if (e < tot) { int q; locate(e, nk_, tt[x], q); v[x] = A.csc_slot[q] - A.slot_base; xv[x] = A.csc_x[q]; }
+                        }
+#pragma unroll
+                        for (int x = 0; x < 4; x++)
+                            if (v[x] >= 0) T[atomicAdd(&sh_off[v[x]], 1)] = make_int2(tt[x], __float_as_int(xv[x]));
+                    }
+                    __threadfence_block();
+                    __syncthreads();
+                    built = true;
+                    single = (k0 == r0 && nk_ == r1 - r0);
+                }
+                const int nk = sh_nk;
+                // ---- (2) the candidates of this block against the piece
+                unsigned long long* __restrict__ g = sh_g[wave];
+                // the wave's live candidates, one after the other; the first 64 raters of the NEXT one are loaded while the
+                // current one's table entries are fetched (a candidate is two dependent round trips otherwise)
+                auto next_live = [&](int c) __attribute__((always_inline)) {
+                    while (c < PRUNE_BLOCK && sh_cnr[c] == 0) c += 4;
+                    return c;
+                };
+                int c = next_live(wave);
+                int pv = 0;
+                float px = 0.f;
+                if (c < PRUNE_BLOCK && lane < sh_cnr[c]) { pv = A.csc_slot[sh_cq0[c] + lane] - A.slot_base; px = A.csc_x[sh_cq0[c] + lane]; }
+                while (c < PRUNE_BLOCK) {                           // wave-uniform
+                    const int i = blk * PRUNE_BLOCK + c;
+                    const int q0 = sh_cq0[c], nr = sh_cnr[c];
+                    const int cn = next_live(c + 4);
+                    int v = pv;
+                    float xf = px;
+                    if (cn < PRUNE_BLOCK && lane < sh_cnr[cn]) { pv = A.csc_slot[sh_cq0[cn] + lane] - A.slot_base; px = A.csc_x[sh_cq0[cn] + lane]; }
+                    for (int qb = 0; qb < nr; qb += 64) {           // a lane per rater of the candidate
+                        if (qb > 0 && qb + lane < nr) { v = A.csc_slot[q0 + qb + lane] - A.slot_base; xf = A.csc_x[q0 + qb + lane]; }
+                        if (qb + lane < nr) {
+                            const double xi = (double)xf;
+                            const int t0 = v ? sh_off[v - 1] : 0, t1 = sh_off[v];
+                            for (int t = t0; t < t1; t += 4) {      // four table entries in flight
+                                int2 ent[4];
+#pragma unroll
+                                for (int x = 0; x < 4; x++) ent[x] = T[min(t + x, t1 - 1)];
+#pragma unroll
+                                for (int x = 0; x < 4; x++)
+                                    if (t + x < t1) atomicAdd(&g[ent[x].x], (unsigned long long)(xi * (double)__int_as_float(ent[x].y) * fx + 0.5));
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    const float ai = A.a_rank[i], bi = A.b_rank[i];
+                    double tt = 0.0;
+                    for (int k = lane; k < nk; k += 64) {
+                        const float gv = A.w2 * (float)((double)g[k] * fx_inv);
+                        tt += (double)fy_log2(fmaf(sh_q[k], bi, fmaf(ai, sh_e[k], gv)));
+                        g[k] = 0ull;
+                    }
+                    for (int o = 32; o > 0; o >>= 1) tt += __shfl_xor(tt, o, 64);
+                    if (lane == 0) sh_t[c] += tt;                   // (candidate c belongs to this wave alone)
+                    c = cn;
+                }
+                k0 += nk;
+            }
+            __syncthreads();
+            const double base = A.pvpi[slot - A.slot_lo];
+            const double tv = sh_t[threadIdx.x];
+            A.S[(int64_t)w * PRUNE_BLOCK + threadIdx.x] = tv != tv ? __builtin_nanf("") : (float)(base + LN2 * tv);
+            if (threadIdx.x == 0) {
+                my_terms += (unsigned long long)(r1 - r0) * 64ull * (unsigned long long)__popc(sub_mask);
+                my_blocks++;
+            }
+        }
+    }
+    if (threadIdx.x == 0 && my_blocks) {
+        atomicAdd(&A.counters[1], my_terms);
+        atomicAdd(&A.counters[3], my_blocks);
+    }
 }
 
 // ================================================================ cooperative ranks (fy_collectives): kernels

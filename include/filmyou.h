@@ -240,6 +240,8 @@ typedef struct {
     double ms_tables;            /* RM2: p(i|C), per-rating values, packed CSR, chunk offsets and segment tables (between prepare and the M build) */
     double ms_mirror;            /* RM2: mirror pass of the symmetric walk (lower triangle of the co-rating matrix + its block maxima) */
     int64_t topn_select_users;   /* users whose list needed the radix-select fallback of the top-N kernel (more than 2048 candidates reached the lower bound) */
+    int64_t panel_clusters;      /* clusters built in column-panel mode (many clusters: only the popular columns of the co-rating matrix are stored) */
+    int64_t stray_blocks;        /* panel mode: surviving (user, block) pairs behind the panel, scored exactly from the sparse data */
 } fy_stats;
 int fy_result_stats(fy_result*, fy_stats* out);
 

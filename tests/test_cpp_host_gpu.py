@@ -56,6 +56,7 @@ def test_cpp_rank_through_the_compiled_rccl_transport(tmp_path, rm_golden):
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     rows = [l.split() for l in out.stdout.strip().splitlines()]
+    rows = [r for r in rows if len(r) == 4 and r[0].lstrip("-").isdigit()]          # (RCCL prints its version banner on stdout)
     got = {(int(a), int(b)): float(c) for a, b, c, _ in rows}
     exp = np.asarray(g["recommendations"])
     assert len(rows) == len(got) == 507

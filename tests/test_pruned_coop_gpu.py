@@ -243,3 +243,68 @@ def test_failed_multi_cluster_job_leaves_the_context_usable(forced):
         break
     assert failures >= 10, failures
     ctx.close()
+
+
+# ---------------------------------------------------------------- column-panel mode (many clusters)
+@pytest.mark.parametrize("shape,K,lam,top_n,panel_cols,max_ch", [("ml100k", 1, "0.1", 20, 256, 0), ("ml100k", 3, "0.5", 100, 512, 0),
+                                                                ("ml100k", 2, "0.1", 50, 1024, 0), ("tiny", 1, "0.1", 10, 256, 0),
+                                                                ("ml100k", 1, "0.0", 30, 256, 0), ("ml100k", 1, "0.1", 20, 256, 256),
+                                                                ("ml100k", 3, "0.5", 100, 256, 512), ("ml100k", 2, "0.1", 50, 512, 256)])
+def test_panel_mode_vs_oracle(forced, monkeypatch, shape, K, lam, top_n, panel_cols, max_ch):
+    """Panel mode stores only the first FY_PANEL_COLS columns of the co-rating rows plus 64-column block maxima; surviving
+    blocks behind the panel ("strays") are scored from the sparse data.  Forced onto small data (in production: >= 4 pruned
+    clusters per rank) with a panel of one or two blocks, so that most survivors are strays; the oracle decides.
+    max_ch > 0: rows cut into chunks of that many columns, so that the rows behind the panel are "tail rows" -- walked over
+    their first chunk(s) only, their bounds behind that from the block-compressed CSR (k_tail_blocks)."""
+    monkeypatch.setenv("FY_PANEL_MIN_CLUSTERS", "1")
+    monkeypatch.setenv("FY_PANEL_COLS", str(panel_cols))
+    if max_ch:
+        monkeypatch.setenv("FY_COOC_MAX_CH", str(max_ch))
+    P = pkg()
+    data, clustering, conf, ref = make(shape, K, lam, top_n)
+    ctx = P.Context(0)
+    rec = P.RM2Job(conf, ctx).run(data, clustering=clustering)
+    st = rec.stats
+    assert st["panel_clusters"] == K and st["blocks_total"] > 0 and st["prune_fallbacks"] == 0
+    if shape == "ml100k" and panel_cols == 256:
+        assert st["stray_blocks"] > 0, "no survivor behind the panel: the stray kernel did not run"
+    assert st["stray_blocks"] <= st["blocks_survived"]
+    assert_topn_matches(rec.rows(), ref, top_n)
+    ctx.close()
+
+
+def test_panel_mode_many_clusters_equals_full_pass(monkeypatch):
+    """The production switch: ML-1M-shaped data in 12 clusters with the production thresholds scaled down (clusters of >= 1024
+    items are pruned), panel mode chosen by the cluster count alone; all rows against the plain full pass (FY_PRUNE=0)."""
+    import os
+    monkeypatch.setenv("FY_PRUNE_MIN_ITEMS", "1024")
+    monkeypatch.setenv("FY_M24_MIN_ITEMS", "0")
+    monkeypatch.setenv("FY_PANEL_COLS", "1024")
+    monkeypatch.setenv("FY_COOC_MAX_CH", "1024")       # tail rows: everything behind column 1024
+    P = pkg()
+    S = synth()
+    u, i, s, facts = S.generate("ml1m")
+    u, i, s = u.numpy(), i.numpy(), s.numpy()
+    uu = np.unique(u)
+    K = 12
+    clustering = (uu, S.hash_clustering(uu, K))
+    conf = P.Configuration()
+    conf.set("lambda", "0.1")
+    conf.setInt("numberOfItems", facts["n_items"])
+    conf.setInt("numberOfClusters", K)
+    conf.setInt("numberOfRecommendations", 50)
+    ctx = P.Context(0)
+    panel = P.RM2Job(conf, ctx).run((u, i, s), clustering=clustering)
+    assert panel.stats["panel_clusters"] == K and panel.stats["blocks_total"] > 0
+    rp = panel.rows()
+    os.environ["FY_PRUNE"] = "0"
+    try:
+        full = P.RM2Job(conf, ctx).run((u, i, s), clustering=clustering)
+    finally:
+        del os.environ["FY_PRUNE"]
+    assert full.stats["panel_clusters"] == 0 and full.stats["blocks_total"] == 0
+    from fullsize_checks import assert_same_lists
+    from util import ATOL
+    n_diff, worst = assert_same_lists(rp, full.rows(), score_rtol=1e-5, score_atol=ATOL)
+    assert n_diff <= 4, n_diff
+    ctx.close()
