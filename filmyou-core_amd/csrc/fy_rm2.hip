@@ -487,6 +487,9 @@ struct MEpilogue {
     int32_t panel_cols;          // 0 = off
     float* __restrict__ Bmax64;  // [row][ldb64], 3 bytes per entry
     int64_t ldb64;
+    // [row][ldb64]: (second largest value of the sub-block, 24 bits) << 8 | column of the largest inside the sub-block; written with
+    // every non-zero Bmax64 entry.  k_bound_repair: a user who rated the column of the maximum is bounded by the second value
+    uint32_t* __restrict__ Brep;
     // tail-bound launches of panel mode (k_tail_blocks below): the "matrix" is a column range of Bmax64 -- ldm columns are
     // written per row, the rows are `pitch` elements apart (0: the pitch is the row length) and the 24-bit rounding goes up
     int64_t pitch;
@@ -581,15 +584,25 @@ __global__ void k_cooc_rm2(CoocArgs A, MEpilogue E, int n_items, int* __restrict
                     out3[3 * c4 + 2] = (v[2] >> 16) | (v[3] << 8);
                 }
                 if (E.Bmax64) {
-                    // 16 lanes = one 64-column sub-block
-                    uint32_t m = max(max(v[0], v[1]), max(v[2], v[3]));
+                    // 16 lanes = one 64-column sub-block.  Keys = value << 6 | column inside the sub-block (all different): the two
+                    // largest keys of the 64, by a four-step butterfly of (first, second) pairs
+                    const uint32_t cq = (uint32_t)((4 * c4) & 63);
+                    const uint32_t k0 = (v[0] << 6) | cq, k1 = (v[1] << 6) | (cq + 1), k2 = (v[2] << 6) | (cq + 2), k3 = (v[3] << 6) | (cq + 3);
+                    const uint32_t a1 = max(k0, k1), a2 = min(k0, k1), b1 = max(k2, k3), b2 = min(k2, k3);
+                    uint32_t t1 = max(a1, b1), t2 = max(min(a1, b1), max(a2, b2));
 #pragma unroll
-                    for (int o = 1; o < 16; o <<= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+                    for (int o = 1; o < 16; o <<= 1) {
+                        const uint32_t p1 = (uint32_t)__shfl_xor((int)t1, o, 64), p2 = (uint32_t)__shfl_xor((int)t2, o, 64);
+                        t2 = max(min(t1, p1), max(t2, p2));
+                        t1 = max(t1, p1);
+                    }
+                    const uint32_t m = t1 >> 6;
                     if ((threadIdx.x & 15) == 0 && m) {
                         uint8_t* bp = reinterpret_cast<uint8_t*>(E.Bmax64) + ((int64_t)mrow * E.ldb64 + (c4 >> 4)) * 3;
                         bp[0] = (uint8_t)m;
                         bp[1] = (uint8_t)(m >> 8);
                         bp[2] = (uint8_t)(m >> 16);
+                        if (E.Brep) E.Brep[(int64_t)mrow * E.ldb64 + (c4 >> 4)] = ((t2 >> 6) << 8) | (t1 & 63u);
                     }
                 }
                 if (E.Bmax) {
@@ -836,6 +849,8 @@ struct ScoreTune {
     int cooc_fx = 1;                   // fixed-point (ds_add_u64) accumulation in the packed walk
     int panel_min_clusters = 4;        // column-panel mode when at least this many clusters of the rank are pruned ones
     int panel_cols = 4096;             // columns of a row kept in panel mode (the seed columns and the popular blocks)
+    int score_heavy = 512;             // users with more ratings are walked by a whole workgroup of the scoring kernel (0 = off)
+    bool panel_repair = true;          // FY_PANEL_REPAIR=0: measurement only
     int panel_lanes = 2;               // job lanes when clusters run in panel mode (measured, 50 clusters: 1 lane 300 ms, 2: 213, 3: 230, 4: 240)
     int panel_max_ch = 6144;           // chunk width of the row kernel in panel mode: three workgroups per CU (measured, 50 clusters: 8192 -> 138 ms, 6144 -> 89, 4096 -> 93)
     double max_surv_frac = 0.25;       // a pruned batch whose surviving blocks exceed this fraction falls back to the full pass
@@ -856,6 +871,8 @@ static ScoreTune score_tune() {
     if (const char* e = getenv("FY_PANEL_MIN_CLUSTERS")) { int v = atoi(e); if (v >= 1) t.panel_min_clusters = v; }
     if (const char* e = getenv("FY_PANEL_COLS")) { int v = atoi(e); if (v >= 256) t.panel_cols = v; }
     if (const char* e = getenv("FY_PANEL_MAX_CH")) { int v = atoi(e); if (v >= 256) t.panel_max_ch = v; }
+    if (const char* e = getenv("FY_SCORE_HEAVY")) { int v = atoi(e); if (v >= 0) t.score_heavy = v; }
+    if (const char* e = getenv("FY_PANEL_REPAIR")) t.panel_repair = atoi(e) != 0;
     if (const char* e = getenv("FY_PANEL_LANES")) { int v = atoi(e); if (v >= 1 && v <= 8) t.panel_lanes = v; }
     if (const char* e = getenv("FY_PRUNE_MIN_ITEMS")) t.prune_min_items = atoi(e);
     if (const char* e = getenv("FY_SEED_CHUNKS")) { int v = atoi(e); if (v >= 0 && v <= 4) { t.seed_chunks = v; t.seed_forced = v > 0; } }
@@ -1211,10 +1228,12 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             // branch and bound
             DevBuf<float> Bmax, amax, bmax, UB, tau;
             DevBuf<float> Gp, Bmax64, amax64, bmax64;    // column-panel mode
+            DevBuf<uint32_t> Brep;
             DevBuf<uint16_t> surv;
             DevBuf<uint8_t> surv_mask;     // panel mode: which 64-column sub-blocks of a surviving block passed the bound
             DevBuf<int2> strayT;           // co-rater tables of k_score_stray
             DevBuf<int2> stray_items;
+            DevBuf<int32_t> n_heavy;       // k_count_heavy
             DevBuf<int32_t> n_quads, quad_prefix;
             DevBuf<int2> item_seg;
             DevBuf<int32_t> item_id;
@@ -1264,11 +1283,13 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 L.S.alloc(ctx, s_el);
                 L.overflow.alloc(ctx, ov_el);
                 L.any_overflow.alloc(ctx, 1);
+                L.n_heavy.alloc(ctx, 1);
                 L.Bmax.alloc(ctx, bm_el);
                 L.amax.alloc(ctx, am_el);
                 L.bmax.alloc(ctx, am_el);
                 L.Gp.alloc(ctx, gp_el);
                 L.Bmax64.alloc(ctx, b64_el);
+                L.Brep.alloc(ctx, gp_el > 1 ? b64_el * 4 / 3 + 4 : 1);     // (b64_el counts floats for 3-byte entries)
                 L.amax64.alloc(ctx, a64_el);
                 L.bmax64.alloc(ctx, a64_el);
                 L.UB.alloc(ctx, ub_el);
@@ -1281,7 +1302,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 L.item_id.alloc(ctx, is_el);
             }
         }
-        DevBuf<unsigned long long> prune_counters(ctx, 4);   // [0] surviving blocks, [1] log terms evaluated by the three pruned passes, [2] users sent to k_topn_select, [3] stray blocks (panel mode)
+        DevBuf<unsigned long long> prune_counters(ctx, 5);   // [0] surviving blocks, [1] log terms evaluated by the three pruned passes, [2] users sent to k_topn_select, [3] stray blocks (panel mode)
         prune_counters.zero();
         int64_t prune_blocks_total = 0, prune_seed_terms_cols = 0, coop_survived = 0, fallback_survived = 0;
         for (auto& p : plans) any_coop = any_coop || p.coop;
@@ -1371,7 +1392,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             CA.fx_scale = fxk >= 0 ? std::ldexp(1.0, fxk) : 0.0;
             MEpilogue ME{L.M.get(), ldm, (float)((1.0 - lambda) * (1.0 - lambda)), fxk >= 0 ? std::ldexp((1.0 - lambda) * (1.0 - lambda), -fxk) : 0.0,
                          pack24 ? 1 : 0, (p.prune && !p.panel) ? L.Bmax.get() : nullptr, p.ldb, 0,
-                         p.panel ? p.panel_cols : 0, p.panel ? L.Bmax64.get() : nullptr, p.ldb64};
+                         p.panel ? p.panel_cols : 0, p.panel ? L.Bmax64.get() : nullptr, p.ldb64, p.panel ? L.Brep.get() : nullptr};
             if (p.panel) {
                 R->st.panel_clusters++;
                 ME.M = L.Gp.get();
@@ -1390,7 +1411,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                             csr_x.get(), pbase, sbase, Ic, p.tail_width, 1, p.p_eff, Ic - p.p_eff, p.q0, p.nq, nullptr, 0, y_pk.get(), nullptr, CA.pk_bytes};
                 CB.fx_scale = CA.fx_scale;
                 MEpilogue MB{reinterpret_cast<float*>(reinterpret_cast<char*>(L.Bmax64.get()) + (size_t)(p.p_eff / 64) * 3), p.tail_width, ME.w2, ME.fx_inv, 1,
-                             nullptr, 0, 0, 0, nullptr, 0, p.ldb64, 1};
+                             nullptr, 0, 0, 0, nullptr, 0, nullptr, p.ldb64, 1};
                 k_item_list<<<grid_for((int64_t)(Ic - p.p_eff)), 256, 0, ls>>>(CB, L.item_seg.get(), L.item_id.get());
                 FY_KERNEL_CHECK();
                 CB.item_seg = L.item_seg.get();
@@ -1431,6 +1452,10 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 SA.csr_idx = P.csr_idx.get(); SA.csr_e = csr_e.get(); SA.csr_q = csr_q.get();
                 SA.pvpi = pvpi.get(); SA.n_out = n_out.get(); SA.slot_lo = lo; SA.slot_base = sbase; SA.slot0 = s0; SA.n_users = nb;
                 SA.S = Sx; SA.ldS = ldSx; SA.n_slices = n_slices; SA.n_chunks = nchunks;
+                if (tune.score_heavy > 0) {     // (stream order: every scoring launch of the batch follows)
+                    k_count_heavy<<<1, 64, 0, ls>>>(P.rowptr.get() + s0, nb, tune.score_heavy, L.n_heavy.get());
+                    SA.n_heavy = L.n_heavy.get();
+                }
                 return SA;
             };
             // the plain full pass over a range of users: every log term, like the reference's loop (AbstractRM2Reducer.java:332-356)
@@ -1497,6 +1522,14 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                     k_bound_select<<<grid_for((int64_t)nb * 64, 256), 256, 0, ls>>>(L.UB.get(), p.ldb, p.nblk, seed_blocks, L.tau.get(), pvpi.get() + (s0 - lo), nb,
                                                                                    L.surv.get(), L.n_quads.get());
                 FY_KERNEL_CHECK();
+                if (p.panel && tune.panel_repair) {
+                    // (4b) sub-blocks that hold an item the user rated: bound again without the user's own co-ratings
+                    RepairArgs RA{L.surv.get(), L.surv_mask.get(), L.n_quads.get(), bld, nb, s0, lo, p.p_eff, Ic, P.rowptr.get(), P.csr_idx.get(),
+                                  csr_x.get(), csr_e.get(), csr_q.get(), L.Bmax64.get(), L.Brep.get(), p.ldb64, L.amax64.get(), L.bmax64.get(),
+                                  L.tau.get(), pvpi.get(), (float)((1.0 - lambda) * (1.0 - lambda)), prune_counters.get()};
+                    k_bound_repair<<<grid_for((int64_t)nb * 64, 256), 256, 0, ls>>>(RA);
+                    FY_KERNEL_CHECK();
+                }
                 exclusive_scan_i32(ctx, L.n_quads.get(), L.quad_prefix.get(), (size_t)nb + 1, ls);
                 // (5) exact scores of the survivors, packed: 256 floats per surviving block at entry quad_prefix[u] + k
                 int32_t hv[3] = {0, 0, 0};   // survivors, first / last CSR entry of the batch
@@ -1576,11 +1609,12 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
         }
         // (the guard's destructor drains the lanes and the main stream before any buffer of this scope is released)
         {
-            unsigned long long hc[4];
-            d2h(ctx, hc, prune_counters.get(), 4);
+            unsigned long long hc[5];
+            d2h(ctx, hc, prune_counters.get(), 5);
             sync(ctx);
             R->st.topn_select_users = (int64_t)hc[2];
             R->st.stray_blocks = (int64_t)hc[3];
+            R->st.bound_repairs = (int64_t)hc[4];
             R->st.blocks_survived = (int64_t)hc[0] + coop_survived + fallback_survived;
             R->st.blocks_total = prune_blocks_total;
             R->st.log_terms_evaluated = prune_blocks_total ? (int64_t)hc[1] + prune_seed_terms_cols : 0;

@@ -45,7 +45,19 @@ struct ScoreArgs {
     float* __restrict__ S2;
     int64_t ldS2;
     int32_t no_mask2;
+    // the first *n_heavy users of the batch (slots are in descending order of degree) are walked by the four waves of a
+    // workgroup together, a quarter of the list each; nullptr = none
+    const int32_t* __restrict__ n_heavy;
 };
+// number of users at the head of a batch (descending degree) with more than `thresh` ratings
+__global__ void k_count_heavy(const int32_t* __restrict__ rowptr /* of the batch's first slot */, int32_t n_users, int32_t thresh,
+                              int32_t* __restrict__ out) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int lo = 0, hi = n_users;       // first u with degree <= thresh
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (rowptr[mid + 1] - rowptr[mid] > thresh) lo = mid + 1; else hi = mid; }
+        *out = lo;
+    }
+}
 
 __device__ __forceinline__ float fy_log2(float x) { return __builtin_amdgcn_logf(x); }   // v_log_f32
 
@@ -121,16 +133,8 @@ __global__ __launch_bounds__(256) void k_score(const float* __restrict__ M_, con
     const double LN2 = 0.69314718055994530942;
     const float qnan = __builtin_nanf("");
     const int row_mul = A.row_mul ? A.row_mul : 1;
-    for (int u = slice * 4 + wave; u < A.n_users; u += A.n_slices * 4) {
-        const int slot = A.slot0 + u;
-        if (n_out_[slot - A.slot_lo] == 0) continue;
-        const int32_t* __restrict__ ro = rb_off_ + (slot - A.slot_base);
-        const int beg = ro[0], end = ro[1];
-        float* __restrict__ dst = Ssel + (int64_t)u * ldS_sel + col;
-        double t[VEC];
-#pragma unroll
-        for (int v = 0; v < VEC; v++) t[v] = 0.0;
-        unsigned mask = 0;
+    // the log terms of the rows [beg, end) of one user's list, added to t / mask
+    auto walk = [&](int beg, int end, double* t, unsigned& mask) __attribute__((always_inline)) {
         // batches of 8 rows: all eight segment loads are issued before the first use, also for a short tail
         // (out-of-range slots re-load the last valid row -- an L1 hit -- and are skipped by a wave-uniform test)
         for (int k = beg; k < end; k += SB) {
@@ -167,6 +171,8 @@ __global__ __launch_bounds__(256) void k_score(const float* __restrict__ M_, con
 #pragma unroll
             for (int v = 0; v < VEC; v++) t[v] += (double)p[v];
         }
+    };
+    auto store = [&](int u, int slot, const double* t, unsigned mask) __attribute__((always_inline)) {
         V o;
         float* ov = reinterpret_cast<float*>(&o);
         const double base = pvpi_[slot - A.slot_lo];
@@ -175,7 +181,53 @@ __global__ __launch_bounds__(256) void k_score(const float* __restrict__ M_, con
 #pragma unroll
         for (int v = 0; v < VEC; v++)
             if ((mask >> v) & 1u || col + v >= Ic_sel) ov[v] = qnan;
-        *reinterpret_cast<V*>(dst) = o;
+        *reinterpret_cast<V*>(Ssel + (int64_t)u * ldS_sel + col) = o;
+    };
+    // ---- heavy users (the head of the batch): one per workgroup, a quarter of the list per wave.  A user with 3 000 ratings on
+    // ONE wave (375 batches, one round trip each) was what a cluster's launch waited for: 1.1 ms for a 3 000-user cluster
+    // whose average wave was done after 0.1 ms.
+    __shared__ double sh_t[3][64][VEC];
+    __shared__ unsigned sh_mask[3][64];
+    const int n_heavy = A.n_heavy ? min(*A.n_heavy, A.n_users) : 0;
+    for (int u = slice; u < n_heavy; u += A.n_slices) {            // block-uniform
+        const int slot = A.slot0 + u;
+        if (n_out_[slot - A.slot_lo] == 0) continue;
+        const int32_t* __restrict__ ro = rb_off_ + (slot - A.slot_base);
+        const int beg = ro[0], end = ro[1];
+        const int quarter = (((end - beg + 3) >> 2) + SB - 1) / SB * SB;   // whole batches per wave
+        const int wb = min(end, beg + wave * quarter), we = min(end, wb + quarter);
+        double t[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; v++) t[v] = 0.0;
+        unsigned mask = 0;
+        walk(wb, we, t, mask);
+        if (wave > 0) {
+#pragma unroll
+            for (int v = 0; v < VEC; v++) sh_t[wave - 1][lane][v] = t[v];
+            sh_mask[wave - 1][lane] = mask;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            for (int x = 0; x < 3; x++) {
+#pragma unroll
+                for (int v = 0; v < VEC; v++) t[v] += sh_t[x][lane][v];
+                mask |= sh_mask[x][lane];
+            }
+            store(u, slot, t, mask);
+        }
+        __syncthreads();   // sh_t is free again
+    }
+    for (int u = n_heavy + slice * 4 + wave; u < A.n_users; u += A.n_slices * 4) {
+        const int slot = A.slot0 + u;
+        if (n_out_[slot - A.slot_lo] == 0) continue;
+        const int32_t* __restrict__ ro = rb_off_ + (slot - A.slot_base);
+        const int beg = ro[0], end = ro[1];
+        double t[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; v++) t[v] = 0.0;
+        unsigned mask = 0;
+        walk(beg, end, t, mask);
+        store(u, slot, t, mask);
     }
 }
 
@@ -670,6 +722,105 @@ __global__ __launch_bounds__(256) void k_bound_select_sub(const float* __restric
         }
         if (lane == 0) n_surv[u] = count;
     }
+}
+
+// Bound repair (panel mode).  The bound of user u for a 64-column sub-block takes, for every rated item j, the LARGEST G[j][i] of
+// the sub-block -- also when that i is an item u rated itself, which is no candidate.  For a user with a few dozen ratings this
+// is the rule, not the exception: G[j][i0] of a rated tail item i0 carries u's own x_ui0 x_uj (large: x = r / s_u) for every j
+// of the list, so i0's sub-block is bounded high in every term while its 63 real candidates score ~100 below the threshold.
+// Measured (ML-25M shape, 50 clusters): ALL surviving sub-blocks behind the panel and half of those inside it are of this kind.
+// For the surviving sub-blocks that hold an item of the user's list the bound is therefore evaluated again with
+//     exact rows (Bmax64 from the row kernel):  the second largest value of the sub-block when the column of the largest is
+//                                               rated by u (Brep) -- an upper bound of every other column;
+//     tail rows behind p_eff (k_tail_blocks):   the stored sum over raters minus u's own term x_uj * max_{i in sub-block} x_ui
+//                                               (u contributes nothing to a column it did not rate),
+// and the sub-block is dropped when the new bound stays below the threshold; blocks left without sub-blocks are removed from
+// the user's list.  One wave per user; users with more than REPAIR_MAX_LIST ratings are left alone (their own terms are small).
+constexpr int REPAIR_MAX_LIST = 256;
+struct RepairArgs {
+    uint16_t* __restrict__ surv;
+    uint8_t* __restrict__ surv_mask;
+    int32_t* __restrict__ n_surv;
+    int64_t ldsurv;
+    int32_t n_users, slot0, slot_lo, p_eff, Ic;
+    const int32_t* __restrict__ rowptr;
+    const int32_t* __restrict__ csr_idx;
+    const float* __restrict__ csr_x;
+    const float* __restrict__ csr_e;
+    const float* __restrict__ csr_q;
+    const float* __restrict__ Bmax64;      // 3 bytes per entry
+    const uint32_t* __restrict__ Brep;
+    int64_t ldb64;
+    const float* __restrict__ amax64;
+    const float* __restrict__ bmax64;
+    const float* __restrict__ tau;         // [u]
+    const double* __restrict__ pvpi;       // [slot - slot_lo]
+    float w2;
+    unsigned long long* __restrict__ counters;   // [4] sub-blocks dropped
+};
+__device__ __forceinline__ float fy_load24(const float* __restrict__ base3, int64_t entry) {
+    const uint8_t* __restrict__ b = reinterpret_cast<const uint8_t*>(base3) + entry * 3;
+    const uint32_t v = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16);
+    return __uint_as_float(v << 7);
+}
+__global__ __launch_bounds__(256) void k_bound_repair(RepairArgs A) {
+    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    const double LN2 = 0.69314718055994530942;
+    unsigned long long dropped = 0;
+    for (int u = blockIdx.x * wpb + (threadIdx.x >> 6); u < A.n_users; u += gridDim.x * wpb) {
+        const int ns = A.n_surv[u];
+        const int slot = A.slot0 + u;
+        const int r0 = A.rowptr[slot], r1 = A.rowptr[slot + 1];
+        if (ns == 0 || r1 - r0 > REPAIR_MAX_LIST) continue;
+        uint16_t* __restrict__ mine = A.surv + (int64_t)u * A.ldsurv;
+        uint8_t* __restrict__ mask_of = A.surv_mask + (int64_t)u * A.ldsurv;
+        const float t = A.tau[u];
+        const double base = A.pvpi[slot - A.slot_lo];
+        int kept = 0;
+        for (int k = 0; k < ns; k++) {                              // wave-uniform
+            const int blk = (int)mine[k];
+            unsigned mask = mask_of[k];
+            for (int qb = 0; qb < 4; qb++) {
+                if (!((mask >> qb) & 1u)) continue;
+                const int sb = 4 * blk + qb;
+                const int c0 = sb * 64;
+                // the user's items inside the sub-block: the largest x among them (0: none -- the bound stands)
+                float ymax = 0.f;
+                for (int f = r0 + lane; f < r1; f += 64) {
+                    const unsigned d = (unsigned)(A.csr_idx[f] - c0);
+                    if (d < 64u) ymax = fmaxf(ymax, A.csr_x[f]);
+                }
+                for (int o = 32; o > 0; o >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, o, 64));
+                if (ymax == 0.f) continue;
+                const float am = A.amax64[sb], bm = A.bmax64[sb];
+                double sum = 0.0;
+                for (int f = r0 + lane; f < r1; f += 64) {
+                    const int j = A.csr_idx[f];
+                    float g = fy_load24(A.Bmax64, (int64_t)j * A.ldb64 + sb);
+                    if (g > 0.f) {
+                        if (j >= A.p_eff && c0 >= A.p_eff) {
+                            g = fmaxf(0.f, g - A.w2 * A.csr_x[f] * ymax * 0.999999f);
+                        } else {
+                            const uint32_t rep = A.Brep[(int64_t)j * A.ldb64 + sb];
+                            const int col = c0 + (int)(rep & 63u);
+                            int l = r0, h = r1;                     // did the user rate the column of the maximum?
+                            while (l < h) { const int m = (l + h) >> 1; if (A.csr_idx[m] < col) l = m + 1; else h = m; }
+                            if (l < r1 && A.csr_idx[l] == col) g = __uint_as_float((rep >> 8) << 7);
+                        }
+                    }
+                    sum += (double)fy_log2(fmaf(A.csr_q[f], bm, fmaf(am, A.csr_e[f], g)));
+                }
+                for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+                if (!fy_bound_keeps((float)(base + LN2 * sum), t, (float)base)) { mask &= ~(1u << qb); dropped++; }
+            }
+            if (mask) {                                             // compaction in place (kept <= k)
+                if (lane == 0) { mine[kept] = (uint16_t)blk; mask_of[kept] = (uint8_t)mask; }
+                kept++;
+            }
+        }
+        if (lane == 0) A.n_surv[u] = kept;
+    }
+    if (lane == 0 && dropped) atomicAdd(&A.counters[4], dropped);
 }
 
 // Exact scores of the surviving blocks that lie behind the column panel ("strays"), from the sparse data alone:

@@ -242,6 +242,7 @@ typedef struct {
     int64_t topn_select_users;   /* users whose list needed the radix-select fallback of the top-N kernel (more than 2048 candidates reached the lower bound) */
     int64_t panel_clusters;      /* clusters built in column-panel mode (many clusters: only the popular columns of the co-rating matrix are stored) */
     int64_t stray_blocks;        /* panel mode: surviving (user, block) pairs behind the panel, scored exactly from the sparse data */
+    int64_t bound_repairs;       /* panel mode: 64-column sub-blocks dropped by the second bound (without the user's own co-ratings) */
 } fy_stats;
 int fy_result_stats(fy_result*, fy_stats* out);
 

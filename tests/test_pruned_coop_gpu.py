@@ -296,6 +296,7 @@ def test_panel_mode_many_clusters_equals_full_pass(monkeypatch):
     ctx = P.Context(0)
     panel = P.RM2Job(conf, ctx).run((u, i, s), clustering=clustering)
     assert panel.stats["panel_clusters"] == K and panel.stats["blocks_total"] > 0
+    assert panel.stats["bound_repairs"] > 0, "the second bound (without the user's own co-ratings) dropped nothing"
     rp = panel.rows()
     os.environ["FY_PRUNE"] = "0"
     try:
