@@ -65,6 +65,8 @@ struct CoocArgs {
     // column-panel mode (fy_rm2.hip): the rows from tail_row0 on have items only for their first tail_chunks chunks
     // (tail_chunks = 0: every row has all its chunks)
     int32_t tail_row0, tail_chunks;
+    // RM2 row kernel: consecutive items a workgroup takes from the item counter per atomic (0 = 1; fy_rm2.hip: cooc_item_grab)
+    int32_t item_grab;
 };
 
 #ifndef FY_COOC_NB
@@ -341,6 +343,7 @@ __attribute__((unused)) static __global__ void k_item_list(CoocArgs A, int2* __r
 
 // segment table of one cluster from its chunk_off table; returns the number of segments (synchronises once)
 struct SegTable {
+    int64_t n_seg = 0;     // segments in the table
     DevBuf<int32_t> ptr;   // nch * (nq + 1)
     DevBuf<int2> seg;
     DevBuf<float> w;

@@ -459,6 +459,7 @@ void build_segments(Context* ctx, const int32_t* csc_slot, const float* csc_w, c
     int32_t total = 0;   // the last count is 0 by construction: the last prefix is the total
     FY_HIP(hipMemcpyAsync(&total, out.ptr.get() + (np - 1), sizeof(int32_t), hipMemcpyDeviceToHost, st));
     FY_HIP(hipStreamSynchronize(st));
+    out.n_seg = total;
     out.seg.alloc(ctx, (size_t)total);
     out.w.alloc(ctx, (size_t)total);
     if ((int64_t)nch * nq > 0) {
@@ -516,10 +517,29 @@ __global__ void k_cooc_rm2(CoocArgs A, MEpilogue E, int n_items, int* __restrict
     for (int t = threadIdx.x; t < CHp; t += blockDim.x) acc[t] = (ACC)0;
     // items are handed out by a global counter: the chunks of a row differ a lot in weight (chunk 0 holds the popular
     // columns), a static stride would leave three quarters of the workgroups idle behind the chunk-0 owners
+    // The counter hands out ITEM_GRAB consecutive items per atomic: one address takes ~82 M device-scope atomics per second on
+    // this part (every launch of this kernel over short items ran at exactly that item rate, whatever the chunk width or the
+    // walk: 99 k items in 1.20 ms, 46 k in 0.57 ms, 364 k in 4.4 ms), and in a cluster of 3 000 users an item is ~60 segments.
+    // The base of the batch after the current one is fetched when a batch is started: its latency never shows.
+    // Rows with thousands of segments (one cluster of 162 000 users) keep one item per atomic: eight consecutive items are the
+    // chunks of ONE row there, and a batch of them unbalances the tail (7.9 -> 12.7 ms).
+    const int ITEM_GRAB = A.item_grab > 0 ? A.item_grab : 1;
     int next = 0, next2 = 0;      // thread 0 only: the next item and the one after it
+    int g_cur = 0, g_end = 0, g_next = 0;
+    auto grab = [&]() __attribute__((always_inline)) {
+        if (g_cur == g_end) {
+            g_cur = g_next;
+            g_end = g_cur + ITEM_GRAB;
+            g_next = atomicAdd(next_item, ITEM_GRAB);
+        }
+        return g_cur++;
+    };
     if (threadIdx.x == 0) {
-        const int first = atomicAdd(next_item, 1);
-        next = atomicAdd(next_item, 1);
+        g_cur = atomicAdd(next_item, ITEM_GRAB);
+        g_end = g_cur + ITEM_GRAB;
+        g_next = atomicAdd(next_item, ITEM_GRAB);
+        const int first = grab();
+        next = grab();
         const int2 se = first < n_items ? A.item_seg[first] : make_int2(0, 0);
         sh_item = first;
         sh_s0 = se.x;
@@ -538,7 +558,7 @@ __global__ void k_cooc_rm2(CoocArgs A, MEpilogue E, int n_items, int* __restrict
         int2 se_next = make_int2(0, 0);
         int id_next = 0;
         if (threadIdx.x == 0) {
-            next2 = atomicAdd(next_item, 1);                         // arrives during this item's work
+            next2 = grab();
             if (next < n_items) { se_next = A.item_seg[next]; id_next = A.item_id[next]; }   // address known since the previous item
         }
         const int lrow = id >> 8;
@@ -852,7 +872,7 @@ struct ScoreTune {
     int score_heavy = 512;             // users with more ratings are walked by a whole workgroup of the scoring kernel (0 = off)
     bool panel_repair = true;          // FY_PANEL_REPAIR=0: measurement only
     int panel_lanes = 2;               // job lanes when clusters run in panel mode (measured, 50 clusters: 1 lane 300 ms, 2: 213, 3: 230, 4: 240)
-    int panel_max_ch = 6144;           // chunk width of the row kernel in panel mode: three workgroups per CU (measured, 50 clusters: 8192 -> 138 ms, 6144 -> 89, 4096 -> 93)
+    int panel_max_ch = 4096;           // chunk width of the row kernel in panel mode: five workgroups per CU (measured, 50 clusters, row kernel ms: 8192 -> 67, 6144 -> 54, 4096 -> 46)
     double max_surv_frac = 0.25;       // a pruned batch whose surviving blocks exceed this fraction falls back to the full pass
 };
 static ScoreTune score_tune() {
@@ -898,6 +918,9 @@ static int fx_exponent(const float* bounds3) {
 
 // launch shape of the RM2 row kernel: as many workgroups per CU as the LDS accumulators allow (fp32: two for ML-25M's
 // 19 712-column chunks), 2048 threads per CU at most
+// items per atomic of the row kernel's work counter: 8 where an item is short (< 256 segments on average), else 1
+static int cooc_item_grab(int64_t n_seg, int64_t n_items) { return n_items > 0 && n_seg / n_items < 256 ? 8 : 1; }
+
 static void launch_cooc_rm2(Context* ctx, const ScoreTune& tune, bool use_pk, const CoocArgs& CA, const MEpilogue& ME, int n_items,
                             int32_t* counter, hipStream_t st) {
     if (n_items <= 0) return;
@@ -1417,6 +1440,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 CB.item_seg = L.item_seg.get();
                 CB.item_id = L.item_id.get();
                 FY_HIP(hipMemsetAsync(L.any_overflow.get(), 0, sizeof(int32_t), ls));
+                CB.item_grab = cooc_item_grab(segs_tail[pi].n_seg, Ic - p.p_eff);
                 launch_cooc_rm2(ctx, tune, use_pk, CB, MB, Ic - p.p_eff, L.any_overflow.get(), ls);
                 R->st.cooc_launches++;
                 CA.tail_row0 = p.p_eff;
@@ -1431,6 +1455,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 CA.item_seg = L.item_seg.get();
                 CA.item_id = L.item_id.get();
                 FY_HIP(hipMemsetAsync(L.any_overflow.get(), 0, sizeof(int32_t), ls));   // reused as the item counter
+                CA.item_grab = cooc_item_grab(segs[pi].n_seg, n_items);
                 launch_cooc_rm2(ctx, tune, use_pk, CA, ME, n_items, L.any_overflow.get(), ls);
             }
             t_cooc.end(sp, ls);
