@@ -1335,41 +1335,50 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
         for (auto& p : plans) any_tail = any_tail || p.p_eff < p.Ic;
         DevBuf<uint32_t> y_pk(ctx, any_tail ? (size_t)P.nnz : 1);     // k_tail_blocks
         span_tables = t_tables.begin();
-        {
-            size_t co_all = 1;
-            bool any_half = false;
-            for (auto& p : plans) { co_all = std::max(co_all, (size_t)p.Uc * (p.nch + 1)); any_half = any_half || p.half || p.p_eff < p.Ic; }
-            DevBuf<int32_t> co_tmp(ctx, co_all);
-            DevBuf<int32_t> csc_rank(ctx, any_half ? (size_t)P.nnz : 1);     // row (rank inside its cluster) of every CSC entry
-            if (any_half) {
-                k_csc_rank<<<grid_for(P.nnz), 256, 0, st>>>(P.nnz, P.csc_pair.get(), P.pair_rank.get(), csc_rank.get());
+        size_t co_all = 1;
+        bool any_half = false;
+        for (auto& p : plans) { co_all = std::max(co_all, (size_t)p.Uc * (p.nch + 1)); any_half = any_half || p.half || p.p_eff < p.Ic; }
+        DevBuf<int32_t> csc_rank(ctx, any_half ? (size_t)P.nnz : 1);     // row (rank inside its cluster) of every CSC entry
+        if (any_half) {
+            k_csc_rank<<<grid_for(P.nnz), 256, 0, st>>>(P.nnz, P.csc_pair.get(), P.pair_rank.get(), csc_rank.get());
+            FY_KERNEL_CHECK();
+        }
+        // first / last CSR entry of every planned cluster (slots are cluster-major): one round trip for all of them
+        std::vector<int32_t> csr_range(2 * plans.size() + 2, 0);
+        for (size_t pi = 0; pi < plans.size(); pi++) {
+            d2h(ctx, &csr_range[2 * pi], P.rowptr.get() + plans[pi].sbase, 1);
+            d2h(ctx, &csr_range[2 * pi + 1], P.rowptr.get() + plans[pi].sbase + plans[pi].Uc, 1);
+        }
+        sync(ctx);
+        // One cluster's tables: packed CSR with chunk-relative indices for its CH, chunk offsets, segment table (+ the tail rows'
+        // one-chunk table over the block-compressed CSR in panel mode).  `co` = scratch for p.Uc * (p.nch + 1) offsets.
+        auto build_tables = [&](size_t pi, hipStream_t ts, int32_t* co) {
+            const Plan& p = plans[pi];
+            const int32_t f0 = csr_range[2 * pi], f1 = csr_range[2 * pi + 1];
+            if (use_pk && f1 > f0) {
+                k_pack_csr<<<grid_for(f1 - f0), 256, 0, ts>>>(f0, f1, p.CH, P.csr_idx.get(), P.csr_r.get(), csr_pk.get());
                 FY_KERNEL_CHECK();
             }
-            for (size_t pi = 0; pi < plans.size(); pi++) {
-                const Plan& p = plans[pi];
-                if (use_pk) {   // the cluster's CSR range (slots are cluster-major), chunk-relative indices for its CH
-                    int32_t fr[2];
-                    d2h(ctx, &fr[0], P.rowptr.get() + p.sbase, 1);
-                    d2h(ctx, &fr[1], P.rowptr.get() + p.sbase + p.Uc, 1);
-                    sync(ctx);
-                    if (fr[1] > fr[0]) {
-                        k_pack_csr<<<grid_for(fr[1] - fr[0]), 256, 0, st>>>(fr[0], fr[1], p.CH, P.csr_idx.get(), P.csr_r.get(), csr_pk.get());
-                        FY_KERNEL_CHECK();
-                    }
-                }
-                if (p.coop) continue;
-                build_chunk_offsets(ctx, P.rowptr.get(), P.csr_idx.get(), p.sbase, p.Uc, p.CH, p.nch, co_tmp.get());
-                build_segments(ctx, P.csc_slot.get(), use_pk ? csc_x_over_s.get() : csc_x.get(), co_tmp.get(), p.sbase, p.q0, p.nq, p.nch, segs[pi], nullptr,
-                               p.half ? csc_rank.get() : nullptr, P.csr_idx.get(), p.CH);
-                if (p.p_eff < p.Ic) {   // panel mode: the tail rows' one-chunk table over the block-compressed CSR
-                    k_tail_blocks<<<grid_for((int64_t)p.Uc * 64), 256, 0, st>>>(p.sbase, p.Uc, p.p_eff, P.rowptr.get(), P.csr_idx.get(), P.csr_r.get(),
-                                                                              y_pk.get(), co_tmp.get());
-                    FY_KERNEL_CHECK();
-                    build_segments(ctx, P.csc_slot.get(), csc_x_over_s.get(), co_tmp.get(), p.sbase, p.q0, p.nq, 1, segs_tail[pi], nullptr, nullptr, nullptr, 0,
-                                   csc_rank.get(), p.p_eff);
-                }
+            if (p.coop) return;
+            build_chunk_offsets(ctx, P.rowptr.get(), P.csr_idx.get(), p.sbase, p.Uc, p.CH, p.nch, co, ts);
+            build_segments(ctx, P.csc_slot.get(), use_pk ? csc_x_over_s.get() : csc_x.get(), co, p.sbase, p.q0, p.nq, p.nch, segs[pi], ts,
+                           p.half ? csc_rank.get() : nullptr, P.csr_idx.get(), p.CH);
+            if (p.p_eff < p.Ic) {
+                k_tail_blocks<<<grid_for((int64_t)p.Uc * 64), 256, 0, ts>>>(p.sbase, p.Uc, p.p_eff, P.rowptr.get(), P.csr_idx.get(), P.csr_r.get(),
+                                                                          y_pk.get(), co);
+                FY_KERNEL_CHECK();
+                build_segments(ctx, P.csc_slot.get(), csc_x_over_s.get(), co, p.sbase, p.q0, p.nq, 1, segs_tail[pi], ts, nullptr, nullptr, 0,
+                               csc_rank.get(), p.p_eff);
             }
-        }
+        };
+        // With several lanes and no cooperative cluster the tables are built by the lane that uses them, right before the row
+        // kernel: table building is mostly host round trips (sizes of the segment tables), 23 ms for 50 clusters during which the
+        // chip idled; in a lane they hide behind the other lanes' kernels.  (A cooperative job packs every cluster's CSR up front.)
+        const bool lazy_tables = NS > 1 && !any_coop;
+        std::vector<DevBuf<int32_t>> co_lane((size_t)NS);
+        for (auto& b : co_lane) b.alloc(ctx, co_all);
+        if (!lazy_tables)
+            for (size_t pi = 0; pi < plans.size(); pi++) build_tables(pi, st, co_lane[0].get());
         t_tables.end(span_tables);
         // Error path: anything thrown below (an allocation, a launch, a collective) unwinds the lanes' buffers, the segment
         // tables and the per-job arrays back into the caching allocator while kernels of OTHER lanes may still be reading
@@ -1407,6 +1416,11 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 continue;
             }
 
+            if (lazy_tables) {
+                const size_t stb = t_tables.begin(ls);
+                build_tables(pi, ls, co_lane[pi % NS].get());
+                t_tables.end(stb, ls);
+            }
             // -- M build
             CoocArgs CA{P.rank_pair.get(), P.pair_start.get(), segs[pi].ptr.get(), segs[pi].seg.get(), segs[pi].w.get(), P.csr_idx.get(),
                         csr_x.get(), pbase, sbase, Ic, CH, nch, 0, Ic, p.q0, p.nq, nullptr, 0, use_pk ? csr_pk.get() : nullptr, nullptr,
