@@ -254,6 +254,9 @@ def main():
                 "algorithmic_bytes_per_launch": 8.0 * unordered_pairs / max(1, st["cooc_launches"]),
                 "share_of_step": ms_cooc / ms_per_step if ms_per_step > 0 else None}
     roofline["frac"] = roofline["achieved"] / HBM_PEAK_GBS
+    if roofline["frac"] > 1.0:
+        roofline["note"] = ("SURVEY 8d's unit (8 B per unordered co-rating pair) overstates this launch: the packed symmetric walk reads 4 B per unordered "
+                            "pair and the column chunks stay in L2 / Infinity Cache; the fraction is the model's, not measured HBM traffic")
     # the symmetric walk leaves the lower triangle to the mirror pass (k_mirror_tiles / k_mirror_diag): the matrix build as a whole
     ms_mirror = mean("ms_mirror")
     roofline["with_mirror_pass"] = {"ms": ms_cooc + ms_mirror, "achieved": 8.0 * unordered_pairs / ((ms_cooc + ms_mirror) * 1e-3) / 1e9 if ms_cooc > 0 else 0.0,
@@ -313,7 +316,9 @@ def main():
                 reg[name] = {"value": r2 / (el2 / 2), "unit": "recs/s", "ms_per_step": 1e3 * el2 / 2, "lists_per_s": u2 / (el2 / 2),
                              "log_terms_per_s": t2 / (el2 / 2),
                              "phase_ms": {k: float(np.mean([x[k] for x in s2])) for k in ("ms_prepare", "ms_tables", "ms_cooc", "ms_mirror", "ms_score", "ms_topn", "ms_total")},
-                             "pruned": bool(s2[-1]["blocks_total"] > 0)}
+                             "pruned": bool(s2[-1]["blocks_total"] > 0), "panel_clusters": int(s2[-1]["panel_clusters"]),
+                             "blocks_survived_frac": (s2[-1]["blocks_survived"] / s2[-1]["blocks_total"]) if s2[-1]["blocks_total"] else None,
+                             "stray_blocks": int(s2[-1]["stray_blocks"]), "bound_repairs": int(s2[-1]["bound_repairs"])}
             except RuntimeError as e:
                 reg[name] = {"error": str(e)}
         out["reference_regime"] = reg
