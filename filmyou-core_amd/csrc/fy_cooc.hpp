@@ -67,7 +67,13 @@ struct CoocArgs {
     int32_t tail_row0, tail_chunks;
     // RM2 row kernel: consecutive items a workgroup takes from the item counter per atomic (0 = 1; fy_rm2.hip: cooc_item_grab)
     int32_t item_grab;
+    // RM2 row kernel: the accumulators of a chunk are stored in four PLANES, column c at (c & 3) * acc_quarter + (c >> 2), so that
+    // the epilogue -- every lane packs four consecutive columns -- reads consecutive 8-byte words from consecutive lanes (with
+    // the columns stored linearly its four 32-byte-strided ds_read_b64 ran four ways bank-conflicted: SQ_LDS_BANK_CONFLICT was
+    // 57 % of the LDS cycles of a 50-cluster job).  0 = linear (item-item similarity: its top-K epilogue walks single columns).
+    int32_t acc_quarter;
 };
+__device__ __forceinline__ int cooc_acc_index(int c, int quarter) { return quarter ? (c & 3) * quarter + (c >> 2) : c; }
 
 #ifndef FY_COOC_NB
 #define FY_COOC_NB 8    // segment loads per group; two groups are in flight per wave (see cooc_accumulate_segments)
@@ -152,7 +158,7 @@ __device__ __forceinline__ void cooc_accumulate_segments(const CoocArgs& A, ACC*
         }
 #pragma unroll
         for (int q = 0; q < NB; q++)
-            if (lane < G.L[q]) atomicAdd(&acc[G.idx[q]], (ACC)G.W[q] * (ACC)G.x[q]);   // ds_add_f64 / ds_add_f32
+            if (lane < G.L[q]) atomicAdd(&acc[cooc_acc_index(G.idx[q], A.acc_quarter)], (ACC)G.W[q] * (ACC)G.x[q]);   // ds_add_f64 / ds_add_f32
     };
     int batch = 0;
     if (cooc_seg_slot(s_begin, 0, wave, nwaves, 0) >= s_end) return;
@@ -195,28 +201,35 @@ __device__ __forceinline__ void cooc_accumulate_segments(const CoocArgs& A, ACC*
 // the atomic), then v_cvt_f32_f16, v_mul_f32 (weight x rating: 24 x 11 significant bits, rounded once to fp32 -- 6e-8
 // relative per contribution, the same error the fp32 weight already carries), v_cvt_f64_f32, the LDS address and the
 // lane < length compare.
+// a group of 8 slice loads of the packed walk, in flight or landed
+struct PkGroup {
+    int L[FY_COOC_NB];
+    float W[FY_COOC_NB];
+    uint32_t pk[FY_COOC_NB];
+};
+// issues the 8 slice loads of the descriptor slots [g, g + 8) of a batch (d, w)
+__device__ __forceinline__ void cooc_pk_issue(const __amdgpu_buffer_rsrc_t rsrc, int lane4, PkGroup& G, const int2& d, float w, int g) {
+#pragma unroll
+    for (int q = 0; q < FY_COOC_NB; q++) {
+        const int F = __builtin_amdgcn_readlane(d.x, g + q);
+        G.L[q] = __builtin_amdgcn_readlane(d.y, g + q);
+        G.W[q] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(w), g + q));
+        G.pk[q] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, lane4, F * 4, 0);
+    }
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t cooc_pk_rsrc(const CoocArgs& A) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(A.csr_pk), 0, (int)A.pk_bytes, 0x00020000);
+}
 template <class ACC>
 __device__ __forceinline__ void cooc_accumulate_pk(const CoocArgs& A, ACC* __restrict__ acc, int s_begin, int s_end, SegBatch first) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = blockDim.x >> 6;
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(A.csr_pk), 0, (int)A.pk_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc = cooc_pk_rsrc(A);
     const int lane4 = lane * 4;
     constexpr int NB = FY_COOC_NB;
-    struct Group {
-        int L[NB];
-        float W[NB];
-        uint32_t pk[NB];
-    };
-    auto issue = [&](Group& G, const int2& d, float w, int g) __attribute__((always_inline)) {
-#pragma unroll
-        for (int q = 0; q < NB; q++) {
-            const int F = __builtin_amdgcn_readlane(d.x, g + q);
-            G.L[q] = __builtin_amdgcn_readlane(d.y, g + q);
-            G.W[q] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(w), g + q));
-            G.pk[q] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, lane4, F * 4, 0);
-        }
-    };
+    using Group = PkGroup;
+    auto issue = [&](Group& G, const int2& d, float w, int g) __attribute__((always_inline)) { cooc_pk_issue(rsrc, lane4, G, d, w, g); };
     const double fx = A.fx_scale;
     auto commit = [&](Group& G) __attribute__((always_inline)) {
 #pragma unroll
@@ -226,10 +239,10 @@ __device__ __forceinline__ void cooc_accumulate_pk(const CoocArgs& A, ACC* __res
                 // round(p * 2^k) without a 64-bit conversion: p * 2^k + 2^52 has the integer in its mantissa (0 <= p * 2^k < 2^52)
                 const double d = fma((double)(G.W[q] * x), fx, 4503599627370496.0);
                 const unsigned long long v = (unsigned long long)__double_as_longlong(d) & 0xFFFFFFFFFFFFFull;
-                if (lane < G.L[q]) atomicAdd(&acc[G.pk[q] & 0xFFFFu], v);   // ds_add_u64
+                if (lane < G.L[q]) atomicAdd(&acc[cooc_acc_index((int)(G.pk[q] & 0xFFFFu), A.acc_quarter)], v);   // ds_add_u64
             } else {
                 const ACC v = (ACC)(G.W[q] * x);
-                if (lane < G.L[q]) atomicAdd(&acc[G.pk[q] & 0xFFFFu], v);   // ds_add_f64
+                if (lane < G.L[q]) atomicAdd(&acc[cooc_acc_index((int)(G.pk[q] & 0xFFFFu), A.acc_quarter)], v);   // ds_add_f64
             }
         }
     };

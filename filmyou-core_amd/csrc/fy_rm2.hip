@@ -497,6 +497,96 @@ struct MEpilogue {
     int ceil24;
 };
 
+// Epilogue of one (row, chunk) item of the RM2 row kernel: G[i][chunk] = w2 * acc -> 24-bit pack (or fp32), the block maxima, and the
+// accumulators re-zeroed in the same pass.  All threads of the workgroup; `id` = (row of the launch << 8) | chunk.
+template <class ACC>
+__device__ __forceinline__ void cooc_rm2_epilogue(const CoocArgs& A, const MEpilogue& E, ACC* __restrict__ acc, int id) {
+    const int lrow = id >> 8;
+    const int row = A.row0 + lrow * (A.row_stride ? A.row_stride : 1);
+    const int mrow = E.local_rows ? lrow : row;
+    const int ch = id & 255;
+    const int c0 = ch * A.CH;
+    // the last chunk also writes the padding columns [Ic, ldm) so the scoring kernel may load whole 256-wide chunks
+    const int c1 = (ch == A.nch - 1) ? (int)E.ldm : min(c0 + A.CH, (int)E.ldm);
+    // symmetric walk: in the row's own chunk nothing in front of its 256-column diagonal block was accumulated (and the
+    // mirror pass writes that part of the row); the block maxima of the diagonal block are the mirror pass's too
+    const int cb = (A.half && c0 <= row) ? (row & ~255) : c0;
+    const int first_bmax_block = A.half ? (row >> 8) + 1 : 0;
+    if (E.pack24) {
+        // four columns -> three dwords (c0 and c1 are multiples of 64)
+        const int64_t row_cols = E.pitch ? E.pitch : (E.panel_cols ? E.panel_cols : E.ldm);
+        const uint32_t radd = E.ceil24 ? 0xFFu : 0x80u;
+        uint32_t* __restrict__ out3 = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(E.M) + (int64_t)mrow * row_cols * 3);
+        for (int c4 = (cb >> 2) + threadIdx.x; 4 * c4 < c1; c4 += blockDim.x) {
+            uint32_t v[4];
+            // plane q of the accumulators holds the columns = q mod 4 (CoocArgs::acc_quarter): consecutive lanes, consecutive words
+            const int qz = A.acc_quarter;
+            ACC* ap = acc + (qz ? c4 - (c0 >> 2) : 4 * c4 - c0);
+            const int qs = qz ? qz : 1;                       // stride between the four columns of the lane
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                float f;                                      // columns >= Ic were never touched: 0
+                if constexpr (std::is_same<ACC, unsigned long long>::value) f = (float)((double)ap[q * qs] * E.fx_inv);
+                else f = E.w2 * (float)ap[q * qs];
+                ap[q * qs] = (ACC)0;
+                v[q] = ((__float_as_uint(f) << 1) + radd) >> 8;    // G >= 0: drop the sign, keep 8 exponent + 16 mantissa bits, round to nearest
+            }
+            if (!E.panel_cols || 4 * c4 < E.panel_cols) {
+                out3[3 * c4 + 0] = v[0] | (v[1] << 24);
+                out3[3 * c4 + 1] = (v[1] >> 8) | (v[2] << 16);
+                out3[3 * c4 + 2] = (v[2] >> 16) | (v[3] << 8);
+            }
+            if (E.Bmax64) {
+                // 16 lanes = one 64-column sub-block.  Keys = value << 6 | column inside the sub-block (all different): the two
+                // largest keys of the 64, by a four-step butterfly of (first, second) pairs
+                const uint32_t cq = (uint32_t)((4 * c4) & 63);
+                const uint32_t k0 = (v[0] << 6) | cq, k1 = (v[1] << 6) | (cq + 1), k2 = (v[2] << 6) | (cq + 2), k3 = (v[3] << 6) | (cq + 3);
+                const uint32_t a1 = max(k0, k1), a2 = min(k0, k1), b1 = max(k2, k3), b2 = min(k2, k3);
+                uint32_t t1 = max(a1, b1), t2 = max(min(a1, b1), max(a2, b2));
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    const uint32_t p1 = (uint32_t)__shfl_xor((int)t1, o, 64), p2 = (uint32_t)__shfl_xor((int)t2, o, 64);
+                    t2 = max(min(t1, p1), max(t2, p2));
+                    t1 = max(t1, p1);
+                }
+                const uint32_t m = t1 >> 6;
+                if ((threadIdx.x & 15) == 0 && m) {
+                    uint8_t* bp = reinterpret_cast<uint8_t*>(E.Bmax64) + ((int64_t)mrow * E.ldb64 + (c4 >> 4)) * 3;
+                    bp[0] = (uint8_t)m;
+                    bp[1] = (uint8_t)(m >> 8);
+                    bp[2] = (uint8_t)(m >> 16);
+                    if (E.Brep) E.Brep[(int64_t)mrow * E.ldb64 + (c4 >> 4)] = ((t2 >> 6) << 8) | (t1 & 63u);
+                }
+            }
+            if (E.Bmax) {
+                // maximum of the values exactly as the scoring kernel will unpack them; one wave = one 256-column
+                // block (c0 and c1 are multiples of 256 when the bound matrix is requested, see pick_chunks)
+                uint32_t m = max(max(v[0], v[1]), max(v[2], v[3]));     // non-negative floats order like their bit patterns
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+                if ((threadIdx.x & 63) == 0 && m && (c4 >> 6) >= first_bmax_block) {
+                    // the maximum of 24-bit values is itself one: Bmax is stored in the same packed format (3 bytes per
+                    // block, byte stores: the four blocks of a packed group belong to different waves or chunks), so
+                    // the bound pass streams 768 instead of 1024 bytes per rated item.  (Zero maxima are not stored:
+                    // the matrix was cleared before the launch.)
+                    uint8_t* bp = reinterpret_cast<uint8_t*>(E.Bmax) + ((int64_t)mrow * E.ldb + (c4 >> 6)) * 3;
+                    bp[0] = (uint8_t)m;
+                    bp[1] = (uint8_t)(m >> 8);
+                    bp[2] = (uint8_t)(m >> 16);
+                }
+            }
+        }
+    } else {
+        float* __restrict__ out = E.M + (int64_t)mrow * E.ldm;
+        for (int col = cb + threadIdx.x; col < c1; col += blockDim.x) {
+            const int at = cooc_acc_index(col - c0, A.acc_quarter);
+            if constexpr (std::is_same<ACC, unsigned long long>::value) out[col] = (float)((double)acc[at] * E.fx_inv);
+            else out[col] = E.w2 * (float)acc[at];
+            acc[at] = (ACC)0;
+        }
+    }
+}
+
 // Persistent workgroups pull (row, chunk) items from a global counter (rows are in popularity order: heavy items first);
 // the epilogue re-zeroes the accumulators it reads, so an item costs one accumulate phase, one barrier, one epilogue and
 // one barrier -- no dispatch, no separate clearing pass.
@@ -561,11 +651,7 @@ __global__ void k_cooc_rm2(CoocArgs A, MEpilogue E, int n_items, int* __restrict
             next2 = grab();
             if (next < n_items) { se_next = A.item_seg[next]; id_next = A.item_id[next]; }   // address known since the previous item
         }
-        const int lrow = id >> 8;
-        const int row = A.row0 + lrow * (A.row_stride ? A.row_stride : 1);
-        const int mrow = E.local_rows ? lrow : row;
-        const int ch = id & 255;
-        const int c0 = ch * A.CH;
+        const int c0 = (id & 255) * A.CH;
         if constexpr (PK) cooc_accumulate_pk<ACC>(A, acc, s0, s1, batch);
         else cooc_accumulate_segments<false, ACC>(A, acc, s0, s1, c0, batch);
         // (every thread read sh_* of THIS item before the barrier that ended the previous epilogue)
@@ -576,81 +662,7 @@ __global__ void k_cooc_rm2(CoocArgs A, MEpilogue E, int n_items, int* __restrict
         s1 = sh_s1;
         const int nid = sh_id;
         batch = cooc_first_batch(A, s0, s1);     // in flight during the epilogue
-        // the last chunk also writes the padding columns [Ic, ldm) so the scoring kernel may load whole 256-wide chunks
-        const int c1 = (ch == A.nch - 1) ? (int)E.ldm : min(c0 + A.CH, (int)E.ldm);
-        // symmetric walk: in the row's own chunk nothing in front of its 256-column diagonal block was accumulated (and the
-        // mirror pass writes that part of the row); the block maxima of the diagonal block are the mirror pass's too
-        const int cb = (A.half && c0 <= row) ? (row & ~255) : c0;
-        const int first_bmax_block = A.half ? (row >> 8) + 1 : 0;
-        if (E.pack24) {
-            // four columns -> three dwords (c0 and c1 are multiples of 64)
-            const int64_t row_cols = E.pitch ? E.pitch : (E.panel_cols ? E.panel_cols : E.ldm);
-            const uint32_t radd = E.ceil24 ? 0xFFu : 0x80u;
-            uint32_t* __restrict__ out3 = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(E.M) + (int64_t)mrow * row_cols * 3);
-            for (int c4 = (cb >> 2) + threadIdx.x; 4 * c4 < c1; c4 += blockDim.x) {
-                uint32_t v[4];
-                ACC* ap = acc + (4 * c4 - c0);
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    float f;                                      // columns >= Ic were never touched: 0
-                    if constexpr (std::is_same<ACC, unsigned long long>::value) f = (float)((double)ap[q] * E.fx_inv);
-                    else f = E.w2 * (float)ap[q];
-                    ap[q] = (ACC)0;
-                    v[q] = ((__float_as_uint(f) << 1) + radd) >> 8;    // G >= 0: drop the sign, keep 8 exponent + 16 mantissa bits, round to nearest
-                }
-                if (!E.panel_cols || 4 * c4 < E.panel_cols) {
-                    out3[3 * c4 + 0] = v[0] | (v[1] << 24);
-                    out3[3 * c4 + 1] = (v[1] >> 8) | (v[2] << 16);
-                    out3[3 * c4 + 2] = (v[2] >> 16) | (v[3] << 8);
-                }
-                if (E.Bmax64) {
-                    // 16 lanes = one 64-column sub-block.  Keys = value << 6 | column inside the sub-block (all different): the two
-                    // largest keys of the 64, by a four-step butterfly of (first, second) pairs
-                    const uint32_t cq = (uint32_t)((4 * c4) & 63);
-                    const uint32_t k0 = (v[0] << 6) | cq, k1 = (v[1] << 6) | (cq + 1), k2 = (v[2] << 6) | (cq + 2), k3 = (v[3] << 6) | (cq + 3);
-                    const uint32_t a1 = max(k0, k1), a2 = min(k0, k1), b1 = max(k2, k3), b2 = min(k2, k3);
-                    uint32_t t1 = max(a1, b1), t2 = max(min(a1, b1), max(a2, b2));
-#pragma unroll
-                    for (int o = 1; o < 16; o <<= 1) {
-                        const uint32_t p1 = (uint32_t)__shfl_xor((int)t1, o, 64), p2 = (uint32_t)__shfl_xor((int)t2, o, 64);
-                        t2 = max(min(t1, p1), max(t2, p2));
-                        t1 = max(t1, p1);
-                    }
-                    const uint32_t m = t1 >> 6;
-                    if ((threadIdx.x & 15) == 0 && m) {
-                        uint8_t* bp = reinterpret_cast<uint8_t*>(E.Bmax64) + ((int64_t)mrow * E.ldb64 + (c4 >> 4)) * 3;
-                        bp[0] = (uint8_t)m;
-                        bp[1] = (uint8_t)(m >> 8);
-                        bp[2] = (uint8_t)(m >> 16);
-                        if (E.Brep) E.Brep[(int64_t)mrow * E.ldb64 + (c4 >> 4)] = ((t2 >> 6) << 8) | (t1 & 63u);
-                    }
-                }
-                if (E.Bmax) {
-                    // maximum of the values exactly as the scoring kernel will unpack them; one wave = one 256-column
-                    // block (c0 and c1 are multiples of 256 when the bound matrix is requested, see pick_chunks)
-                    uint32_t m = max(max(v[0], v[1]), max(v[2], v[3]));     // non-negative floats order like their bit patterns
-#pragma unroll
-                    for (int o = 1; o < 64; o <<= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
-                    if ((threadIdx.x & 63) == 0 && m && (c4 >> 6) >= first_bmax_block) {
-                        // the maximum of 24-bit values is itself one: Bmax is stored in the same packed format (3 bytes per
-                        // block, byte stores: the four blocks of a packed group belong to different waves or chunks), so
-                        // the bound pass streams 768 instead of 1024 bytes per rated item.  (Zero maxima are not stored:
-                        // the matrix was cleared before the launch.)
-                        uint8_t* bp = reinterpret_cast<uint8_t*>(E.Bmax) + ((int64_t)mrow * E.ldb + (c4 >> 6)) * 3;
-                        bp[0] = (uint8_t)m;
-                        bp[1] = (uint8_t)(m >> 8);
-                        bp[2] = (uint8_t)(m >> 16);
-                    }
-                }
-            }
-        } else {
-            float* __restrict__ out = E.M + (int64_t)mrow * E.ldm;
-            for (int col = cb + threadIdx.x; col < c1; col += blockDim.x) {
-                if constexpr (std::is_same<ACC, unsigned long long>::value) out[col] = (float)((double)acc[col - c0] * E.fx_inv);
-                else out[col] = E.w2 * (float)acc[col - c0];
-                acc[col - c0] = (ACC)0;
-            }
-        }
+        cooc_rm2_epilogue<ACC>(A, E, acc, id);
         item = nitem;
         id = nid;
         if (threadIdx.x == 0) next = next2;
@@ -785,6 +797,7 @@ static void cooc_rm2_allow_lds() {
     FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cooc_rm2<false, float>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cooc_rm2<true, float>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cooc_rm2<true, unsigned long long>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cooc_rm2<true, unsigned long long, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
 }
 
 #include "fy_rm2_kernels.hpp"   // scoring, top-N, branch-and-bound and cooperative-rank kernels (part of this translation unit)
@@ -869,6 +882,7 @@ struct ScoreTune {
     int cooc_fx = 1;                   // fixed-point (ds_add_u64) accumulation in the packed walk
     int panel_min_clusters = 4;        // column-panel mode when at least this many clusters of the rank are pruned ones
     int panel_cols = 4096;             // columns of a row kept in panel mode (the seed columns and the popular blocks)
+    bool cooc_planes = true;           // FY_COOC_PLANES=0: linear accumulator layout (measurement only)
     int score_heavy = 512;             // users with more ratings are walked by a whole workgroup of the scoring kernel (0 = off)
     bool panel_repair = true;          // FY_PANEL_REPAIR=0: measurement only
     int panel_lanes = 2;               // job lanes when clusters run in panel mode (measured, 50 clusters: 1 lane 300 ms, 2: 213, 3: 230, 4: 240)
@@ -891,6 +905,7 @@ static ScoreTune score_tune() {
     if (const char* e = getenv("FY_PANEL_MIN_CLUSTERS")) { int v = atoi(e); if (v >= 1) t.panel_min_clusters = v; }
     if (const char* e = getenv("FY_PANEL_COLS")) { int v = atoi(e); if (v >= 256) t.panel_cols = v; }
     if (const char* e = getenv("FY_PANEL_MAX_CH")) { int v = atoi(e); if (v >= 256) t.panel_max_ch = v; }
+    if (const char* e = getenv("FY_COOC_PLANES")) t.cooc_planes = atoi(e) != 0;
     if (const char* e = getenv("FY_SCORE_HEAVY")) { int v = atoi(e); if (v >= 0) t.score_heavy = v; }
     if (const char* e = getenv("FY_PANEL_REPAIR")) t.panel_repair = atoi(e) != 0;
     if (const char* e = getenv("FY_PANEL_LANES")) { int v = atoi(e); if (v >= 1 && v <= 8) t.panel_lanes = v; }
@@ -921,9 +936,11 @@ static int fx_exponent(const float* bounds3) {
 // items per atomic of the row kernel's work counter: 8 where an item is short (< 256 segments on average), else 1
 static int cooc_item_grab(int64_t n_seg, int64_t n_items) { return n_items > 0 && n_seg / n_items < 256 ? 8 : 1; }
 
-static void launch_cooc_rm2(Context* ctx, const ScoreTune& tune, bool use_pk, const CoocArgs& CA, const MEpilogue& ME, int n_items,
+static void launch_cooc_rm2(Context* ctx, const ScoreTune& tune, bool use_pk, const CoocArgs& CA_, const MEpilogue& ME, int n_items,
                             int32_t* counter, hipStream_t st) {
     if (n_items <= 0) return;
+    CoocArgs CA = CA_;
+    CA.acc_quarter = tune.cooc_planes ? cooc_lds_columns(CA.CH) / 4 : 0;
     const size_t lds = (size_t)cooc_lds_columns(CA.CH) * (tune.cooc_f32 ? 4 : 8);
     const int by_lds = (int)std::max<size_t>(1, (160 * 1024 - 512) / (lds + 64));
     int block = tune.cooc_block;

@@ -25,6 +25,20 @@ def device_doubles(ptr, n):
 
 @pytest.mark.parametrize("shape,K,world", [("tiny", 1, 2), ("tiny", 5, 3), ("ml100k", 1, 4), ("ml100k", 12, 8)])
 def test_sharded_equals_single(ctx, shape, K, world):
+    sharded_equals_single(ctx, shape, K, world)
+
+
+def test_sharded_panel_mode(ctx, monkeypatch):
+    """The many-cluster (column-panel) path with the users of every cluster split over three ranks: each rank builds the
+    cluster's panel and bounds for its own users (forced onto small data like tests/test_pruned_coop_gpu.py does)."""
+    for k, v in (("FY_PRUNE_MIN_ITEMS", "256"), ("FY_M24_MIN_ITEMS", "0"), ("FY_SEED_CHUNKS", "1"), ("FY_PANEL_MIN_CLUSTERS", "1"),
+                 ("FY_PANEL_COLS", "256"), ("FY_COOC_MAX_CH", "256")):
+        monkeypatch.setenv(k, v)
+    st = sharded_equals_single(ctx, "ml100k", 2, 3)
+    assert all(x["panel_clusters"] > 0 for x in st)
+
+
+def sharded_equals_single(ctx, shape, K, world):
     P, S = pkg(), synth()
     u, i, s, facts = S.generate(shape)
     u, i, s = u.numpy(), i.numpy(), s.numpy()
@@ -75,6 +89,7 @@ def test_sharded_equals_single(ctx, shape, K, world):
     assert sum(x["users_scored"] for x in st) == single.stats["users_scored"]
     assert sum(x["log_terms"] for x in st) == single.stats["log_terms"]
     ratings.close()
+    return st
 
 
 def test_stats_exchange_wraps_the_library_buffer(ctx, rm_golden):
