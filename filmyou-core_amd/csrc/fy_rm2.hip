@@ -543,12 +543,18 @@ __device__ __forceinline__ void cooc_rm2_epilogue(const CoocArgs& A, const MEpil
                 const uint32_t k0 = (v[0] << 6) | cq, k1 = (v[1] << 6) | (cq + 1), k2 = (v[2] << 6) | (cq + 2), k3 = (v[3] << 6) | (cq + 3);
                 const uint32_t a1 = max(k0, k1), a2 = min(k0, k1), b1 = max(k2, k3), b2 = min(k2, k3);
                 uint32_t t1 = max(a1, b1), t2 = max(min(a1, b1), max(a2, b2));
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    const uint32_t p1 = (uint32_t)__shfl_xor((int)t1, o, 64), p2 = (uint32_t)__shfl_xor((int)t2, o, 64);
-                    t2 = max(min(t1, p1), max(t2, p2));
-                    t1 = max(t1, p1);
-                }
+                // rotations inside the row of 16 lanes (DPP row_ror: no LDS instruction -- as ds_bpermute shuffles these were a third
+                // of the kernel's LDS instructions in a 50-cluster job): after ror 8, 4, 2, 1 every lane has seen all 16, each once
+#define FY_ROR16(x, n) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(x), 0x120 + (n), 0xF, 0xF, false))
+#define FY_TOP2_STEP(n)                                         \
+    {                                                           \
+        const uint32_t p1 = FY_ROR16(t1, n), p2 = FY_ROR16(t2, n); \
+        t2 = max(min(t1, p1), max(t2, p2));                     \
+        t1 = max(t1, p1);                                       \
+    }
+                FY_TOP2_STEP(8) FY_TOP2_STEP(4) FY_TOP2_STEP(2) FY_TOP2_STEP(1)
+#undef FY_TOP2_STEP
+#undef FY_ROR16
                 const uint32_t m = t1 >> 6;
                 if ((threadIdx.x & 15) == 0 && m) {
                     uint8_t* bp = reinterpret_cast<uint8_t*>(E.Bmax64) + ((int64_t)mrow * E.ldb64 + (c4 >> 4)) * 3;
