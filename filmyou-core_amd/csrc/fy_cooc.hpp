@@ -356,17 +356,20 @@ __attribute__((unused)) static __global__ void k_item_list(CoocArgs A, int2* __r
 
 // segment table of one cluster from its chunk_off table; returns the number of segments (synchronises once)
 struct SegTable {
-    int64_t n_seg = 0;     // segments in the table
+    int64_t n_seg = 0;     // segments in the table (an upper bound when the table was sized without a round trip)
+    DevBuf<int32_t> cnt, scratch;   // build_segments' temporaries: they live as long as the table (a lane may still be reading them)
     DevBuf<int32_t> ptr;   // nch * (nq + 1)
     DevBuf<int2> seg;
     DevBuf<float> w;
 };
 // half_row_of_entry != nullptr: symmetric walk (only the columns behind the entry's own row; fy_rm2.hip, struct Half)
 // only_rows_of_entry != nullptr: CSC entries of the rows in front of only_rows_from get no segments (tail-row launches)
+// max_segments > 0: an upper bound of the number of segments -- the table is allocated for it and the call does not wait for
+// the device (otherwise it reads the exact count back: two host round trips)
 void build_segments(Context* ctx, const int32_t* csc_slot, const float* csc_w, const int32_t* chunk_off, int32_t slot_base,
                     int32_t q0, int32_t nq, int32_t nch, SegTable& out, hipStream_t st = nullptr,
                     const int32_t* half_row_of_entry = nullptr, const int32_t* csr_idx = nullptr, int32_t CH = 0,
-                    const int32_t* only_rows_of_entry = nullptr, int32_t only_rows_from = 0);
+                    const int32_t* only_rows_of_entry = nullptr, int32_t only_rows_from = 0, int64_t max_segments = 0);
 
 // chunk_off table for one cluster: one thread per (slot, boundary)
 void build_chunk_offsets(Context* ctx, const int32_t* rowptr, const int32_t* csr_idx, int32_t slot_base, int32_t n_slots,

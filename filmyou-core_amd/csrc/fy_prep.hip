@@ -573,7 +573,15 @@ void build_structure(Context* ctx, const fy_ratings* R, int32_t K, int64_t n_map
         P.work_prefix.resize(nU);
         d2h(ctx, P.work_prefix.data(), wpre.get(), (size_t)nU);
         d2h(ctx, &P.sum_deg2, d2pre.get() + (nU - 1), 1);
+        std::vector<int64_t> at_end((size_t)K + 1, 0);     // inclusive prefix of n_u^2 at the last slot of every cluster
+        for (int c = 0; c < K; c++)
+            if (P.ucstart[c + 1] > P.ucstart[c]) d2h(ctx, &at_end[(size_t)c + 1], d2pre.get() + (P.ucstart[c + 1] - 1), 1);
         sync(ctx);
+        P.cluster_deg2.assign((size_t)K, 0);
+        int64_t before = 0;
+        for (int c = 0; c < K; c++) {
+            if (P.ucstart[c + 1] > P.ucstart[c]) { P.cluster_deg2[c] = at_end[(size_t)c + 1] - before; before = at_end[(size_t)c + 1]; }
+        }
     }
 }
 

@@ -21,6 +21,7 @@ struct Prepared {
     int64_t nnz = 0;          // ratings kept (score > 0)
     int32_t nU = 0, nI = 0, nP = 0, K = 0;
     int64_t sum_deg2 = 0;     // sum_u n_u^2
+    std::vector<int64_t> cluster_deg2;   // [c]: sum of n_u^2 over the users of cluster c (host; upper bounds of the segment tables)
     bool ratings_fp16_exact = false;   // every kept rating is exactly representable in fp16 (enables the packed CSR of fy_cooc.hpp)
     // users, dense (ascending raw id)
     DevBuf<int32_t> uid, ucluster, udeg, slot2du, du2slot;

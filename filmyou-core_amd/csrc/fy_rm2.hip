@@ -446,19 +446,23 @@ __global__ void k_seg_fill(const int32_t* __restrict__ csc_slot, const float* __
 
 void build_segments(Context* ctx, const int32_t* csc_slot, const float* csc_w, const int32_t* chunk_off, int32_t slot_base,
                     int32_t q0, int32_t nq, int32_t nch, SegTable& out, hipStream_t st, const int32_t* half_row_of_entry,
-                    const int32_t* csr_idx, int32_t CH, const int32_t* only_rows_of_entry, int32_t only_rows_from) {
+                    const int32_t* csr_idx, int32_t CH, const int32_t* only_rows_of_entry, int32_t only_rows_from, int64_t max_segments) {
     if (!st) st = ctx->stream;
     const size_t np = (size_t)nch * ((size_t)nq + 1);
     out.ptr.alloc(ctx, np);
-    DevBuf<int32_t> cnt(ctx, np);
-    DevBuf<int32_t> half_start(ctx, half_row_of_entry ? (size_t)nq + 1 : 1);
-    const Half H{half_row_of_entry, csr_idx, CH, half_start.get(), only_rows_of_entry, only_rows_from};
-    k_seg_counts<<<grid_for((int64_t)nq + 1), 256, 0, st>>>(csc_slot, chunk_off, slot_base, q0, nq, nch, cnt.get(), H);
+    out.cnt.alloc(ctx, np);
+    out.scratch.alloc(ctx, half_row_of_entry ? (size_t)nq + 1 : 1);
+    const Half H{half_row_of_entry, csr_idx, CH, out.scratch.get(), only_rows_of_entry, only_rows_from};
+    k_seg_counts<<<grid_for((int64_t)nq + 1), 256, 0, st>>>(csc_slot, chunk_off, slot_base, q0, nq, nch, out.cnt.get(), H);
     FY_KERNEL_CHECK();
-    exclusive_scan_i32(ctx, cnt.get(), out.ptr.get(), np, st);
-    int32_t total = 0;   // the last count is 0 by construction: the last prefix is the total
-    FY_HIP(hipMemcpyAsync(&total, out.ptr.get() + (np - 1), sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    FY_HIP(hipStreamSynchronize(st));
+    exclusive_scan_i32(ctx, out.cnt.get(), out.ptr.get(), np, st);
+    int64_t total = max_segments;
+    if (max_segments <= 0) {
+        int32_t t32 = 0;   // the last count is 0 by construction: the last prefix is the total
+        FY_HIP(hipMemcpyAsync(&t32, out.ptr.get() + (np - 1), sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        FY_HIP(hipStreamSynchronize(st));
+        total = t32;
+    }
     out.n_seg = total;
     out.seg.alloc(ctx, (size_t)total);
     out.w.alloc(ctx, (size_t)total);
@@ -467,7 +471,7 @@ void build_segments(Context* ctx, const int32_t* csc_slot, const float* csc_w, c
                                                                  out.seg.get(), out.w.get(), H);
         FY_KERNEL_CHECK();
     }
-    FY_HIP(hipStreamSynchronize(st));     // half_start is scratch of this call
+    if (max_segments <= 0) FY_HIP(hipStreamSynchronize(st));     // (the callers of the exact mode release their inputs right after the call)
 }
 
 // ================================================================ G build: co-rating row kernel + RM2 epilogue
@@ -805,8 +809,13 @@ static void cooc_rm2_allow_lds() {
     FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cooc_rm2<true, unsigned long long>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cooc_rm2<true, unsigned long long, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
 }
+static void stray_allow_lds();
 
 #include "fy_rm2_kernels.hpp"   // scoring, top-N, branch-and-bound and cooperative-rank kernels (part of this translation unit)
+
+static void stray_allow_lds() {   // k_score_stray: (Uc + 1) rater offsets of dynamic LDS, up to 128 KB
+    FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_score_stray), hipFuncAttributeMaxDynamicSharedMemorySize, (STRAY_UCAP + 1) * (int)sizeof(int32_t)));
+}
 
 void launch_topn_rows(Context* ctx, hipStream_t st, const float* S, int64_t ldS, int32_t n_cols, int32_t n_rows,
                       const int32_t* n_out, const int32_t* out_off, const int32_t* rank_item_raw, const int32_t* slot2du,
@@ -888,6 +897,7 @@ struct ScoreTune {
     int cooc_fx = 1;                   // fixed-point (ds_add_u64) accumulation in the packed walk
     int panel_min_clusters = 4;        // column-panel mode when at least this many clusters of the rank are pruned ones
     int panel_cols = 4096;             // columns of a row kept in panel mode (the seed columns and the popular blocks)
+    bool bounded_tables = true;        // FY_BOUNDED_TABLES=0: exact table sizes (two host round trips per table)
     bool cooc_planes = true;           // FY_COOC_PLANES=0: linear accumulator layout (measurement only)
     int score_heavy = 512;             // users with more ratings are walked by a whole workgroup of the scoring kernel (0 = off)
     bool panel_repair = true;          // FY_PANEL_REPAIR=0: measurement only
@@ -911,6 +921,7 @@ static ScoreTune score_tune() {
     if (const char* e = getenv("FY_PANEL_MIN_CLUSTERS")) { int v = atoi(e); if (v >= 1) t.panel_min_clusters = v; }
     if (const char* e = getenv("FY_PANEL_COLS")) { int v = atoi(e); if (v >= 256) t.panel_cols = v; }
     if (const char* e = getenv("FY_PANEL_MAX_CH")) { int v = atoi(e); if (v >= 256) t.panel_max_ch = v; }
+    if (const char* e = getenv("FY_BOUNDED_TABLES")) t.bounded_tables = atoi(e) != 0;
     if (const char* e = getenv("FY_COOC_PLANES")) t.cooc_planes = atoi(e) != 0;
     if (const char* e = getenv("FY_SCORE_HEAVY")) { int v = atoi(e); if (v >= 0) t.score_heavy = v; }
     if (const char* e = getenv("FY_PANEL_REPAIR")) t.panel_repair = atoi(e) != 0;
@@ -939,8 +950,9 @@ static int fx_exponent(const float* bounds3) {
 
 // launch shape of the RM2 row kernel: as many workgroups per CU as the LDS accumulators allow (fp32: two for ML-25M's
 // 19 712-column chunks), 2048 threads per CU at most
-// items per atomic of the row kernel's work counter: 8 where an item is short (< 256 segments on average), else 1
-static int cooc_item_grab(int64_t n_seg, int64_t n_items) { return n_items > 0 && n_seg / n_items < 256 ? 8 : 1; }
+// items per atomic of the row kernel's work counter: 8 where an item is short (fewer than ~12 000 co-rating contributions, i.e.
+// < 256 segments on average; `visits` = the cluster's sum of n_u^2, an upper bound of the launch's contributions), else 1
+static int cooc_item_grab(int64_t visits, int64_t n_items) { return n_items > 0 && visits / n_items < 12000 ? 8 : 1; }
 
 static void launch_cooc_rm2(Context* ctx, const ScoreTune& tune, bool use_pk, const CoocArgs& CA_, const MEpilogue& ME, int n_items,
                             int32_t* counter, hipStream_t st) {
@@ -1191,6 +1203,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
         const int64_t ws = prm.workspace_bytes > 0 ? prm.workspace_bytes : tune.workspace_default;
         const int max_ch_lds = tune.cooc_max_ch;   // fp64 accumulators in LDS
         cooc_rm2_allow_lds();
+        stray_allow_lds();
 
         // ---- per-cluster plan; the clusters are spread over up to four "lanes" (HIP streams with their own M / score
         // scratch): the tail of one cluster's launches -- its heaviest user sits on a single wave for milliseconds, and
@@ -1375,6 +1388,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
         sync(ctx);
         // One cluster's tables: packed CSR with chunk-relative indices for its CH, chunk offsets, segment table (+ the tail rows'
         // one-chunk table over the block-compressed CSR in panel mode).  `co` = scratch for p.Uc * (p.nch + 1) offsets.
+        const bool bounded_tables = NS > 1 && !any_coop && tune.bounded_tables;     // (= lazy_tables below)
         auto build_tables = [&](size_t pi, hipStream_t ts, int32_t* co) {
             const Plan& p = plans[pi];
             const int32_t f0 = csr_range[2 * pi], f1 = csr_range[2 * pi + 1];
@@ -1384,14 +1398,18 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             }
             if (p.coop) return;
             build_chunk_offsets(ctx, P.rowptr.get(), P.csr_idx.get(), p.sbase, p.Uc, p.CH, p.nch, co, ts);
+            // In a lane the tables are sized by an upper bound instead of a count read back from the device (an entry of rater v
+            // has at most n_v / 64 + nch segments): the host does not wait, the lane's queue stays full
+            const int64_t deg2_c = (size_t)p.c < P.cluster_deg2.size() ? P.cluster_deg2[p.c] : 0;
+            const int64_t seg_bound = bounded_tables && deg2_c > 0 ? deg2_c / 64 + (int64_t)p.nq * p.nch + 64 : 0;
             build_segments(ctx, P.csc_slot.get(), use_pk ? csc_x_over_s.get() : csc_x.get(), co, p.sbase, p.q0, p.nq, p.nch, segs[pi], ts,
-                           p.half ? csc_rank.get() : nullptr, P.csr_idx.get(), p.CH);
+                           p.half ? csc_rank.get() : nullptr, P.csr_idx.get(), p.CH, nullptr, 0, seg_bound);
             if (p.p_eff < p.Ic) {
                 k_tail_blocks<<<grid_for((int64_t)p.Uc * 64), 256, 0, ts>>>(p.sbase, p.Uc, p.p_eff, P.rowptr.get(), P.csr_idx.get(), P.csr_r.get(),
                                                                           y_pk.get(), co);
                 FY_KERNEL_CHECK();
                 build_segments(ctx, P.csc_slot.get(), csc_x_over_s.get(), co, p.sbase, p.q0, p.nq, 1, segs_tail[pi], ts, nullptr, nullptr, 0,
-                               csc_rank.get(), p.p_eff);
+                               csc_rank.get(), p.p_eff, bounded_tables && deg2_c > 0 ? deg2_c / 64 + (int64_t)p.nq + 64 : 0);
             }
         };
         // With several lanes and no cooperative cluster the tables are built by the lane that uses them, right before the row
@@ -1477,7 +1495,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 CB.item_seg = L.item_seg.get();
                 CB.item_id = L.item_id.get();
                 FY_HIP(hipMemsetAsync(L.any_overflow.get(), 0, sizeof(int32_t), ls));
-                CB.item_grab = cooc_item_grab(segs_tail[pi].n_seg, Ic - p.p_eff);
+                CB.item_grab = 8;      // a tail row's bound item is a handful of segments
                 launch_cooc_rm2(ctx, tune, use_pk, CB, MB, Ic - p.p_eff, L.any_overflow.get(), ls);
                 R->st.cooc_launches++;
                 CA.tail_row0 = p.p_eff;
@@ -1492,7 +1510,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 CA.item_seg = L.item_seg.get();
                 CA.item_id = L.item_id.get();
                 FY_HIP(hipMemsetAsync(L.any_overflow.get(), 0, sizeof(int32_t), ls));   // reused as the item counter
-                CA.item_grab = cooc_item_grab(segs[pi].n_seg, n_items);
+                CA.item_grab = cooc_item_grab(((size_t)c < P.cluster_deg2.size() ? P.cluster_deg2[c] : P.sum_deg2) / (p.half ? 2 : 1), n_items);
                 launch_cooc_rm2(ctx, tune, use_pk, CA, ME, n_items, L.any_overflow.get(), ls);
             }
             t_cooc.end(sp, ls);

@@ -836,7 +836,7 @@ __global__ __launch_bounds__(256) void k_bound_repair(RepairArgs A) {
 //       ds_add_u64: the sum does not depend on the order of the lanes), then the log terms are summed over the list.
 // A candidate costs its co-ratings with the list, not the length of its raters' rows.  Lists longer than STRAY_JCAP (or with
 // more than STRAY_TCAP co-raters) are walked in pieces -- the score is a sum over j -- and T is then rebuilt per block.
-constexpr int STRAY_UCAP = 16384;    // users of the cluster (panel mode is for many small clusters: fy_rm2.hip, Plan::panel)
+constexpr int STRAY_UCAP = 32768;    // users of the cluster (panel mode is for many small clusters: fy_rm2.hip, Plan::panel)
 constexpr int STRAY_JCAP = 256;
 constexpr int STRAY_TCAP = 32768;    // >= STRAY_UCAP: one item's raters always fit
 struct StrayArgs {
@@ -891,8 +891,8 @@ __global__ __launch_bounds__(256) void k_score_stray(StrayArgs A) {
     __shared__ int32_t sh_cq0[PRUNE_BLOCK], sh_cnr[PRUNE_BLOCK];      // the candidates' CSC ranges
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const double LN2 = 0.69314718055994530942;
-    // x_vi x_vj <= 1/4 (both ratings are part of s_v), so a sum over at most Uc = 2^14 raters stays below 2^12: 50 fraction bits
-    const double fx = 1125899906842624.0, fx_inv = 1.0 / 1125899906842624.0;
+    // x_vi x_vj <= 1/4 (both ratings are part of s_v), so a sum over at most Uc = 2^15 raters stays below 2^13: 49 fraction bits
+    const double fx = 562949953421312.0, fx_inv = 1.0 / 562949953421312.0;
     int2* __restrict__ T = A.T + (int64_t)blockIdx.x * STRAY_TCAP;
     unsigned long long my_terms = 0, my_blocks = 0;
     for (int t = threadIdx.x; t < 4 * STRAY_JCAP; t += blockDim.x) (&sh_g[0][0])[t] = 0ull;
