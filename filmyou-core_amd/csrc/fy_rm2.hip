@@ -896,6 +896,8 @@ struct ScoreTune {
     int cooc_half = 1;                 // symmetric walk (upper triangle + mirror pass) for clusters with packed rows
     int cooc_fx = 1;                   // fixed-point (ds_add_u64) accumulation in the packed walk
     int panel_min_clusters = 4;        // column-panel mode when at least this many clusters of the rank are pruned ones
+    int prune_min_users = 600;         // clusters with fewer users take the plain full pass
+    int panel_wide_below_users = 2500; // panel mode: clusters with fewer users keep twice the panel columns
     int panel_cols = 4096;             // columns of a row kept in panel mode (the seed columns and the popular blocks)
     bool bounded_tables = true;        // FY_BOUNDED_TABLES=0: exact table sizes (two host round trips per table)
     bool cooc_planes = true;           // FY_COOC_PLANES=0: linear accumulator layout (measurement only)
@@ -919,14 +921,16 @@ static ScoreTune score_tune() {
     if (const char* e = getenv("FY_COOC_HALF")) t.cooc_half = atoi(e) != 0;
     if (const char* e = getenv("FY_COOC_FX")) t.cooc_fx = atoi(e) != 0;
     if (const char* e = getenv("FY_PANEL_MIN_CLUSTERS")) { int v = atoi(e); if (v >= 1) t.panel_min_clusters = v; }
-    if (const char* e = getenv("FY_PANEL_COLS")) { int v = atoi(e); if (v >= 256) t.panel_cols = v; }
+    if (const char* e = getenv("FY_PANEL_COLS")) { int v = atoi(e); if (v >= 256) { t.panel_cols = v; t.panel_wide_below_users = 0; } }
+    if (const char* e = getenv("FY_PANEL_WIDE_BELOW_USERS")) { int v = atoi(e); if (v >= 0) t.panel_wide_below_users = v; }
     if (const char* e = getenv("FY_PANEL_MAX_CH")) { int v = atoi(e); if (v >= 256) t.panel_max_ch = v; }
     if (const char* e = getenv("FY_BOUNDED_TABLES")) t.bounded_tables = atoi(e) != 0;
     if (const char* e = getenv("FY_COOC_PLANES")) t.cooc_planes = atoi(e) != 0;
     if (const char* e = getenv("FY_SCORE_HEAVY")) { int v = atoi(e); if (v >= 0) t.score_heavy = v; }
     if (const char* e = getenv("FY_PANEL_REPAIR")) t.panel_repair = atoi(e) != 0;
     if (const char* e = getenv("FY_PANEL_LANES")) { int v = atoi(e); if (v >= 1 && v <= 8) t.panel_lanes = v; }
-    if (const char* e = getenv("FY_PRUNE_MIN_ITEMS")) t.prune_min_items = atoi(e);
+    if (const char* e = getenv("FY_PRUNE_MIN_ITEMS")) { t.prune_min_items = atoi(e); t.prune_min_users = 0; }   // (a forced item threshold -- tests -- lifts the user threshold too)
+    if (const char* e = getenv("FY_PRUNE_MIN_USERS")) { int v = atoi(e); if (v >= 0) t.prune_min_users = v; }
     if (const char* e = getenv("FY_SEED_CHUNKS")) { int v = atoi(e); if (v >= 0 && v <= 4) { t.seed_chunks = v; t.seed_forced = v > 0; } }
     if (const char* e = getenv("FY_WORKSPACE_GB")) { long v = atol(e); if (v >= 1) t.workspace_default = (int64_t)v << 30; }
     if (const char* e = getenv("FY_LANES")) { int v = atoi(e); if (v >= 1 && v <= 8) t.lanes = v; }
@@ -1233,7 +1237,9 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             p.ldb = round_up(p.nblk, 256);
             // (the threshold is the N-th best of at most 1024 seed scores: for lists longer than ~200 items it is too weak --
             // N = 1000 at ML-25M shape: 77 % of the blocks survive and the three passes cost twice the plain one)
-            p.prune = tune.prune && p.pack24 && p.Ic >= tune.prune_min_items && p.nblk < 0xFFFF &&
+            // (and clusters of a few hundred users are not pruned at all: their seed thresholds are weak -- at 400 clusters of ML-25M
+            // shape, 406 users each, 16-44 % of the blocks survive and the plain full pass is 1.6x faster than any pruned variant)
+            p.prune = tune.prune && p.pack24 && p.Ic >= tune.prune_min_items && p.nblk < 0xFFFF && p.Uc >= tune.prune_min_users &&
                       (tune.seed_forced || 5 * (int64_t)prm.number_of_recommendations <= 4 * 256);
             if (J->count_balanced && !p.prune) FY_FAIL(FY_ERR_STATE, "internal: count-balanced ownership without a cooperative cluster");
             // all ranks hold users of this cluster and can talk to each other: score it together, every rank with its
@@ -1269,7 +1275,11 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                         p.half = false;      // a row's block maxima need the whole row
                         // (the item ids of the row kernel hold the chunk in 8 bits)
                         pick_chunks(p.Ic, std::min<int>(max_ch_lds, std::max<int>(tune.panel_max_ch, (int)round_up(ceil_div(p.Ic, 255), 256))), p.CH, p.nch);
-                        p.panel_cols = (int32_t)std::min<int64_t>(p.ldm, std::max<int64_t>(round_up(tune.panel_cols, 256), (int64_t)tune.seed_chunks * 256));
+                        // smaller clusters keep a wider panel: their survivors reach further down the popularity order (measured,
+                        // ML-25M shape, ms per job with 4096 / 8192 columns: 50 clusters of 3250 users 124 / 141, 100 clusters of
+                        // 1625 users 295 / 227, 200 clusters of 812 users 919 / 509 -- the difference is blocks behind the panel)
+                        const int64_t want_cols = (int64_t)tune.panel_cols * (p.Uc < tune.panel_wide_below_users ? 2 : 1);
+                        p.panel_cols = (int32_t)std::min<int64_t>(p.ldm, std::max<int64_t>(round_up(want_cols, 256), (int64_t)tune.seed_chunks * 256));
                         p.tail_chunks = (int32_t)ceil_div(p.panel_cols, p.CH);
                         p.p_eff = (int32_t)std::min<int64_t>((int64_t)p.tail_chunks * p.CH, p.Ic);
                         if (p.p_eff % 256 != 0 || p.tail_chunks >= p.nch) { p.p_eff = p.Ic; p.tail_chunks = 0; }   // one chunk, or a ragged one: no tail rows
