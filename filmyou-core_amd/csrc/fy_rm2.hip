@@ -1617,7 +1617,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                     RepairArgs RA{L.surv.get(), L.surv_mask.get(), L.n_quads.get(), bld, nb, s0, lo, p.p_eff, Ic, P.rowptr.get(), P.csr_idx.get(),
                                   csr_x.get(), csr_e.get(), csr_q.get(), L.Bmax64.get(), L.Brep.get(), p.ldb64, L.amax64.get(), L.bmax64.get(),
                                   L.tau.get(), pvpi.get(), (float)((1.0 - lambda) * (1.0 - lambda)), prune_counters.get()};
-                    k_bound_repair<<<grid_for((int64_t)nb * 64, 256), 256, 0, ls>>>(RA);
+                    k_bound_repair<<<std::min<int>(nb, ctx->num_cus * 16), 256, 0, ls>>>(RA);
                     FY_KERNEL_CHECK();
                 }
                 exclusive_scan_i32(ctx, L.n_quads.get(), L.quad_prefix.get(), (size_t)nb + 1, ls);

@@ -764,10 +764,14 @@ __device__ __forceinline__ float fy_load24(const float* __restrict__ base3, int6
     return __uint_as_float(v << 7);
 }
 __global__ __launch_bounds__(256) void k_bound_repair(RepairArgs A) {
-    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    // One WORKGROUP per user: its four waves take every fourth surviving block (a wave per user left a cluster of 800 users on 200
+    // workgroups, each walking its user's blocks one after the other: 0.64 ms per cluster at 200 clusters), the new masks meet in
+    // LDS and wave 0 compacts the user's list.
+    __shared__ uint8_t sh_newmask[1024];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const double LN2 = 0.69314718055994530942;
     unsigned long long dropped = 0;
-    for (int u = blockIdx.x * wpb + (threadIdx.x >> 6); u < A.n_users; u += gridDim.x * wpb) {
+    for (int u = blockIdx.x; u < A.n_users; u += gridDim.x) {       // block-uniform
         const int ns = A.n_surv[u];
         const int slot = A.slot0 + u;
         const int r0 = A.rowptr[slot], r1 = A.rowptr[slot + 1];
@@ -776,49 +780,65 @@ __global__ __launch_bounds__(256) void k_bound_repair(RepairArgs A) {
         uint8_t* __restrict__ mask_of = A.surv_mask + (int64_t)u * A.ldsurv;
         const float t = A.tau[u];
         const double base = A.pvpi[slot - A.slot_lo];
-        int kept = 0;
-        for (int k = 0; k < ns; k++) {                              // wave-uniform
-            const int blk = (int)mine[k];
-            unsigned mask = mask_of[k];
-            for (int qb = 0; qb < 4; qb++) {
-                if (!((mask >> qb) & 1u)) continue;
-                const int sb = 4 * blk + qb;
-                const int c0 = sb * 64;
-                // the user's items inside the sub-block: the largest x among them (0: none -- the bound stands)
-                float ymax = 0.f;
-                for (int f = r0 + lane; f < r1; f += 64) {
-                    const unsigned d = (unsigned)(A.csr_idx[f] - c0);
-                    if (d < 64u) ymax = fmaxf(ymax, A.csr_x[f]);
-                }
-                for (int o = 32; o > 0; o >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, o, 64));
-                if (ymax == 0.f) continue;
-                const float am = A.amax64[sb], bm = A.bmax64[sb];
-                double sum = 0.0;
-                for (int f = r0 + lane; f < r1; f += 64) {
-                    const int j = A.csr_idx[f];
-                    float g = fy_load24(A.Bmax64, (int64_t)j * A.ldb64 + sb);
-                    if (g > 0.f) {
-                        if (j >= A.p_eff && c0 >= A.p_eff) {
-                            g = fmaxf(0.f, g - A.w2 * A.csr_x[f] * ymax * 0.999999f);
-                        } else {
-                            const uint32_t rep = A.Brep[(int64_t)j * A.ldb64 + sb];
-                            const int col = c0 + (int)(rep & 63u);
-                            int l = r0, h = r1;                     // did the user rate the column of the maximum?
-                            while (l < h) { const int m = (l + h) >> 1; if (A.csr_idx[m] < col) l = m + 1; else h = m; }
-                            if (l < r1 && A.csr_idx[l] == col) g = __uint_as_float((rep >> 8) << 7);
-                        }
+        for (int k0 = 0; k0 < ns; k0 += 1024) {                     // (a list longer than the LDS array: in pieces)
+            const int nk = min(1024, ns - k0);
+            for (int k = k0 + wave; k < k0 + nk; k += 4) {          // wave-uniform
+                const int blk = (int)mine[k];
+                unsigned mask = mask_of[k];
+                for (int qb = 0; qb < 4; qb++) {
+                    if (!((mask >> qb) & 1u)) continue;
+                    const int sb = 4 * blk + qb;
+                    const int c0 = sb * 64;
+                    // the user's items inside the sub-block: the largest x among them (0: none -- the bound stands)
+                    float ymax = 0.f;
+                    for (int f = r0 + lane; f < r1; f += 64) {
+                        const unsigned d = (unsigned)(A.csr_idx[f] - c0);
+                        if (d < 64u) ymax = fmaxf(ymax, A.csr_x[f]);
                     }
-                    sum += (double)fy_log2(fmaf(A.csr_q[f], bm, fmaf(am, A.csr_e[f], g)));
+                    for (int o = 32; o > 0; o >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, o, 64));
+                    if (ymax == 0.f) continue;
+                    const float am = A.amax64[sb], bm = A.bmax64[sb];
+                    double sum = 0.0;
+                    for (int f = r0 + lane; f < r1; f += 64) {
+                        const int j = A.csr_idx[f];
+                        float g = fy_load24(A.Bmax64, (int64_t)j * A.ldb64 + sb);
+                        if (g > 0.f) {
+                            if (j >= A.p_eff && c0 >= A.p_eff) {
+                                g = fmaxf(0.f, g - A.w2 * A.csr_x[f] * ymax * 0.999999f);
+                            } else {
+                                const uint32_t rep = A.Brep[(int64_t)j * A.ldb64 + sb];
+                                const int col = c0 + (int)(rep & 63u);
+                                int l = r0, h = r1;                     // did the user rate the column of the maximum?
+                                while (l < h) { const int m = (l + h) >> 1; if (A.csr_idx[m] < col) l = m + 1; else h = m; }
+                                if (l < r1 && A.csr_idx[l] == col) g = __uint_as_float((rep >> 8) << 7);
+                            }
+                        }
+                        sum += (double)fy_log2(fmaf(A.csr_q[f], bm, fmaf(am, A.csr_e[f], g)));
+                    }
+                    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+                    if (!fy_bound_keeps((float)(base + LN2 * sum), t, (float)base)) { mask &= ~(1u << qb); dropped++; }
                 }
-                for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-                if (!fy_bound_keeps((float)(base + LN2 * sum), t, (float)base)) { mask &= ~(1u << qb); dropped++; }
+                if (lane == 0) sh_newmask[k - k0] = (uint8_t)mask;
             }
-            if (mask) {                                             // compaction in place (kept <= k)
-                if (lane == 0) { mine[kept] = (uint16_t)blk; mask_of[kept] = (uint8_t)mask; }
-                kept++;
+            __syncthreads();
+            if (wave == 0) {                                            // compaction in place (kept <= position read)
+                int kept = k0 == 0 ? 0 : A.n_surv[u];                   // (pieces behind the first append to what the earlier ones kept)
+                for (int kk = 0; kk < nk; kk += 64) {
+                    const int k = kk + lane;
+                    const unsigned m = k < nk ? sh_newmask[k] : 0u;
+                    const int blk = k < nk ? (int)mine[k0 + k] : 0;
+                    const unsigned long long bal = __ballot(m != 0u);
+                    if (m) {
+                        const int at = kept + __popcll(bal & ((1ull << lane) - 1ull));
+                        mine[at] = (uint16_t)blk;
+                        mask_of[at] = (uint8_t)m;
+                    }
+                    kept += __popcll(bal);
+                }
+                if (lane == 0) A.n_surv[u] = kept;
             }
+            __syncthreads();
         }
-        if (lane == 0) A.n_surv[u] = kept;
     }
     if (lane == 0 && dropped) atomicAdd(&A.counters[4], dropped);
 }
