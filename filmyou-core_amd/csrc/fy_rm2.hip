@@ -1654,7 +1654,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                     FY_KERNEL_CHECK();
                     if (p.panel && panel_blocks < p.nblk) {     // survivors behind the panel: exact, from the sparse data
                         const size_t slds = ((size_t)p.Uc + 1) * sizeof(int32_t);
-                        const int sgrid = std::min<int>(n_surv_total, ctx->num_cus * (int)std::max<size_t>(1, std::min<size_t>(6, (150 * 1024) / (slds + 20 * 1024))));
+                        const int sgrid = std::min<int>(n_surv_total, ctx->num_cus * (int)std::max<size_t>(1, std::min<size_t>(6, (150 * 1024) / (slds + 34 * 1024))));
                         L.strayT.alloc(ctx, (size_t)sgrid * STRAY_TCAP);
                         L.stray_items.alloc(ctx, (size_t)n_surv_total + 1);      // (a group holds at least one surviving block)
                         FY_HIP(hipMemsetAsync(L.any_overflow.get(), 0, sizeof(int32_t), ls));   // reused as the item counter

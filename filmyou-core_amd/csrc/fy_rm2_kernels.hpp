@@ -857,8 +857,8 @@ __global__ __launch_bounds__(256) void k_bound_repair(RepairArgs A) {
 // A candidate costs its co-ratings with the list, not the length of its raters' rows.  Lists longer than STRAY_JCAP (or with
 // more than STRAY_TCAP co-raters) are walked in pieces -- the score is a sum over j -- and T is then rebuilt per block.
 constexpr int STRAY_UCAP = 32768;    // users of the cluster (panel mode is for many small clusters: fy_rm2.hip, Plan::panel)
-constexpr int STRAY_JCAP = 256;
-constexpr int STRAY_TCAP = 32768;    // >= STRAY_UCAP: one item's raters always fit
+constexpr int STRAY_JCAP = 512;
+constexpr int STRAY_TCAP = 65536;    // >= STRAY_UCAP: one item's raters always fit
 struct StrayArgs {
     const int32_t* __restrict__ surv_prefix;
     const uint16_t* __restrict__ surv;
