@@ -309,3 +309,20 @@ def test_panel_mode_many_clusters_equals_full_pass(monkeypatch):
     n_diff, worst = assert_same_lists(rp, full.rows(), score_rtol=1e-5, score_atol=ATOL)
     assert n_diff <= 4, n_diff
     ctx.close()
+
+
+def test_small_clusters_take_the_full_pass(forced, monkeypatch):
+    """Clusters of a few hundred users are not pruned (their seed thresholds are too weak: DESIGN.md section 7b, cluster-count
+    sweep): the user threshold FY_PRUNE_MIN_USERS (600 in production) decides per cluster; the lists are the oracle's either way."""
+    P = pkg()
+    data, clustering, conf, ref = make("ml100k", 3, "0.1", 20)       # 314 users per cluster
+    ctx = P.Context(0)
+    monkeypatch.setenv("FY_PRUNE_MIN_USERS", "400")
+    rec = P.RM2Job(conf, ctx).run(data, clustering=clustering)
+    assert rec.stats["blocks_total"] == 0 and rec.stats["panel_clusters"] == 0
+    assert_topn_matches(rec.rows(), ref, 20)
+    monkeypatch.setenv("FY_PRUNE_MIN_USERS", "100")
+    rec = P.RM2Job(conf, ctx).run(data, clustering=clustering)
+    assert rec.stats["blocks_total"] > 0
+    assert_topn_matches(rec.rows(), ref, 20)
+    ctx.close()
