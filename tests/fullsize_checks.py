@@ -28,8 +28,9 @@ def load_shape(shape):
     return dict(dev=(u, i, s), facts=facts, uu=uu, iu=iu, R=R, shape=shape)
 
 
-def run_rm2(data, top_n, lam, env=None):
-    """One RM2 job (one cluster) through the host mirror; `env` = tuning variables for this job only."""
+def run_rm2(data, top_n, lam, env=None, clusters=1):
+    """One RM2 job (users hashed to `clusters` clusters; 1 = one neighbourhood) through the host mirror; `env` = tuning variables for
+    this job only."""
     P = pkg()
     old = {}
     for k, v in (env or {}).items():
@@ -40,9 +41,13 @@ def run_rm2(data, top_n, lam, env=None):
         conf = P.Configuration()
         conf.set("lambda", repr(lam))
         conf.setInt("numberOfItems", data["facts"]["n_items"])
-        conf.setInt("numberOfClusters", 1)
+        conf.setInt("numberOfClusters", clusters)
         conf.setInt("numberOfRecommendations", top_n)
-        rec = P.RM2Job(conf, ctx).run(P.Ratings(ctx, *data["dev"]))
+        clustering = None
+        if clusters > 1:
+            uu = np.arange(1, data["facts"]["n_users"] + 1, dtype=np.int32)      # ids are 1..n in the synthetic shapes
+            clustering = (uu, synth().hash_clustering(uu, clusters))
+        rec = P.RM2Job(conf, ctx).run(P.Ratings(ctx, *data["dev"]), clustering=clustering)
         rows, sums, st = rec.rows(), rec.sums(), rec.stats
         rec.close()
         ctx.close()

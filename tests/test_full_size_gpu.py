@@ -41,5 +41,20 @@ def test_rm2_pruned_equals_full_pass_all_rows(data, pruned):
     assert n_diff <= 1e-5 * len(rows["user"])
 
 
+def test_rm2_panel_mode_50_clusters_equals_full_pass_all_rows(data):
+    """The reference's own regime at full size: 50 hashed clusters, column-panel mode (no dense matrix per cluster, 64-column block
+    bounds, tail-row bounds from the block-compressed CSR, second bound without the user's own co-ratings, strays from the sparse
+    data) against the same job with FY_PRUNE=0 (dense matrices, every log term): all 8.1 M rows."""
+    rows, _, st = run_rm2(data, TOPN, LAM, clusters=50)
+    assert st["panel_clusters"] == 50 and st["blocks_total"] > 0 and st["bound_repairs"] > 0
+    assert st["blocks_survived"] < 0.05 * st["blocks_total"]
+    rows_full, _, st_full = run_rm2(data, TOPN, LAM, env={"FY_PRUNE": "0"}, clusters=50)
+    assert st_full["panel_clusters"] == 0 and st_full["blocks_total"] == 0 and st_full["recs"] == st["recs"]
+    n_diff, worst = assert_same_lists(rows, rows_full, score_rtol=1e-5)
+    print("panel mode vs full pass, 50 clusters: %d rows, %d differ (ties at a cut-off), worst score difference %.2e, %d strays"
+          % (len(rows["user"]), n_diff, worst, st["stray_blocks"]))
+    assert n_diff <= 1e-5 * len(rows["user"])
+
+
 def test_itemsim_full_size(data):
     check_itemsim(data)

@@ -36,5 +36,16 @@ def test_rm2_netflix_pruned_equals_full_pass_all_rows(data, pruned):
     assert n_diff <= 1e-5 * len(rows["user"])
 
 
+def test_rm2_netflix_panel_mode_50_clusters_equals_full_pass_all_rows(data):
+    """50 hashed clusters (9 600 users each) in column-panel mode against the same job with FY_PRUNE=0: all 48 M rows."""
+    rows, _, st = run_rm2(data, TOPN, LAM, clusters=50)
+    assert st["panel_clusters"] == 50 and st["blocks_total"] > 0
+    rows_full, _, st_full = run_rm2(data, TOPN, LAM, env={"FY_PRUNE": "0"}, clusters=50)
+    assert st_full["panel_clusters"] == 0 and st_full["blocks_total"] == 0 and st_full["recs"] == st["recs"]
+    n_diff, worst = assert_same_lists(rows, rows_full, score_rtol=1e-5)
+    print("panel mode vs full pass, 50 clusters: %d rows, %d differ, worst score difference %.2e, %d strays" % (len(rows["user"]), n_diff, worst, st["stray_blocks"]))
+    assert n_diff <= 1e-5 * len(rows["user"])
+
+
 def test_itemsim_netflix_shape(data):
     check_itemsim(data, n_rows=4)
