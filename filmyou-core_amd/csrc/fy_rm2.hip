@@ -229,32 +229,42 @@ __global__ void k_pack_csr(int32_t f0, int32_t f1, int32_t CH, const int32_t* __
 // per tail row the sum of maxima is within ~14 % of the exact maximum (measured at ML-25M shape in 50 clusters: 1088
 // surviving blocks instead of 1080), a row needs ONE item with (I_c - p_eff) / 64 accumulators instead of one item per
 // 8192-column chunk, and no matrix element behind the panel is ever formed.
-// One wave per user; the user's compressed entries are written in place of the first entries of its CSR range (y_pk is as long
-// as the CSR), co2[2 k] / co2[2 k + 1] = their range: the "chunk offsets" of a one-chunk segment table.
-__global__ void k_tail_blocks(int32_t slot_base, int32_t n_slots, int32_t p_eff, const int32_t* __restrict__ rowptr,
-                              const int32_t* __restrict__ csr_idx, const float* __restrict__ csr_r, uint32_t* __restrict__ y_pk,
-                              int32_t* __restrict__ co2) {
-    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
-    for (int32_t k = blockIdx.x * wpb + (threadIdx.x >> 6); k < n_slots; k += gridDim.x * wpb) {
+// The user's compressed entries are written in place of the first entries of its CSR range (y_pk is as long as the CSR),
+// co2[2 k] / co2[2 k + 1] = their range: the "chunk offsets" of a one-chunk segment table.
+__global__ __launch_bounds__(256) void k_tail_blocks(int32_t slot_base, int32_t n_slots, int32_t p_eff, const int32_t* __restrict__ rowptr,
+                                                     const int32_t* __restrict__ csr_idx, const float* __restrict__ csr_r, uint32_t* __restrict__ y_pk,
+                                                     int32_t* __restrict__ co2) {
+    // One workgroup per user: the entries behind p_eff are a suffix of the row (found by a binary search), its 64-entry pieces
+    // are dealt to the four waves; a piece looks one entry back for the block of its predecessor and takes its output slots
+    // from an LDS counter (the order of a user's compressed entries does not matter: the sums they enter are integer sums).
+    __shared__ int sh_count;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int32_t k = blockIdx.x; k < n_slots; k += gridDim.x) {      // block-uniform
         const int32_t base = rowptr[slot_base + k], end = rowptr[slot_base + k + 1];
-        int count = 0, carry = -1;
-        for (int32_t f0 = base; f0 < end; f0 += 64) {       // (a user's CSR row is sorted by column)
+        int32_t lo = base, hi = end;                                  // first entry with column >= p_eff
+        while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (csr_idx[mid] < p_eff) lo = mid + 1; else hi = mid; }
+        const int32_t first = lo;
+        if (threadIdx.x == 0) sh_count = 0;
+        __syncthreads();
+        for (int32_t f0 = first + wave * 64; f0 < end; f0 += 4 * 64) {   // wave-uniform
             const int32_t f = f0 + lane;
-            const int32_t col = f < end ? csr_idx[f] : -1;
-            const int blk = col >= p_eff ? (col - p_eff) >> 6 : -1;
+            const int blk = f < end ? (csr_idx[f] - p_eff) >> 6 : -1;
             int prev = __shfl_up(blk, 1, 64);
-            if (lane == 0) prev = carry;
+            if (lane == 0) prev = f0 > first ? (csr_idx[f0 - 1] - p_eff) >> 6 : -1;
             const bool start = blk >= 0 && blk != prev;
             const unsigned long long bal = __ballot(start);
+            int at = 0;
+            if (lane == 0 && bal) at = atomicAdd(&sh_count, (int)__popcll(bal));
+            at = __shfl(at, 0, 64);
             if (start) {
                 float m = csr_r[f];
                 for (int32_t g = f + 1; g < end && ((csr_idx[g] - p_eff) >> 6) == blk; g++) m = fmaxf(m, csr_r[g]);
-                y_pk[base + count + __popcll(bal & ((1ull << lane) - 1ull))] = (uint32_t)blk | ((uint32_t)__half_as_ushort(__float2half(m)) << 16);
+                y_pk[base + at + __popcll(bal & ((1ull << lane) - 1ull))] = (uint32_t)blk | ((uint32_t)__half_as_ushort(__float2half(m)) << 16);
             }
-            count += __popcll(bal);
-            carry = __shfl(blk, 63, 64);
         }
-        if (lane == 0) { co2[2 * k] = base; co2[2 * k + 1] = base + count; }
+        __syncthreads();
+        if (threadIdx.x == 0) { co2[2 * k] = base; co2[2 * k + 1] = base + sh_count; }
+        __syncthreads();     // sh_count is read before the next user resets it
     }
 }
 
@@ -1415,7 +1425,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             build_segments(ctx, P.csc_slot.get(), use_pk ? csc_x_over_s.get() : csc_x.get(), co, p.sbase, p.q0, p.nq, p.nch, segs[pi], ts,
                            p.half ? csc_rank.get() : nullptr, P.csr_idx.get(), p.CH, nullptr, 0, seg_bound);
             if (p.p_eff < p.Ic) {
-                k_tail_blocks<<<grid_for((int64_t)p.Uc * 64), 256, 0, ts>>>(p.sbase, p.Uc, p.p_eff, P.rowptr.get(), P.csr_idx.get(), P.csr_r.get(),
+                k_tail_blocks<<<std::min<int>(p.Uc, ctx->num_cus * 16), 256, 0, ts>>>(p.sbase, p.Uc, p.p_eff, P.rowptr.get(), P.csr_idx.get(), P.csr_r.get(),
                                                                           y_pk.get(), co);
                 FY_KERNEL_CHECK();
                 build_segments(ctx, P.csc_slot.get(), csc_x_over_s.get(), co, p.sbase, p.q0, p.nq, 1, segs_tail[pi], ts, nullptr, nullptr, 0,
