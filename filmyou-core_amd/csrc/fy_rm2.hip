@@ -1634,8 +1634,13 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 // (5) exact scores of the survivors, packed: 256 floats per surviving block at entry quad_prefix[u] + k
                 int32_t hv[3] = {0, 0, 0};   // survivors, first / last CSR entry of the batch
                 FY_HIP(hipMemcpyAsync(&hv[0], L.quad_prefix.get() + nb, sizeof(int32_t), hipMemcpyDeviceToHost, ls));
-                FY_HIP(hipMemcpyAsync(&hv[1], P.rowptr.get() + s0, sizeof(int32_t), hipMemcpyDeviceToHost, ls));
-                FY_HIP(hipMemcpyAsync(&hv[2], P.rowptr.get() + s0 + nb, sizeof(int32_t), hipMemcpyDeviceToHost, ls));
+                if (s0 == sbase && nb == p.Uc) {      // the whole cluster: its CSR range is on the host already
+                    hv[1] = csr_range[2 * pi];
+                    hv[2] = csr_range[2 * pi + 1];
+                } else {
+                    FY_HIP(hipMemcpyAsync(&hv[1], P.rowptr.get() + s0, sizeof(int32_t), hipMemcpyDeviceToHost, ls));
+                    FY_HIP(hipMemcpyAsync(&hv[2], P.rowptr.get() + s0 + nb, sizeof(int32_t), hipMemcpyDeviceToHost, ls));
+                }
                 FY_HIP(hipStreamSynchronize(ls));   // (everything queued on this lane before has finished: Ssurv may be re-sized)
                 const int32_t n_surv_total = hv[0];
                 const int64_t blocks_checked = (int64_t)nb * std::max(0, p.nblk - seed_blocks);
@@ -1660,7 +1665,8 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                     ScoreArgs SQ = score_args(Gmat, gld, Ic, a_rank.get() + pbase, s0, nb, L.Ssurv.get(), 0, n_slices, n_chunks);
                     const int panel_blocks = p.panel ? p.panel_cols / 256 : 0x7FFFFFFF;
                     k_score_blocks<8><<<std::min(n_surv_total, ctx->num_cus * 16), 256, 0, ls>>>(SQ.M, SQ.a_rank, P.rowptr.get(), SQ.csr_idx, SQ.csr_e, SQ.csr_q, SQ.pvpi,
-                                                                        L.quad_prefix.get(), L.surv.get(), SQ.S, SQ, bld, prune_counters.get(), panel_blocks);
+                                                                        L.quad_prefix.get(), L.surv.get(), SQ.S, SQ, bld, prune_counters.get(), panel_blocks,
+                                                                        p.panel ? L.surv_mask.get() : nullptr);
                     FY_KERNEL_CHECK();
                     if (p.panel && panel_blocks < p.nblk) {     // survivors behind the panel: exact, from the sparse data
                         const size_t slds = ((size_t)p.Uc + 1) * sizeof(int32_t);

@@ -594,7 +594,8 @@ __global__ __launch_bounds__(256) void k_score_blocks(const float* __restrict__ 
                                                       const double* __restrict__ pvpi_,
                                                       const int32_t* __restrict__ surv_prefix_, const uint16_t* __restrict__ surv_,
                                                       float* __restrict__ S_, ScoreArgs A, int64_t ldb,
-                                                      unsigned long long* __restrict__ counters, int32_t panel_blocks = 0x7FFFFFFF) {
+                                                      unsigned long long* __restrict__ counters, int32_t panel_blocks = 0x7FFFFFFF,
+                                                      const uint8_t* __restrict__ surv_mask_ = nullptr) {
     __shared__ double sh_t[3][64][4];
     __shared__ unsigned sh_mask[3][64];
     const int lane = threadIdx.x & 63;
@@ -615,6 +616,9 @@ __global__ __launch_bounds__(256) void k_score_blocks(const float* __restrict__ 
         const int slot = A.slot0 + u;
         const int blk = (int)surv_[(int64_t)u * ldb + (w - surv_prefix_[u])];
         if (blk >= panel_blocks) continue;             // a block behind the column panel: k_score_stray's (block-uniform)
+        // panel mode: only the 64-column sub-blocks that passed the bounds are read and scored (16 lanes each); the others' lanes
+        // load nothing -- a surviving block has 1.3 live sub-blocks on average, and the pass is bound by the row segments it reads
+        const bool live = !surv_mask_ || ((surv_mask_[(int64_t)u * ldb + (w - surv_prefix_[u])] >> (lane >> 4)) & 1u);
         const int col0 = blk * PRUNE_BLOCK;
         const int col = col0 + lane * 4;
         float a[4], bb[4];
@@ -639,7 +643,8 @@ __global__ __launch_bounds__(256) void k_score_blocks(const float* __restrict__ 
                 jj[x] = csr_idx_[kk];
                 e[x] = csr_e_[kk];
                 qq[x] = csr_q_[kk];
-                g[x] = *reinterpret_cast<const U3*>(Mcol + (int64_t)jj[x] * pitch);
+                g[x] = U3{0u, 0u, 0u};
+                if (live) g[x] = *reinterpret_cast<const U3*>(Mcol + (int64_t)jj[x] * pitch);
             }
             float p[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -670,10 +675,10 @@ __global__ __launch_bounds__(256) void k_score_blocks(const float* __restrict__ 
             }
             const double base = pvpi_[slot - A.slot_lo];
             float4 o;
-            o.x = ((mask & 1u) || col + 0 >= A.Ic) ? qnan : (float)(base + LN2 * t[0]);
-            o.y = ((mask & 2u) || col + 1 >= A.Ic) ? qnan : (float)(base + LN2 * t[1]);
-            o.z = ((mask & 4u) || col + 2 >= A.Ic) ? qnan : (float)(base + LN2 * t[2]);
-            o.w = ((mask & 8u) || col + 3 >= A.Ic) ? qnan : (float)(base + LN2 * t[3]);
+            o.x = (!live || (mask & 1u) || col + 0 >= A.Ic) ? qnan : (float)(base + LN2 * t[0]);
+            o.y = (!live || (mask & 2u) || col + 1 >= A.Ic) ? qnan : (float)(base + LN2 * t[1]);
+            o.z = (!live || (mask & 4u) || col + 2 >= A.Ic) ? qnan : (float)(base + LN2 * t[2]);
+            o.w = (!live || (mask & 8u) || col + 3 >= A.Ic) ? qnan : (float)(base + LN2 * t[3]);
             // packed: entry w holds the block's 256 scores (the top-N kernels find them through quad_prefix)
             *reinterpret_cast<float4*>(S_ + (int64_t)w * PRUNE_BLOCK + lane * 4) = o;
             my_terms += (unsigned long long)(row_end - row_beg) * 256ull;

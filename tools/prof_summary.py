@@ -21,7 +21,7 @@ def main():
         tot = sum(v[1] for v in agg.values())
         print("# %s  total kernel ms %.3f" % (os.path.relpath(path, d), tot))
         print("%-60s %8s %12s %12s %6s" % ("kernel", "calls", "total_ms", "avg_ms", "%"))
-        for name, (n, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:25]:
+        for name, (n, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:int(os.environ.get('PROF_TOP', '25'))]:
             if want in name:
                 print("%-60s %8d %12.3f %12.4f %6.1f" % (name[:60], n, ms, ms / n, 100 * ms / tot))
     for path in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)):
