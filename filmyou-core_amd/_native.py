@@ -19,7 +19,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
 
 # every symbol include/filmyou.h declares (tests check the library exports exactly these)
 SYMBOLS = [
-    "fy_abi_version", "fy_last_error", "fy_context_create", "fy_context_destroy", "fy_context_synchronize", "fy_context_inject_alloc_failure",
+    "fy_abi_version", "fy_last_error", "fy_context_create", "fy_context_destroy", "fy_context_synchronize", "fy_context_reload_tuning", "fy_context_inject_alloc_failure",
     "fy_context_stream", "fy_ratings_create", "fy_ratings_destroy", "fy_ratings_nnz", "fy_rm2_prepare",
     "fy_rm2_partial_stats", "fy_rm2_set_global_stats", "fy_rm2_set_collectives", "fy_rccl_unique_id", "fy_rccl_create", "fy_rccl_collectives", "fy_rccl_counters", "fy_rccl_destroy", "fy_rm2_score", "fy_rm2_job_destroy", "fy_rm2_run",
     "fy_itemsim_build", "fy_itemsim_run", "fy_itemcf_recommend", "fy_cluster_assign", "fy_nmf_factorize", "fy_result_size", "fy_result_key0", "fy_result_key1", "fy_result_value",
@@ -39,15 +39,33 @@ def _stale():
 
 
 def build(force=False, verbose=False):
-    """hipcc cross-compiles for gfx950 without a GPU (about half a minute).  Returns the .so path."""
+    """hipcc cross-compiles for gfx950 without a GPU: one object per source (in parallel, only the stale ones), then one link.
+    Returns the .so path."""
     if not force and not _stale():
         build_host_driver()
         return LIB_PATH
-    os.makedirs(LIB_DIR, exist_ok=True)
+    from concurrent.futures import ThreadPoolExecutor
+    obj_dir = os.path.join(LIB_DIR, "obj")
+    os.makedirs(obj_dir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
-    cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
+    cflags = [f for f in HIPCC_FLAGS if f not in ("-shared", "-ldl")]
+    common = max(os.path.getmtime(d) for d in [os.path.join(CSRC, h) for h in HEADERS] + [INCLUDE])
+
+    def compile_one(src):
+        path, obj = os.path.join(CSRC, src), os.path.join(obj_dir, src + ".o")
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(common, os.path.getmtime(path)):
+            return obj
+        cmd = [hipcc] + cflags + ["-c", "-o", obj, path]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB_PATH] + objs + ["-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
@@ -109,7 +127,8 @@ class Stats(C.Structure):
                 ("ms_topn", C.c_double), ("ms_total", C.c_double), ("score_launches", C.c_int64),
                 ("cooc_launches", C.c_int64), ("blocks_total", C.c_int64), ("blocks_survived", C.c_int64),
                 ("log_terms_evaluated", C.c_int64), ("prune_fallbacks", C.c_int64), ("ms_tables", C.c_double), ("ms_mirror", C.c_double), ("topn_select_users", C.c_int64),
-                ("panel_clusters", C.c_int64), ("stray_blocks", C.c_int64), ("bound_repairs", C.c_int64)]
+                ("panel_clusters", C.c_int64), ("stray_blocks", C.c_int64), ("bound_repairs", C.c_int64),
+                ("isim_candidates", C.c_int64), ("isim_redone_rows", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -144,6 +163,7 @@ def load():
     L.fy_context_destroy.restype = None
     L.fy_context_synchronize.argtypes = [vp]
     L.fy_context_inject_alloc_failure.argtypes = [vp, i64]
+    L.fy_context_reload_tuning.argtypes = [vp]
     L.fy_context_stream.argtypes = [vp]
     L.fy_context_stream.restype = vp
     L.fy_ratings_create.argtypes = [vp, i64, vp, vp, vp, C.c_int, pvp]

@@ -1,4 +1,6 @@
 // fy_api.hip -- the extern "C" surface declared in include/filmyou.h: context, ratings, results, error plumbing.
+#include <algorithm>
+#include <cstdlib>
 #include <memory>
 #include <new>
 
@@ -17,6 +19,45 @@ const char* last_error() { return g_err; }
 }  // namespace fy
 
 using namespace fy;
+
+// the ONE place the library reads its environment (fy_context_create, fy_context_reload_tuning)
+void fy::load_tuning_from_env(Tuning& t) {
+    t = Tuning{};
+    if (const char* e = getenv("FY_M24")) t.pack24 = atoi(e) != 0;
+    if (const char* e = getenv("FY_M24_MIN_ITEMS")) t.pack24_min_items = atoi(e);
+    if (const char* e = getenv("FY_SCORE_SLICES")) t.max_slices = atoi(e);
+    if (const char* e = getenv("FY_SCORE_UPW")) { int v = atoi(e); if (v >= 1) t.users_per_wave = v; }
+    if (const char* e = getenv("FY_PRUNE")) t.prune = atoi(e) != 0;
+    if (const char* e = getenv("FY_COOP")) t.coop = atoi(e) != 0;
+    if (const char* e = getenv("FY_COOP_FORCE")) t.coop_force = atoi(e) != 0;
+    if (const char* e = getenv("FY_COOC_PK")) t.cooc_pk = atoi(e) != 0;
+    if (const char* e = getenv("FY_COOC_F32")) t.cooc_f32 = atoi(e) != 0;
+    if (const char* e = getenv("FY_COOC_HALF")) t.cooc_half = atoi(e) != 0;
+    if (const char* e = getenv("FY_COOC_FX")) t.cooc_fx = atoi(e) != 0;
+    if (const char* e = getenv("FY_PANEL_MIN_CLUSTERS")) { int v = atoi(e); if (v >= 1) t.panel_min_clusters = v; }
+    if (const char* e = getenv("FY_PANEL_COLS")) { int v = atoi(e); if (v >= 256) { t.panel_cols = v; t.panel_wide_below_users = 0; } }
+    if (const char* e = getenv("FY_PANEL_WIDE_BELOW_USERS")) { int v = atoi(e); if (v >= 0) t.panel_wide_below_users = v; }
+    if (const char* e = getenv("FY_PANEL_MAX_CH")) { int v = atoi(e); if (v >= 256) t.panel_max_ch = v; }
+    if (const char* e = getenv("FY_BOUNDED_TABLES")) t.bounded_tables = atoi(e) != 0;
+    if (const char* e = getenv("FY_COOC_PLANES")) t.cooc_planes = atoi(e) != 0;
+    if (const char* e = getenv("FY_SCORE_HEAVY")) { int v = atoi(e); if (v >= 0) t.score_heavy = v; }
+    if (const char* e = getenv("FY_PANEL_REPAIR")) t.panel_repair = atoi(e) != 0;
+    if (const char* e = getenv("FY_PANEL_LANES")) { int v = atoi(e); if (v >= 1 && v <= 8) t.panel_lanes = v; }
+    if (const char* e = getenv("FY_PRUNE_MIN_ITEMS")) { t.prune_min_items = atoi(e); t.prune_min_users = 0; }   // (a forced item threshold -- tests -- lifts the user threshold too)
+    if (const char* e = getenv("FY_PRUNE_MIN_USERS")) { int v = atoi(e); if (v >= 0) t.prune_min_users = v; }
+    if (const char* e = getenv("FY_SEED_CHUNKS")) { int v = atoi(e); if (v >= 0 && v <= 4) { t.seed_chunks = v; t.seed_forced = v > 0; } }
+    if (const char* e = getenv("FY_WORKSPACE_GB")) { long v = atol(e); if (v >= 1) t.workspace_default = (int64_t)v << 30; }
+    if (const char* e = getenv("FY_LANES")) { int v = atoi(e); if (v >= 1 && v <= 8) t.lanes = v; t.lanes_forced = true; }
+    if (const char* e = getenv("FY_COOC_BLOCK")) { int v = atoi(e); if (v == 256 || v == 512 || v == 1024) t.cooc_block = v; }
+    if (const char* e = getenv("FY_COOC_MAX_CH")) { int v = atoi(e); if (v >= 64 && v <= 20224) { t.cooc_max_ch = v; t.cooc_max_ch_forced = true; } }
+    if (const char* e = getenv("FY_TOPN_FORCE_SELECT")) t.force_select = atoi(e) != 0;
+    if (const char* e = getenv("FY_MAX_SURV_FRAC")) { double v = atof(e); if (v >= 0.0) t.max_surv_frac = v; }
+    if (const char* e = getenv("FY_ISIM_HEAVY")) t.isim_heavy = std::max(0, atoi(e));
+    if (const char* e = getenv("FY_ISIM_GRAM")) t.isim_gram = atoi(e) != 0;
+    if (const char* e = getenv("FY_ISIM_GRAM_MIN_ITEMS")) t.isim_gram_min_items = std::max(0, atoi(e));
+    if (const char* e = getenv("FY_ISIM_CAPG")) { int v = atoi(e); if (v >= 1 && v <= 2040) t.isim_capg = v; }
+    if (const char* e = getenv("FY_ISIM_PIECE")) { int v = atoi(e); if (v >= 64 && v % 64 == 0) t.isim_piece = v; }
+}
 
 // every entry point: no exception may cross the ABI
 #define FY_TRY try {
@@ -60,6 +101,7 @@ int fy_context_create(int device_ordinal, fy_context** out) {
     c->c.num_cus = prop.multiProcessorCount;
     c->c.total_mem = prop.totalGlobalMem;
     FY_HIP(hipStreamCreateWithFlags(&c->c.stream, hipStreamNonBlocking));
+    fy::load_tuning_from_env(c->c.tune);
     *out = c.release();
     FY_CATCH
 }
@@ -82,6 +124,12 @@ void fy_context_destroy(fy_context* c) {
 int fy_context_inject_alloc_failure(fy_context* c, int64_t nth) {
     if (!c || nth < 0) { set_error("context is NULL or nth < 0"); return FY_ERR_INVALID_ARGUMENT; }
     c->c.fail_alloc_in = nth;
+    return FY_OK;
+}
+
+int fy_context_reload_tuning(fy_context* c) {
+    if (!c) { set_error("context is NULL"); return FY_ERR_INVALID_ARGUMENT; }
+    fy::load_tuning_from_env(c->c.tune);
     return FY_OK;
 }
 

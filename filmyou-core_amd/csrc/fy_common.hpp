@@ -18,6 +18,8 @@ namespace fy {
 // ---------------------------------------------------------------- errors
 void set_error(const char* fmt, ...);
 const char* last_error();
+struct Tuning;
+void load_tuning_from_env(Tuning& t);   // fy_api.hip
 
 struct Failure {
     int code;
@@ -40,6 +42,54 @@ struct Failure {
 
 #define FY_KERNEL_CHECK() FY_HIP(hipGetLastError())
 
+// ---------------------------------------------------------------- launch-shape knobs
+// Defaults are the production values.  The environment overrides (FY_*) are TEST AND MEASUREMENT HOOKS: each
+// one forces a path that the default heuristics would pick only at a larger size, so that the parity tests can drive every
+// path at a size the oracle finishes; none of them changes a result beyond the summation order.  The environment is read ONCE,
+// when the context is created (load_tuning_from_env, fy_api.hip; fy_context_reload_tuning reads it again) -- no job calls getenv.
+struct Tuning {
+    int force_select = 0;              // route every user through k_topn_select
+    int pack24 = 1;                    // M rows as 24-bit floats (3 bytes per element): -25 % of the dominant traffic
+    int pack24_min_items = 4096;       // ... for clusters with at least this many items
+    int max_slices = 65536;            // user slices (workgroups) per column chunk
+    int users_per_wave = 16;           // users a wave of the scoring kernel walks for one column chunk
+    int64_t workspace_default = (int64_t)16 << 30;   // score scratch per batch of users
+    int lanes = 4;                     // HIP streams the clusters of one job are spread over
+    bool lanes_forced = false;         // FY_LANES given: panel mode does not lower it
+    int prune = 1;                     // branch and bound over 256-column candidate blocks
+    int prune_min_items = 8192;
+    int seed_chunks = 0;               // 256-column chunks scored exactly before the bound pass (the most popular candidates);
+                                       // 0 = from the list length: ~5 N columns (N = 50: one chunk, N = 100: two), at most four
+    int cooc_block = 0;                // force the row kernel's workgroup size
+    int cooc_max_ch = 19968;           // LDS accumulators of the row kernel: 156 KiB of 64-bit words of the 160 KiB LDS (ML-25M shape: three
+                                       // column chunks instead of four, 19.7 -> 17.8 ms; smaller forces more chunks)
+    bool cooc_max_ch_forced = false;   // FY_COOC_MAX_CH given (the item-similarity build has its own default)
+    int seed_forced = 0;               // FY_SEED_CHUNKS given: prune whatever the list length
+    int coop = 1;                      // cooperative scoring of clusters that span all ranks (needs fy_collectives)
+    int coop_force = 0;                // cooperative path also with world == 1 (identity collectives)
+    int cooc_pk = 1;                   // packed 4-byte CSR entries for the row kernel when the ratings are fp16-exact
+    int cooc_f32 = 0;                  // row kernel accumulators in fp32 (ds_add_f32): MEASUREMENT ONLY -- 4x slower, see fy_cooc.hpp
+    int cooc_half = 1;                 // symmetric walk (upper triangle + mirror pass) for clusters with packed rows
+    int cooc_fx = 1;                   // fixed-point (ds_add_u64) accumulation in the packed walk
+    int panel_min_clusters = 4;        // column-panel mode when at least this many clusters of the rank are pruned ones
+    int prune_min_users = 600;         // clusters with fewer users take the plain full pass
+    int panel_wide_below_users = 2500; // panel mode: clusters with fewer users keep twice the panel columns
+    int panel_cols = 4096;             // columns of a row kept in panel mode (the seed columns and the popular blocks)
+    bool bounded_tables = true;        // FY_BOUNDED_TABLES=0: exact table sizes (two host round trips per table)
+    bool cooc_planes = true;           // FY_COOC_PLANES=0: linear accumulator layout (measurement only)
+    int score_heavy = 512;             // users with more ratings are walked by a whole workgroup of the scoring kernel (0 = off)
+    bool panel_repair = true;          // FY_PANEL_REPAIR=0: measurement only
+    int panel_lanes = 2;               // job lanes when clusters run in panel mode (measured, 50 clusters: 1 lane 300 ms, 2: 213, 3: 230, 4: 240)
+    int panel_max_ch = 4096;           // chunk width of the row kernel in panel mode: five workgroups per CU (measured, 50 clusters, row kernel ms: 8192 -> 67, 6144 -> 54, 4096 -> 46)
+    double max_surv_frac = 0.25;       // a pruned batch whose surviving blocks exceed this fraction falls back to the full pass
+    // item-item similarity build (fy_itemsim.hip)
+    int isim_heavy = 4096;             // row-at-a-time kernel: raters above which a row is split by column chunk
+    int isim_gram = -1;                // symmetric Gram + band sweep: -1 = by size (cosine, >= isim_gram_min_items items), 0 = never, 1 = whenever possible
+    int isim_gram_min_items = 4096;
+    int isim_capg = 2040;              // candidates a row of the band sweep may collect before it is redone exactly (<= 2040: k_isim_finish sorts them in LDS)
+    int isim_piece = 8192;             // columns per piece of the band sweep
+};
+
 // ---------------------------------------------------------------- context
 // One GPU, one stream, and a caching HBM allocator.  Every kernel and copy of a context runs on `stream`, so a block
 // released by the host while work is still queued may be handed to a later allocation: the later user is ordered behind
@@ -56,6 +106,7 @@ struct Context {
     std::multimap<size_t, void*> free_blocks;   // capacity -> block
     std::map<void*, size_t> capacity;            // every block ever handed out
     int64_t fail_alloc_in = 0;                   // fault injection (fy_context_inject_alloc_failure): the n-th request from now fails
+    Tuning tune;                                 // launch-shape knobs, read from the environment when the context is created
 
     void* alloc(size_t bytes) {
         const size_t want = (bytes + 255) & ~size_t(255);

@@ -8,10 +8,17 @@
 //   co-occurrence sim(i, j) = #users who rated both
 // over co-rated pairs only, j != i when excludeSelfSimilarity, sim >= threshold (no threshold: sim > 0), the
 // maxSimilaritiesPerRow best per item (ties, unspecified in Mahout, by ascending item id).
-// No dense I x I matrix is ever written: a workgroup owns item row i, accumulates it chunk by chunk in LDS (fp64) and
-// keeps a running top-K in LDS; only I x K rows leave the chip.
+// Two builds:
+//  * symmetric (round 3; cosine on positive fp16-exact ratings, one rank, the benchmark sizes): the product is symmetric, so
+//    only its upper triangle is accumulated -- by the RM2 row kernel itself (fy_rm2.hip: gram_half_build: symmetric walk,
+//    fixed-point ds_add_u64, half the pair visits) into an fp32 matrix in HBM -- and k_isim_sweep streams every element ONCE
+//    for BOTH rows it belongs to: G[i][j] (i < j) is a candidate of row i where it is read along the row and of row j where
+//    it is read down the column, 64 rows (= 256-byte row segments) at a time.  No mirror pass.
+//  * row at a time (every other configuration): a workgroup owns item row i, accumulates it chunk by chunk in LDS (fp64) and
+//    keeps a running top-K in LDS; no I x I matrix is written, only I x K rows leave the chip.
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <memory>
 
 #include "fy_cooc.hpp"
@@ -326,6 +333,463 @@ __global__ void k_cooc_itemsim(CoocArgs A, ISimEpilogue E, int* __restrict__ nex
     }
 }
 
+
+// ================================================================ symmetric build: band sweep over the fp32 half Gram
+// G (fy_rm2.hip: gram_half_build): row i holds sum_v r_vi r_vj for the columns j > i (exact zeros for (i & ~255) <= j <= i,
+// nothing in front).  sim(i, j) = G * inv_norm[i] * inv_norm[j].  A workgroup owns a PIECE = (band of 64 rows [i0, i0 + 64)) x
+// (column range [c0, c1)):
+//   * "down the column": for every row j in [c0, c1) above the band (j < i0 + lane), the 256-byte segment G[j][i0 .. i0 + 64) --
+//     lane l looks at the candidate j of ITS row i0 + l;
+//   * "along the row": for every row of the band, G[i][max(c0, i0) .. c1) in 1 KB tiles -- all lanes look at candidates of one row.
+// Every element of the triangle is read exactly once by each of the two rows it belongs to; a band's pieces have equal size.
+// Running top-K without a sort: a candidate must reach the row's threshold key tau (float bits order like the floats: all
+// similarities here are > 0).  Passing candidates are appended to the row's list in HBM and counted in a 64-bucket histogram of
+// their keys in LDS (8 buckets per octave below 1.0); when a row has collected K more, tau rises to the lower edge of the
+// highest bucket with K candidates at or above it -- a valid lower bound of the row's final K-th best (they are K real
+// candidates of the row), shared with the band's other pieces through tau_g.  After warm-up a few candidates per thousand
+// pass; k_isim_finish selects and sorts the lists.  A row whose list overflows (massive ties inside one bucket) is redone
+// exactly by k_isim_finish from the matrix.
+constexpr int SWEEP_KEY_SHIFT = 20, SWEEP_KEY_BASE = 1016 - 63;   // bucket = (key >> 20) - base: 63 <-> [1, 1.125), 0 <-> everything below 2^-7.875
+struct SweepArgs {
+    const float* __restrict__ G;
+    int64_t ldm;
+    int32_t Ic, K;
+    const float* __restrict__ invn32;          // [ldm + slack] 1 / norm in rank order, fp32 (0 behind Ic): the prefilter
+    const double* __restrict__ invn;           // [Ic]
+    const int32_t* __restrict__ rank_item_raw;
+    uint32_t* __restrict__ tau_g;              // [Ic]: key a candidate of the row must reach
+    int32_t* __restrict__ gcnt;                // [Ic]: candidates appended
+    uint64_t* __restrict__ glist;              // [Ic][capg]: key << 32 | (0x7FFFFFFF - raw item id)
+    int32_t capg;
+    int32_t* __restrict__ overflow;            // [Ic]
+    int32_t nbands, piece;
+    uint32_t tau0;                             // the job's own threshold as a key (1 = "similarity > 0")
+    int32_t exclude_self;
+    int32_t* __restrict__ out_cnt;             // k_isim_finish: [Ic], [Ic * K], [Ic * K]
+    int32_t* __restrict__ out_other;
+    float* __restrict__ out_sim;
+};
+
+// wave-level: lanes with `pass` hold a candidate (row i = band row rl, column col, raw Gram value v) that survived the fp32
+// prefilter; exact value, append, histogram, and -- every 8th candidate of a row once it has K -- a new threshold for the row
+__device__ __forceinline__ void sweep_take(const SweepArgs& A, uint32_t (*H)[64], uint32_t* tau_l, uint32_t* cnt_l, bool pass, int rl, int i, int col,
+                                           float v, int i0) {
+    const int lane = threadIdx.x & 63;
+    bool trig = false;
+    if (pass) {
+        const float sf = (float)((double)v * A.invn[i] * A.invn[col]);
+        const uint32_t key = __float_as_uint(sf);
+        if (sf > 0.0f && key >= tau_l[rl]) {
+            int bk = (int)(key >> SWEEP_KEY_SHIFT) - SWEEP_KEY_BASE;
+            bk = bk < 0 ? 0 : (bk > 63 ? 63 : bk);
+            atomicAdd(&H[rl][bk], 1u);
+            const uint32_t n = atomicAdd(&cnt_l[rl], 1u) + 1u;
+            const int pos = atomicAdd(&A.gcnt[i], 1);
+            if (pos < A.capg) A.glist[(int64_t)i * A.capg + pos] = ((uint64_t)key << 32) | (uint32_t)(0x7FFFFFFF - A.rank_item_raw[col]);
+            else A.overflow[i] = 1;
+            trig = n >= (uint32_t)A.K && (n & 7u) == 0u;
+        }
+    }
+    unsigned long long m = __ballot(trig);
+    while (m) {   // wave-uniform
+        const int src = __ffsll((long long)m) - 1;
+        const int r = __shfl(rl, src, 64);
+        m &= ~__ballot(rl == r);                       // (along a row every lane holds the same row)
+        uint32_t h = H[r][lane];                       // suffix sums over the buckets: candidates at or above bucket `lane`
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_down((int)h, o, 64);
+            if (lane + o < 64) h += t;
+        }
+        const unsigned long long ok = __ballot(h >= (uint32_t)A.K);
+        if (ok) {
+            const int B = 63 - __clzll((long long)ok);
+            if (B > 0 && lane == 0) {
+                const uint32_t nt = (uint32_t)(B + SWEEP_KEY_BASE) << SWEEP_KEY_SHIFT;
+                atomicMax(&tau_l[r], nt);
+                atomicMax(&A.tau_g[i0 + r], nt);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_isim_sweep(SweepArgs A) {
+    __shared__ uint32_t H[64][64];
+    __shared__ uint32_t tau_l[64], cnt_l[64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p = blockIdx.x / A.nbands, b = blockIdx.x - p * A.nbands;
+    const int i0 = b * 64;
+    const int c0 = p * A.piece, c1 = min(c0 + A.piece, (int)A.ldm);
+    for (int t = tid; t < 64 * 64; t += 256) (&H[0][0])[t] = 0u;
+    if (tid < 64) {
+        tau_l[tid] = i0 + tid < A.Ic ? A.tau_g[i0 + tid] : 0xFFFFFFFFu;
+        cnt_l[tid] = 0u;
+    }
+    __syncthreads();
+    // The fast path of both parts is straight-line: U loads in flight, one compare per element against the row's threshold in
+    // fp32 with a margin, the outcome kept as one bit per element.  Only when some lane of the wave holds a set bit does the
+    // wave enter the slow path -- ONE copy of sweep_take per part, each lane presenting its own lowest set element.  (The first
+    // version called sweep_take from every unrolled compare: 24 inlined copies, and it read the column-side norms with
+    // wave-uniform loads that the compiler turned into dependent vector loads behind s_waitcnt vmcnt(0): 8.6 ms for 14 GB.)
+    // ---- down the column: rows j of the matrix in [c0, jend), segment [i0, i0 + 64); wave w takes j = c0 + w, c0 + w + 4, ...
+    const int jend = min(min(c1, i0 + 64), A.Ic);
+    if (c0 < jend) {
+        const int i = i0 + lane;
+        const bool valid = i < A.Ic;
+        const float my_inv = valid ? A.invn32[i] : 0.0f;
+        const float* __restrict__ gp = A.G + i0 + lane;
+        constexpr int U = 8;
+        for (int jb = c0 + wave; jb < jend; jb += 4 * 64) {     // 64 of the wave's rows per block: their norms in one load, lane k <-> row jb + 4 k
+            const float nj_vec = A.invn32[min(jb + 4 * lane, jend - 1)];
+            for (int k0 = 0; k0 < 64 && jb + 4 * k0 < jend; k0 += U) {     // wave-uniform
+                float v[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) v[u] = gp[(int64_t)min(jb + 4 * (k0 + u), jend - 1) * A.ldm];     // unconditional loads (a clamped row is masked below)
+                const float tauf = __uint_as_float(tau_l[lane]) * 0.999999f;
+                uint32_t pm = 0;
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int jj = jb + 4 * (k0 + u);
+                    const float nj = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(nj_vec), k0 + u));
+                    const float s = v[u] * nj * my_inv;
+                    // (bitwise, not &&: short-circuit evaluation turned these into exec-masked branches around the loads)
+                    pm |= ((uint32_t)valid & (uint32_t)(jj < jend) & (uint32_t)(jj < i) & (uint32_t)(s > 0.0f) & (uint32_t)(s >= tauf)) << u;
+                }
+                while (__ballot(pm != 0)) {      // slow path: rare once the thresholds have warmed up
+                    const int u = pm ? __ffs((int)pm) - 1 : 0;
+                    float vu = v[0];
+#pragma unroll
+                    for (int q = 1; q < U; q++) vu = u == q ? v[q] : vu;
+                    sweep_take(A, H, tau_l, cnt_l, pm != 0, lane, i, jb + 4 * (k0 + u), vu, i0);
+                    pm &= pm - 1;
+                }
+            }
+        }
+    }
+    // ---- along the row: columns [cs, c1) of the band's rows (a row's candidates are the columns behind it)
+    const int cs = max(c0, i0);
+    if (cs < c1) {
+        constexpr int U = 4;
+        for (int r = wave; r < 64; r += 4) {
+            const int i = i0 + r;
+            if (i >= A.Ic) break;                            // wave-uniform
+            const float ri = A.invn32[i];
+            const float* __restrict__ grow = A.G + (int64_t)i * A.ldm;
+            for (int t0 = cs + 4 * lane; t0 < c1 + 4 * lane; t0 += 256 * U) {     // (t0 - 4 lane is wave-uniform)
+                float4 v[U], n4[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {                // tiles behind c1 read the slack behind the row / the matrix: masked below
+                    v[u] = *reinterpret_cast<const float4*>(grow + t0 + 256 * u);
+                    n4[u] = *reinterpret_cast<const float4*>(A.invn32 + t0 + 256 * u);
+                }
+                const float tauf = __uint_as_float(tau_l[r]) * 0.999999f;
+                float vv[4 * U];
+                uint32_t pm = 0;
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    vv[4 * u + 0] = v[u].x; vv[4 * u + 1] = v[u].y; vv[4 * u + 2] = v[u].z; vv[4 * u + 3] = v[u].w;
+                    const float nn[4] = {n4[u].x, n4[u].y, n4[u].z, n4[u].w};
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int col = t0 + 256 * u + e;
+                        const float s = vv[4 * u + e] * ri * nn[e];
+                        pm |= ((uint32_t)(col < c1) & (uint32_t)(col > i) & (uint32_t)(col < A.Ic) & (uint32_t)(s > 0.0f) & (uint32_t)(s >= tauf)) << (4 * u + e);
+                    }
+                }
+                while (__ballot(pm != 0)) {
+                    const int x = pm ? __ffs((int)pm) - 1 : 0;
+                    float vx = vv[0];
+#pragma unroll
+                    for (int q = 1; q < 4 * U; q++) vx = x == q ? vv[q] : vx;
+                    sweep_take(A, H, tau_l, cnt_l, pm != 0, r, i, t0 + 256 * (x >> 2) + (x & 3), vx, i0);
+                    pm &= pm - 1;
+                }
+            }
+        }
+    }
+}
+
+// (LDS traffic between the lanes of ONE wave needs no s_barrier -- a wave's LDS instructions complete in order -- only a
+// compiler fence, so that a lane's read of another lane's word is not moved in front of the writes)
+__device__ __forceinline__ void isim_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+// the diagonal candidate of row i (not part of the triangle): sum r^2 / norm^2; 0 = none
+__device__ __forceinline__ uint64_t isim_self_candidate(const SweepArgs& A, int i) {
+    if (A.exclude_self) return 0ull;
+    const double inv_i = A.invn[i], nrm = 1.0 / inv_i;
+    const float sf = (float)(nrm * nrm * inv_i * inv_i);
+    const uint32_t key = __float_as_uint(sf);
+    return (sf > 0.0f && key >= A.tau0) ? (((uint64_t)key << 32) | (uint32_t)(0x7FFFFFFF - A.rank_item_raw[i])) : 0ull;
+}
+
+// One WAVE per row: the K best of the row's candidate list (a few hundred entries of 8 bytes, L2-resident), sorted by
+// descending similarity, ties by ascending item id -- the order of the composite key << 32 | (0x7FFFFFFF - id), all distinct.
+// More than FIN_SMALL candidates are first cut by a radix select over the composite, 8 bits per level from the top, until the
+// entries at or above the prefix fit the sort buffer (two levels = 16 key bits in practice; eight levels are exact for any
+// input).  No workgroup barrier anywhere: 59 047 workgroups with ~40 barriers each were 2.0 ms, this is one pass of waves.
+// Rows whose list overflowed in the sweep are handed to k_isim_redo.
+constexpr int FIN_SURV = 512, FIN_SMALL = 128;
+__global__ __launch_bounds__(256) void k_isim_finish(SweepArgs A, int32_t* __restrict__ redo_list, int32_t* __restrict__ n_redo) {
+    __shared__ uint64_t surv_all[4][FIN_SURV];
+    __shared__ uint32_t hist_all[4][256];
+    __shared__ uint32_t scal_all[4][4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = blockIdx.x * 4 + w;
+    if (i >= A.Ic) return;                               // wave-uniform; nothing below synchronises the workgroup
+    if (A.overflow[i]) {
+        if (lane == 0) redo_list[atomicAdd(n_redo, 1)] = i;
+        return;
+    }
+    uint64_t* surv = surv_all[w];
+    uint32_t* hist = hist_all[w];
+    uint32_t* scal = scal_all[w];
+    const int n = min(A.gcnt[i], A.capg);
+    const uint64_t* __restrict__ L = A.glist + (int64_t)i * A.capg;
+    const uint64_t c_self = isim_self_candidate(A, i);
+    const int m = n + (c_self ? 1 : 0);
+    auto get = [&](int t) -> uint64_t { return t < n ? L[t] : c_self; };
+    int cnt = 0;
+    if (m <= FIN_SMALL || m <= A.K) {                   // (K <= 512 = FIN_SURV here: itemsim_symmetric)
+        for (int t = lane; t < m && t < FIN_SURV; t += 64) surv[t] = get(t);
+        cnt = min(m, FIN_SURV);
+        if (m > FIN_SURV) cnt = -1;                      // K > FIN_SURV never reaches this kernel
+    } else {
+        uint64_t prefix = 0;
+        uint32_t above = 0;
+        int shift = 56;
+        for (;; shift -= 8) {
+            for (int bb = lane; bb < 256; bb += 64) hist[bb] = 0u;
+            isim_wave_sync();
+            const uint64_t hi_mask = shift == 56 ? 0ull : ~0ull << (shift + 8);
+            for (int t = lane; t < m; t += 64) {
+                const uint64_t c = get(t);
+                if ((c & hi_mask) == prefix) atomicAdd(&hist[(uint32_t)(c >> shift) & 255u], 1u);
+            }
+            isim_wave_sync();
+            if (lane == 0) {
+                uint32_t cum = above;
+                int bb = 255;
+                for (; bb > 0; bb--) {
+                    if (cum + hist[bb] >= (uint32_t)A.K) break;
+                    cum += hist[bb];
+                }
+                scal[0] = (uint32_t)bb;
+                scal[1] = cum;
+                scal[2] = cum + hist[bb];
+            }
+            isim_wave_sync();
+            prefix |= (uint64_t)scal[0] << shift;
+            above = scal[1];
+            const uint32_t at_or_above = scal[2];
+            isim_wave_sync();
+            if (at_or_above <= (uint32_t)FIN_SURV || shift == 0) break;      // (shift == 0: the prefix is the K-th composite itself)
+        }
+        if (lane == 0) scal[3] = 0u;
+        isim_wave_sync();
+        for (int t0 = 0; t0 < m; t0 += 64) {
+            const int t = t0 + lane;
+            const uint64_t c = t < m ? get(t) : 0ull;
+            const bool keep = t < m && c >= prefix;
+            const unsigned long long bal = __ballot(keep);
+            if (bal) {
+                const uint32_t base = scal[3];
+                if (keep) {
+                    const uint32_t pos = base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+                    if (pos < (uint32_t)FIN_SURV) surv[pos] = c;
+                }
+                isim_wave_sync();
+                if (lane == 0) scal[3] = base + (uint32_t)__popcll(bal);
+                isim_wave_sync();
+            }
+        }
+        cnt = (int)min(scal[3], (uint32_t)FIN_SURV);
+    }
+    int P2 = 1;
+    while (P2 < cnt) P2 <<= 1;
+    for (int t = cnt + lane; t < P2; t += 64) surv[t] = 0ull;
+    isim_wave_sync();
+    for (int k = 2; k <= P2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = lane; t < P2; t += 64) {
+                const int l = t ^ j;
+                if (l > t) {
+                    const uint64_t x = surv[t], y = surv[l];
+                    const bool desc = (t & k) == 0;
+                    if (desc ? (x < y) : (x > y)) { surv[t] = y; surv[l] = x; }
+                }
+            }
+            isim_wave_sync();
+        }
+    const int keep = min(cnt, A.K);
+    if (lane == 0) A.out_cnt[i] = keep;
+    for (int t = lane; t < keep; t += 64) {
+        const uint64_t c = surv[t];
+        A.out_other[(int64_t)i * A.K + t] = 0x7FFFFFFF - (int32_t)(uint32_t)c;
+        A.out_sim[(int64_t)i * A.K + t] = __uint_as_float((uint32_t)(c >> 32));
+    }
+}
+
+// rows whose candidate list overflowed (massive ties inside one bucket of the sweep's histogram): every column of the row, from
+// the matrix, through the running top-K of the row-at-a-time kernel (isim_cut: exact for any input)
+__global__ __launch_bounds__(256) void k_isim_redo(SweepArgs A, const int32_t* __restrict__ redo_list, const int32_t* __restrict__ n_redo) {
+    __shared__ uint64_t cand[ISIM_CAP];
+    __shared__ uint32_t sh_cnt, sh_tau, sh_aux[2], hist[256];
+    const int tid = threadIdx.x;
+    const int n_rows = *n_redo;
+    for (int x = blockIdx.x; x < n_rows; x += gridDim.x) {      // block-uniform
+        const int i = redo_list[x];
+        const double inv_i = A.invn[i];
+        if (tid == 0) { sh_cnt = 0; sh_tau = A.tau0; }
+        __syncthreads();
+        for (int base = 0; base < A.Ic; base += 256) {
+            const int col = base + tid;
+            bool want = false;
+            uint64_t c = 0;
+            if (col < A.Ic && col != i) {
+                const float v = col > i ? A.G[(int64_t)i * A.ldm + col] : A.G[(int64_t)col * A.ldm + i];
+                const float sf = (float)((double)v * inv_i * A.invn[col]);
+                const uint32_t key = __float_as_uint(sf);
+                want = sf > 0.0f && key >= sh_tau;
+                c = ((uint64_t)key << 32) | (uint32_t)(0x7FFFFFFF - A.rank_item_raw[col]);
+            }
+            const unsigned long long bal = __ballot(want);
+            if (bal) {
+                const int lane = tid & 63;
+                uint32_t at = 0;
+                if (lane == __ffsll((long long)bal) - 1) at = atomicAdd(&sh_cnt, (uint32_t)__popcll(bal));
+                at = __shfl(at, __ffsll((long long)bal) - 1, 64);
+                if (want) cand[at + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = c;
+            }
+            __syncthreads();
+            if (sh_cnt + 256 + 1 > (uint32_t)ISIM_CAP) isim_cut(cand, A.K, ISIM_CAP, hist, &sh_cnt, &sh_tau, sh_aux);   // block-uniform (+ 1: the diagonal)
+        }
+        const uint64_t c_self = isim_self_candidate(A, i);
+        if (c_self && tid == 0) cand[sh_cnt++] = c_self;
+        __syncthreads();
+        isim_select(cand, (int)sh_cnt, A.K, hist, &sh_cnt, &sh_tau, sh_aux);
+        const int n = (int)sh_cnt;
+        int P2 = 1;
+        while (P2 < n) P2 <<= 1;
+        for (int t = n + tid; t < P2; t += 256) cand[t] = 0ull;
+        __syncthreads();
+        isim_sort_desc(cand, P2);
+        const int keep = min(n, A.K);
+        if (tid == 0) A.out_cnt[i] = keep;
+        for (int t = tid; t < keep; t += 256) {
+            const uint64_t c = cand[t];
+            A.out_other[(int64_t)i * A.K + t] = 0x7FFFFFFF - (int32_t)(uint32_t)c;
+            A.out_sim[(int64_t)i * A.K + t] = __uint_as_float((uint32_t)(c >> 32));
+        }
+        __syncthreads();     // everybody is done with cand / sh_cnt before the next row resets them
+    }
+}
+__global__ void k_sum_i32(int32_t n, const int32_t* __restrict__ v, unsigned long long* __restrict__ out) {
+    unsigned long long s = 0;
+    for (int32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) s += (unsigned long long)v[t];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, s);
+}
+
+// per item in rank order: 1 / norm (fp64 and fp32) and the bounds of the fixed-point scale (largest column sum / largest rating)
+__global__ void k_isim_gram_prep(int32_t Ic, int64_t ld_pad, const int32_t* __restrict__ rank_pair, const int32_t* __restrict__ pair_start,
+                                 const float* __restrict__ csc_r, const double* __restrict__ norm, double* __restrict__ invn, float* __restrict__ invn32,
+                                 uint32_t* __restrict__ bounds /* [0] max column sum, [1] max rating, as float bits */) {
+    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    for (int64_t r = blockIdx.x * wpb + (threadIdx.x >> 6); r < ld_pad; r += (int64_t)gridDim.x * wpb) {
+        if (r >= Ic) { if (lane == 0) invn32[r] = 0.0f; continue; }
+        const int32_t pr = rank_pair[r];
+        float sum = 0.0f, mx = 0.0f;
+        for (int32_t q = pair_start[pr] + lane; q < pair_start[pr + 1]; q += 64) { sum += csc_r[q]; mx = fmaxf(mx, csc_r[q]); }
+        for (int o = 32; o > 0; o >>= 1) { sum += __shfl_down(sum, o, 64); mx = fmaxf(mx, __shfl_down(mx, o, 64)); }
+        if (lane == 0) {
+            const double inv = 1.0 / norm[pr];
+            invn[r] = inv;
+            invn32[r] = (float)inv;
+            // positive floats order like their bits; the read in front keeps 59 047 atomics off ONE address (82 M/s: 1.4 ms)
+            if (__float_as_uint(sum * 1.0001f) > bounds[0]) atomicMax(&bounds[0], __float_as_uint(sum * 1.0001f));
+            if (__float_as_uint(mx) > bounds[1]) atomicMax(&bounds[1], __float_as_uint(mx));
+        }
+    }
+}
+__global__ void k_fill_u32(int64_t n, uint32_t v, uint32_t* __restrict__ out) {
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) out[t] = v;
+}
+
+// the symmetric build; false = not applicable here (the caller runs the row-at-a-time build).  cnt / other / sim as the other build leaves them.
+static bool itemsim_symmetric(Context* ctx, const fy_itemsim_params* prm, const Prepared& P, const double* norm, int32_t* cnt, int32_t* other,
+                              float* sim, double* ms_cooc, fy_stats* st_out) {
+    const Tuning& tune = ctx->tune;
+    const int32_t Ic = P.nP, K = prm->max_similarities_per_item;
+    if (tune.isim_gram == 0 || prm->world != 1 || prm->similarity != FY_SIMILARITY_COSINE || !tune.cooc_pk || !P.ratings_fp16_exact ||
+        !P.ratings_positive || K > FIN_SURV / 2 || (prm->has_threshold && !(prm->threshold > 0.0)))
+        return false;
+    if (tune.isim_gram < 0 && Ic < tune.isim_gram_min_items) return false;
+    const int64_t ldm = round_up(Ic, 256), slack = 1024;
+    if ((uint64_t)Ic * (uint64_t)ldm * 4 > ctx->total_mem / 3) return false;     // the fp32 matrix must fit comfortably
+    hipStream_t st = ctx->stream;
+    DevBuf<double> invn(ctx, (size_t)Ic);
+    DevBuf<float> invn32(ctx, (size_t)(ldm + slack));
+    DevBuf<uint32_t> d_bounds(ctx, 2);
+    d_bounds.zero();
+    k_isim_gram_prep<<<grid_for((ldm + slack) * 64, 256), 256, 0, st>>>(Ic, ldm + slack, P.rank_pair.get(), P.pair_start.get(), P.csc_r.get(), norm, invn.get(),
+                                                                        invn32.get(), d_bounds.get());
+    FY_KERNEL_CHECK();
+    uint32_t hb[2];
+    d2h(ctx, hb, d_bounds.get(), 2);
+    sync(ctx);
+    float fsum, fmax;
+    memcpy(&fsum, &hb[0], 4);
+    memcpy(&fmax, &hb[1], 4);
+    const float bounds3[3] = {fsum, fmax, fmax};
+    DevBuf<float> G(ctx, (size_t)Ic * ldm + slack);
+    EventTimer t_all(ctx);
+    const size_t sp = t_all.begin();
+    double ms_tables = 0.0;
+    if (!gram_half_build(ctx, P, P.csc_r.get(), bounds3, G.get(), ldm, &ms_tables, nullptr)) return false;
+    const int capg = tune.isim_capg;
+    DevBuf<uint32_t> tau_g(ctx, (size_t)Ic);
+    DevBuf<int32_t> gcnt(ctx, (size_t)Ic), overflow(ctx, (size_t)Ic);
+    DevBuf<uint64_t> glist(ctx, (size_t)Ic * capg);
+    gcnt.zero();
+    overflow.zero();
+    uint32_t tau0 = 1u;      // no threshold: similarity > 0 (NO_THRESHOLD = Double.MIN_VALUE)
+    if (prm->has_threshold) {
+        float tf = (float)prm->threshold;
+        if ((double)tf < prm->threshold) tf = nextafterf(tf, INFINITY);      // float s >= double threshold  <=>  s >= the next float at or above it
+        memcpy(&tau0, &tf, 4);
+    }
+    k_fill_u32<<<grid_for(Ic), 256, 0, st>>>(Ic, tau0, tau_g.get());
+    FY_KERNEL_CHECK();
+    SweepArgs SA{G.get(), ldm, Ic, K, invn32.get(), invn.get(), P.rank_item_raw.get(), tau_g.get(), gcnt.get(), glist.get(), capg, overflow.get(),
+                 (int32_t)ceil_div(Ic, 64), tune.isim_piece, tau0, prm->exclude_self, cnt, other, sim};
+    const int npieces = (int)ceil_div(Ic, SA.piece);
+    k_isim_sweep<<<SA.nbands * npieces, 256, 0, st>>>(SA);
+    FY_KERNEL_CHECK();
+    DevBuf<int32_t> redo_list(ctx, (size_t)Ic), n_redo(ctx, 1);
+    n_redo.zero();
+    k_isim_finish<<<(int)ceil_div(Ic, 4), 256, 0, st>>>(SA, redo_list.get(), n_redo.get());
+    FY_KERNEL_CHECK();
+    k_isim_redo<<<ctx->num_cus * 2, 256, 0, st>>>(SA, redo_list.get(), n_redo.get());
+    FY_KERNEL_CHECK();
+    t_all.end(sp);
+    DevBuf<unsigned long long> d_cands(ctx, 1);
+    d_cands.zero();
+    k_sum_i32<<<grid_for(Ic), 256, 0, st>>>(Ic, gcnt.get(), d_cands.get());
+    FY_KERNEL_CHECK();
+    unsigned long long h_cands = 0;
+    int32_t h_redo = 0;
+    d2h(ctx, &h_cands, d_cands.get(), 1);
+    d2h(ctx, &h_redo, n_redo.get(), 1);
+    sync(ctx);
+    *ms_cooc = t_all.total_ms() - ms_tables;
+    st_out->ms_tables = ms_tables;
+    st_out->isim_candidates = (int64_t)h_cands;
+    st_out->isim_redone_rows = h_redo;
+    return true;
+}
+
 // packed CSR (fy_cooc.hpp): column index relative to its chunk | the raw rating (or 1 for the co-occurrence count) as fp16
 __global__ void k_isim_pack_csr(int64_t nnz, int32_t CH, const int32_t* __restrict__ csr_idx, const float* __restrict__ csr_r, int cosine,
                                 uint32_t* __restrict__ pk) {
@@ -340,7 +804,6 @@ __global__ void k_isim_inv_norms(int32_t Ic, const int32_t* __restrict__ rank_pa
     for (int32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < Ic; r += gridDim.x * blockDim.x) inv[r] = 1.0 / norm[rank_pair[r]];
 }
 
-constexpr int ISIM_HEAVY = 4096;   // raters above which a row is split by column chunk (test hook: FY_ISIM_HEAVY)
 __global__ void k_isim_count_heavy(int32_t rows_mine, int32_t rank, int32_t world, const int32_t* __restrict__ rank_pair,
                                    const int32_t* __restrict__ pair_start, int32_t heavy, int32_t* __restrict__ n_heavy) {
     for (int32_t m = blockIdx.x * blockDim.x + threadIdx.x; m < rows_mine; m += gridDim.x * blockDim.x) {
@@ -502,14 +965,23 @@ fy_result* itemsim_build(Context* ctx, const fy_itemsim_params* prm, const fy_ra
     const int32_t Ic = P.nP;   // single "cluster": every item is a pair
     const int cosine = prm->similarity == FY_SIMILARITY_COSINE;
     // packed row kernel (4-byte CSR entries, norms applied in the epilogue) when every rating is fp16-exact
-    const char* pk_env = getenv("FY_COOC_PK");
-    const bool use_pk = P.ratings_fp16_exact && !(pk_env && atoi(pk_env) == 0);
+    const Tuning& tune = ctx->tune;
+    const bool use_pk = P.ratings_fp16_exact && tune.cooc_pk;
     DevBuf<double> norm(ctx, Ic), inv_norm(ctx, Ic);
-    DevBuf<float> csc_w(ctx, P.nnz), csr_w(ctx, use_pk ? 1 : (size_t)P.nnz);
-    DevBuf<uint32_t> csr_pk(ctx, use_pk ? (size_t)P.nnz : 1);
     k_item_norms<<<grid_for((int64_t)Ic * 64, 256), 256, 0, st>>>(Ic, P.pair_start.get(), P.csc_r.get(), norm.get());
     FY_KERNEL_CHECK();
-    if (use_pk) {
+    const int K = prm->max_similarities_per_item;
+    const int32_t rows_mine = (Ic - prm->rank + prm->world - 1) / prm->world;
+    DevBuf<int32_t> cnt(ctx, (size_t)rows_mine + 1), off(ctx, (size_t)rows_mine + 1), other(ctx, (size_t)rows_mine * K);
+    DevBuf<float> sim(ctx, (size_t)rows_mine * K);
+    cnt.zero();
+    double ms_sym = 0.0;
+    const bool symmetric = itemsim_symmetric(ctx, prm, P, norm.get(), cnt.get(), other.get(), sim.get(), &ms_sym, &Rs->st);
+    if (symmetric) Rs->st.cooc_launches = 1;
+    DevBuf<float> csc_w(ctx, symmetric ? 1 : (size_t)P.nnz), csr_w(ctx, (use_pk || symmetric) ? 1 : (size_t)P.nnz);
+    DevBuf<uint32_t> csr_pk(ctx, (use_pk && !symmetric) ? (size_t)P.nnz : 1);
+    if (symmetric) {
+    } else if (use_pk) {
         k_isim_raw_weights<<<grid_for(P.nnz), 256, 0, st>>>(P.nnz, P.csc_r.get(), cosine, csc_w.get());
         FY_KERNEL_CHECK();
         k_isim_inv_norms<<<grid_for(Ic), 256, 0, st>>>(Ic, P.rank_pair.get(), norm.get(), inv_norm.get());
@@ -521,21 +993,16 @@ fy_result* itemsim_build(Context* ctx, const fy_itemsim_params* prm, const fy_ra
         FY_KERNEL_CHECK();
     }
 
-    const int K = prm->max_similarities_per_item;
     // LDS = fp64 accumulators + candidate buffer <= 160 KiB.  (A 512-entry buffer would allow three column chunks instead of
     // four at ML-25M shape, but the extra cuts cost more than the shorter walk gains: 28.5 against 27.2 ms.)
     const int cap = ISIM_CAP;
     int max_ch = ((160 * 1024 - cap * 8 - 2048) / 8) / 256 * 256;
-    if (const char* e = getenv("FY_COOC_MAX_CH")) { const int v = atoi(e); if (v >= 64 && v <= max_ch) max_ch = v; }   // test hook: force column chunks
+    if (tune.cooc_max_ch_forced && tune.cooc_max_ch <= max_ch) max_ch = tune.cooc_max_ch;   // test hook: force column chunks
     int32_t CH, nch;
     pick_chunks(Ic, max_ch, CH, nch);
     DevBuf<int32_t> chunk_off(ctx, (size_t)P.nU * (nch + 1));
     build_chunk_offsets(ctx, P.rowptr.get(), P.csr_idx.get(), 0, P.nU, CH, nch, chunk_off.get());
-    const int32_t rows_mine = (Ic - prm->rank + prm->world - 1) / prm->world;
-    DevBuf<int32_t> cnt(ctx, (size_t)rows_mine + 1), off(ctx, (size_t)rows_mine + 1), other(ctx, (size_t)rows_mine * K);
-    DevBuf<float> sim(ctx, (size_t)rows_mine * K);
-    cnt.zero();
-    if (rows_mine > 0) {
+    if (rows_mine > 0 && !symmetric) {
         SegTable segs;
         build_segments(ctx, P.csc_slot.get(), csc_w.get(), chunk_off.get(), 0, 0, (int32_t)P.nnz, nch, segs);
         if (use_pk) {
@@ -549,8 +1016,7 @@ fy_result* itemsim_build(Context* ctx, const fy_itemsim_params* prm, const fy_ra
         DevBuf<int32_t> part_cnt(ctx, (size_t)rows_mine * nch);
         part_cnt.zero();
         // rows are in popularity order: the rows with more than ISIM_HEAVY raters are a prefix
-        int32_t heavy_raters = ISIM_HEAVY;
-        if (const char* e = getenv("FY_ISIM_HEAVY")) heavy_raters = std::max(0, atoi(e));
+        const int32_t heavy_raters = tune.isim_heavy;
         DevBuf<int32_t> d_heavy(ctx, 1);
         d_heavy.zero();
         k_isim_count_heavy<<<grid_for(rows_mine), 256, 0, st>>>(rows_mine, prm->rank, prm->world, P.rank_pair.get(), P.pair_start.get(), heavy_raters, d_heavy.get());
@@ -606,7 +1072,7 @@ fy_result* itemsim_build(Context* ctx, const fy_itemsim_params* prm, const fy_ra
     // sum_u n_u (n_u - 1) / 2 = (sum n_u^2 - nnz) / 2: the unit Mahout's co-occurrence mapper enumerates
     Rs->st.unordered_pairs = (P.sum_deg2 - P.nnz) / 2;
     Rs->st.ms_prepare = t_prep.total_ms();
-    Rs->st.ms_cooc = t_cooc.total_ms();
+    Rs->st.ms_cooc = symmetric ? ms_sym : t_cooc.total_ms();
     Rs->st.ms_total = t_total.total_ms();
     return Rs.release();
 }

@@ -71,7 +71,7 @@ void inclusive_scan_i64(Context* c, const int64_t* in, int64_t* out, size_t n) {
 }
 
 // ---------------------------------------------------------------- kernels
-enum { ERR_NEG_ID = 1, ERR_DUP = 2, ERR_CLUSTER_RANGE = 4, NOTE_NOT_FP16 = 8 };
+enum { ERR_NEG_ID = 1, ERR_DUP = 2, ERR_CLUSTER_RANGE = 4, NOTE_NOT_FP16 = 8, NOTE_NONPOSITIVE = 16 };
 
 static inline int grid_for(int64_t n, int block = 256, int cap = 256 * 16) {
     int64_t g = ceil_div(n, block);
@@ -103,7 +103,7 @@ __global__ void k_user_item_keys(int64_t n, const int32_t* __restrict__ user, co
                                  const float* __restrict__ score, int keep_nonpositive, int ib, uint32_t drop_user,
                                  uint64_t* __restrict__ keys, unsigned long long* __restrict__ kept, int* __restrict__ err) {
     unsigned long long local = 0;
-    bool not_half = false;
+    bool not_half = false, not_pos = false;
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
         const float s = score[t];
         const bool keep = keep_nonpositive ? (s == s) : (s > 0.0f);   // NaN never passes "score > 0"
@@ -112,6 +112,7 @@ __global__ void k_user_item_keys(int64_t n, const int32_t* __restrict__ user, co
             const int32_t u = user[t], i = item[t];
             if (u < 0 || i < 0) atomicOr(err, ERR_NEG_ID);
             if (__half2float(__float2half(s)) != s) not_half = true;
+            if (!(s > 0.0f)) not_pos = true;
             k = ((uint64_t)(uint32_t)u << ib) | (uint32_t)i;
             local++;
         }
@@ -121,6 +122,7 @@ __global__ void k_user_item_keys(int64_t n, const int32_t* __restrict__ user, co
     for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o, 64);
     if ((threadIdx.x & 63) == 0 && local) atomicAdd(kept, local);
     if (__ballot(not_half) && (threadIdx.x & 63) == 0) atomicOr(err, NOTE_NOT_FP16);
+    if (__ballot(not_pos) && (threadIdx.x & 63) == 0) atomicOr(err, NOTE_NONPOSITIVE);
 }
 
 __global__ void k_heads_hi32(int64_t n, const uint64_t* __restrict__ keys, uint32_t* __restrict__ head, int check_dup,
@@ -382,6 +384,7 @@ void build_structure(Context* ctx, const fy_ratings* R, int32_t K, int64_t n_map
         const int flags = fetch(ctx, err.get());
         if (flags & ERR_NEG_ID) FY_FAIL(FY_ERR_NEGATIVE_ID, "negative user or item id in the ratings");
         P.ratings_fp16_exact = !(flags & NOTE_NOT_FP16);
+        P.ratings_positive = !(flags & NOTE_NONPOSITIVE);
     }
     if (nnz == 0) {
         P.nU = P.nI = P.nP = 0;

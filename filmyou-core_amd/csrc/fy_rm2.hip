@@ -880,76 +880,10 @@ static void owner_range(const fy_rm2_job* J, int k, int32_t& lo, int32_t& hi) {
     hi = (int32_t)(n * (k + 1) / W);
 }
 
-// launch-shape knobs.  The environment overrides are TEST HOOKS: each one forces a path that the default heuristics would
-// pick only at a larger size, so that the parity tests can drive every path at a size the oracle finishes (none of them
-// changes a result beyond the summation order; the timing-only switches of round 1 are gone from the product library).
-struct ScoreTune {
-    int force_select = 0;              // route every user through k_topn_select
-    int pack24 = 1;                    // M rows as 24-bit floats (3 bytes per element): -25 % of the dominant traffic
-    int pack24_min_items = 4096;       // ... for clusters with at least this many items
-    int max_slices = 65536;            // user slices (workgroups) per column chunk
-    int users_per_wave = 16;           // users a wave of the scoring kernel walks for one column chunk
-    int64_t workspace_default = (int64_t)16 << 30;   // score scratch per batch of users
-    int lanes = 4;                     // HIP streams the clusters of one job are spread over
-    int prune = 1;                     // branch and bound over 256-column candidate blocks
-    int prune_min_items = 8192;
-    int seed_chunks = 0;               // 256-column chunks scored exactly before the bound pass (the most popular candidates);
-                                       // 0 = from the list length: ~5 N columns (N = 50: one chunk, N = 100: two), at most four
-    int cooc_block = 0;                // force the row kernel's workgroup size
-    int cooc_max_ch = 19968;           // LDS accumulators of the row kernel: 156 KiB of fp64 of the 160 KiB LDS (ML-25M shape: three
-                                       // column chunks instead of four, 19.7 -> 17.8 ms; smaller forces more chunks)
-    int seed_forced = 0;               // FY_SEED_CHUNKS given: prune whatever the list length
-    int coop = 1;                      // cooperative scoring of clusters that span all ranks (needs fy_collectives)
-    int coop_force = 0;                // cooperative path also with world == 1 (identity collectives)
-    int cooc_pk = 1;                   // packed 4-byte CSR entries for the row kernel when the ratings are fp16-exact
-    int cooc_f32 = 0;                  // row kernel accumulators in fp32 (ds_add_f32): MEASUREMENT ONLY -- 4x slower, see fy_cooc.hpp
-    int cooc_half = 1;                 // symmetric walk (upper triangle + mirror pass) for clusters with packed rows
-    int cooc_fx = 1;                   // fixed-point (ds_add_u64) accumulation in the packed walk
-    int panel_min_clusters = 4;        // column-panel mode when at least this many clusters of the rank are pruned ones
-    int prune_min_users = 600;         // clusters with fewer users take the plain full pass
-    int panel_wide_below_users = 2500; // panel mode: clusters with fewer users keep twice the panel columns
-    int panel_cols = 4096;             // columns of a row kept in panel mode (the seed columns and the popular blocks)
-    bool bounded_tables = true;        // FY_BOUNDED_TABLES=0: exact table sizes (two host round trips per table)
-    bool cooc_planes = true;           // FY_COOC_PLANES=0: linear accumulator layout (measurement only)
-    int score_heavy = 512;             // users with more ratings are walked by a whole workgroup of the scoring kernel (0 = off)
-    bool panel_repair = true;          // FY_PANEL_REPAIR=0: measurement only
-    int panel_lanes = 2;               // job lanes when clusters run in panel mode (measured, 50 clusters: 1 lane 300 ms, 2: 213, 3: 230, 4: 240)
-    int panel_max_ch = 4096;           // chunk width of the row kernel in panel mode: five workgroups per CU (measured, 50 clusters, row kernel ms: 8192 -> 67, 6144 -> 54, 4096 -> 46)
-    double max_surv_frac = 0.25;       // a pruned batch whose surviving blocks exceed this fraction falls back to the full pass
-};
-static ScoreTune score_tune() {
-    ScoreTune t;
-    if (const char* e = getenv("FY_M24")) t.pack24 = atoi(e) != 0;
-    if (const char* e = getenv("FY_M24_MIN_ITEMS")) t.pack24_min_items = atoi(e);
-    if (const char* e = getenv("FY_SCORE_SLICES")) t.max_slices = atoi(e);
-    if (const char* e = getenv("FY_SCORE_UPW")) { int v = atoi(e); if (v >= 1) t.users_per_wave = v; }
-    if (const char* e = getenv("FY_PRUNE")) t.prune = atoi(e) != 0;
-    if (const char* e = getenv("FY_COOP")) t.coop = atoi(e) != 0;
-    if (const char* e = getenv("FY_COOP_FORCE")) t.coop_force = atoi(e) != 0;
-    if (const char* e = getenv("FY_COOC_PK")) t.cooc_pk = atoi(e) != 0;
-    if (const char* e = getenv("FY_COOC_F32")) t.cooc_f32 = atoi(e) != 0;
-    if (const char* e = getenv("FY_COOC_HALF")) t.cooc_half = atoi(e) != 0;
-    if (const char* e = getenv("FY_COOC_FX")) t.cooc_fx = atoi(e) != 0;
-    if (const char* e = getenv("FY_PANEL_MIN_CLUSTERS")) { int v = atoi(e); if (v >= 1) t.panel_min_clusters = v; }
-    if (const char* e = getenv("FY_PANEL_COLS")) { int v = atoi(e); if (v >= 256) { t.panel_cols = v; t.panel_wide_below_users = 0; } }
-    if (const char* e = getenv("FY_PANEL_WIDE_BELOW_USERS")) { int v = atoi(e); if (v >= 0) t.panel_wide_below_users = v; }
-    if (const char* e = getenv("FY_PANEL_MAX_CH")) { int v = atoi(e); if (v >= 256) t.panel_max_ch = v; }
-    if (const char* e = getenv("FY_BOUNDED_TABLES")) t.bounded_tables = atoi(e) != 0;
-    if (const char* e = getenv("FY_COOC_PLANES")) t.cooc_planes = atoi(e) != 0;
-    if (const char* e = getenv("FY_SCORE_HEAVY")) { int v = atoi(e); if (v >= 0) t.score_heavy = v; }
-    if (const char* e = getenv("FY_PANEL_REPAIR")) t.panel_repair = atoi(e) != 0;
-    if (const char* e = getenv("FY_PANEL_LANES")) { int v = atoi(e); if (v >= 1 && v <= 8) t.panel_lanes = v; }
-    if (const char* e = getenv("FY_PRUNE_MIN_ITEMS")) { t.prune_min_items = atoi(e); t.prune_min_users = 0; }   // (a forced item threshold -- tests -- lifts the user threshold too)
-    if (const char* e = getenv("FY_PRUNE_MIN_USERS")) { int v = atoi(e); if (v >= 0) t.prune_min_users = v; }
-    if (const char* e = getenv("FY_SEED_CHUNKS")) { int v = atoi(e); if (v >= 0 && v <= 4) { t.seed_chunks = v; t.seed_forced = v > 0; } }
-    if (const char* e = getenv("FY_WORKSPACE_GB")) { long v = atol(e); if (v >= 1) t.workspace_default = (int64_t)v << 30; }
-    if (const char* e = getenv("FY_LANES")) { int v = atoi(e); if (v >= 1 && v <= 8) t.lanes = v; }
-    if (const char* e = getenv("FY_COOC_BLOCK")) { int v = atoi(e); if (v == 256 || v == 512 || v == 1024) t.cooc_block = v; }
-    if (const char* e = getenv("FY_COOC_MAX_CH")) { int v = atoi(e); if (v >= 64 && v <= 20224) t.cooc_max_ch = v; }
-    if (const char* e = getenv("FY_TOPN_FORCE_SELECT")) t.force_select = atoi(e) != 0;
-    if (const char* e = getenv("FY_MAX_SURV_FRAC")) { double v = atof(e); if (v >= 0.0) t.max_surv_frac = v; }
-    return t;
-}
+// launch-shape knobs: fy::Tuning (fy_common.hpp), read from the environment ONCE when the context is created
+// (fy_context_create / fy_context_reload_tuning in fy_api.hip) -- no job reads the environment.
+using ScoreTune = fy::Tuning;
+static inline const ScoreTune& score_tune(const Context* ctx) { return ctx->tune; }
 
 // Exponent k of the fixed-point scale 2^k of a cluster (CoocArgs::fx_scale): the largest k with (largest contribution) * 2^k < 2^51
 // and (largest possible Gram entry) * 2^k < 2^62, from the cluster's bounds (sum and maximum of the segment weights r / s^2 per
@@ -990,6 +924,64 @@ static void launch_cooc_rm2(Context* ctx, const ScoreTune& tune, bool use_pk, co
         else k_cooc_rm2<false, float><<<grid, block, lds, st>>>(CA, ME, n_items, counter);
     }
     FY_KERNEL_CHECK();
+}
+
+// The upper triangle of the co-rating Gram of a ONE-cluster structure with caller-chosen weights, as fp32 (the item-item
+// similarity build, fy_itemsim.hip): G[i][j] = sum_v w_vi r_vj for j > i, zero for (i & ~255) <= j <= i, rows `ldm` floats
+// apart; nothing in front of a row's diagonal 256-column block is written.  The same symmetric walk, segment table, item
+// list and fixed-point accumulators as the RM2 matrix build -- only the epilogue's scale differs (no (1 - lambda)^2).
+// `csc_w` = the weight of every CSC entry (the row side of a product), the column side is the raw rating of the packed
+// CSR; bounds3 = {largest column sum of the weights, largest weight, largest rating} (fx_exponent).  Returns false when the
+// fixed-point scale cannot be used (the caller keeps its own path); everything is queued on the context's stream.
+bool fy::gram_half_build(Context* ctx, const Prepared& P, const float* csc_w, const float* bounds3, float* G, int64_t ldm, double* ms_tables,
+                         double* ms_walk) {
+    const ScoreTune tune = score_tune(ctx);
+    const int32_t Ic = P.nP;
+    if (P.K != 1 || !P.ratings_fp16_exact || !P.ratings_positive || Ic <= 0) return false;
+    const int fxk = fx_exponent(bounds3);
+    if (fxk < 0) return false;
+    int32_t CH, nch;
+    pick_chunks(Ic, tune.cooc_max_ch, CH, nch);
+    if (nch >= 256) return false;                      // (the item ids of the row kernel hold the chunk in 8 bits)
+    hipStream_t st = ctx->stream;
+    cooc_rm2_allow_lds();
+    EventTimer t_tab(ctx), t_walk(ctx);
+    const size_t s0 = t_tab.begin();
+    DevBuf<uint32_t> csr_pk(ctx, (size_t)P.nnz);
+    k_pack_csr<<<grid_for(P.nnz), 256, 0, st>>>(0, (int32_t)P.nnz, CH, P.csr_idx.get(), P.csr_r.get(), csr_pk.get());
+    FY_KERNEL_CHECK();
+    DevBuf<int32_t> co(ctx, (size_t)P.nU * (nch + 1)), csc_rank(ctx, (size_t)P.nnz);
+    build_chunk_offsets(ctx, P.rowptr.get(), P.csr_idx.get(), 0, P.nU, CH, nch, co.get(), st);
+    k_csc_rank<<<grid_for(P.nnz), 256, 0, st>>>(P.nnz, P.csc_pair.get(), P.pair_rank.get(), csc_rank.get());
+    FY_KERNEL_CHECK();
+    SegTable segs;
+    build_segments(ctx, P.csc_slot.get(), csc_w, co.get(), 0, 0, (int32_t)P.nnz, nch, segs, st, csc_rank.get(), P.csr_idx.get(), CH);
+    CoocArgs CA{P.rank_pair.get(), P.pair_start.get(), segs.ptr.get(), segs.seg.get(), segs.w.get(), P.csr_idx.get(), nullptr, 0, 0, Ic, CH, nch,
+                0, Ic, 0, (int32_t)P.nnz, nullptr, 0, csr_pk.get(), nullptr, (uint32_t)std::min<int64_t>((int64_t)P.nnz * 4, 0xFFFFFFFFll)};
+    CA.half = 1;
+    CA.fx_scale = std::ldexp(1.0, fxk);
+    const int n_items = (int)cooc_item_count(Ic, CH, nch, true);
+    DevBuf<int2> item_seg(ctx, (size_t)Ic * nch);
+    DevBuf<int32_t> item_id(ctx, (size_t)Ic * nch), counter(ctx, 1);
+    k_item_list<<<grid_for((int64_t)Ic * nch), 256, 0, st>>>(CA, item_seg.get(), item_id.get());
+    FY_KERNEL_CHECK();
+    CA.item_seg = item_seg.get();
+    CA.item_id = item_id.get();
+    counter.zero();
+    CA.item_grab = cooc_item_grab(P.sum_deg2 / 2, n_items);
+    MEpilogue ME{};
+    ME.M = G;
+    ME.ldm = ldm;
+    ME.w2 = 1.0f;
+    ME.fx_inv = std::ldexp(1.0, -fxk);
+    t_tab.end(s0);
+    const size_t s1 = t_walk.begin();
+    launch_cooc_rm2(ctx, tune, true, CA, ME, n_items, counter.get(), st);
+    t_walk.end(s1);
+    sync(ctx);     // the tables of this scope go back to the allocator
+    if (ms_tables) *ms_tables = t_tab.total_ms();
+    if (ms_walk) *ms_walk = t_walk.total_ms();
+    return true;
 }
 
 // user slices (workgroups per column chunk) of a scoring launch over `nb` users and `chunks` column chunks: a wave walks up to
@@ -1127,7 +1119,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
     }
     const int32_t nU = P.nU, nP = P.nP, nI = P.nI, K = P.K;
     const double lambda = prm.lambda;
-    ScoreTune tune = score_tune();
+    ScoreTune tune = score_tune(ctx);
     // tau_u is the N-th best of the seed scores: a seed of only a few N columns gives a weak threshold and many survivors
     // (Netflix shape, N = 100: 2.7 % of the blocks survive a 256-column seed, 0.1 % a 512-column one)
     if (tune.seed_chunks == 0) tune.seed_chunks = (int)std::min<int64_t>(4, std::max<int64_t>(1, ceil_div(5 * (int64_t)prm.number_of_recommendations, 256)));
@@ -1298,7 +1290,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
         }
         bool any_panel = false;
         for (auto& p : plans) any_panel = any_panel || p.panel;
-        const int want_lanes = any_panel && !getenv("FY_LANES") ? std::min(tune.lanes, tune.panel_lanes) : tune.lanes;
+        const int want_lanes = any_panel && !tune.lanes_forced ? std::min(tune.lanes, tune.panel_lanes) : tune.lanes;
         const int NS = (int)std::min<size_t>(plans.size() > 1 ? (size_t)want_lanes : 1, plans.size());
         struct Lane {
             hipStream_t st;

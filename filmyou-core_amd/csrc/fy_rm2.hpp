@@ -31,6 +31,10 @@ void rm2_set_collectives(fy_rm2_job*, const fy_collectives*);
 fy_result* rm2_score(fy_rm2_job*);
 void rm2_job_destroy(fy_rm2_job*);
 fy_result* itemsim_build(Context*, const fy_itemsim_params*, const fy_ratings*);
+struct Prepared;
+// upper triangle of the weighted co-rating Gram of a one-cluster structure as fp32 (fy_rm2.hip; used by fy_itemsim.hip)
+bool gram_half_build(Context* ctx, const Prepared& P, const float* csc_w, const float* bounds3, float* G, int64_t ldm, double* ms_tables,
+                     double* ms_walk);
 void cluster_assign(Context*, int32_t n_rows, int32_t k, const double* H, int location, int32_t first_user, int32_t cluster_offset,
                     int32_t n_clusters, int32_t* user_out, int32_t* cluster_out, int32_t* count_inout);
 void nmf_factorize(Context*, const fy_nmf_params*, const fy_ratings*, double* H, double* W, fy_stats* st);

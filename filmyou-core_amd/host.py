@@ -82,6 +82,20 @@ class Context:
         _check(self._lib.fy_context_create(int(device), C.byref(h)))
         self._h = h
         self.device = int(device)
+        self._tuning_env = self._fy_env()
+
+    @staticmethod
+    def _fy_env():
+        return tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("FY_")))
+
+    def sync_tuning(self):
+        """The library reads its FY_* knobs (test / measurement hooks) from the environment once, at fy_context_create.  This
+        host mirror re-reads them (fy_context_reload_tuning) when the process environment has changed since -- the parity tests
+        switch paths per test on one context; a production job never gets here with a changed environment."""
+        env = self._fy_env()
+        if env != self._tuning_env:
+            _check(self._lib.fy_context_reload_tuning(self._h))
+            self._tuning_env = env
 
     def synchronize(self):
         _check(self._lib.fy_context_synchronize(self._h))
@@ -284,6 +298,7 @@ class RM2Job:
                 cc[:k] = np.asarray(clustering_count, dtype=np.int32)[:k]
             job = C.c_void_p()
             try:
+                ctx.sync_tuning()
                 _check(lib.fy_rm2_prepare(ctx._h, C.byref(p), r._h, len(mu), mu.ctypes.data, mc.ctypes.data,
                                           cc.ctypes.data if cc is not None else None, C.byref(job)))
             except FilmYouError as e:
@@ -411,6 +426,7 @@ class PreparedRM2:
         res = C.c_void_p()
         try:
             try:
+                self._ctx.sync_tuning()
                 _check(self._lib.fy_rm2_score(self._h, C.byref(res)))
             except FilmYouError as e:
                 if getattr(self, "_comm_error", None) is not None:
@@ -479,6 +495,7 @@ class BaselineRecommenderJob:
                                      int(world), 0)
             res = C.c_void_p()
             try:
+                ctx.sync_tuning()
                 _check(lib.fy_itemcf_recommend(ctx._h, C.byref(p), r._h, sims._h, C.byref(res)))
             except FilmYouError as e:
                 raise RuntimeError("%s failed!: %s" % (self.JOB_NAME, e.message)) from e
@@ -518,6 +535,7 @@ class RowSimilarityJob:
         res = C.c_void_p()
         try:
             try:
+                ctx.sync_tuning()
                 _check(lib.fy_itemsim_build(ctx._h, C.byref(p), r._h, C.byref(res)))
             except FilmYouError as e:
                 raise RuntimeError("%s failed!: %s" % (self.JOB_NAME, e.message)) from e

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FY_ABI_VERSION 2
+#define FY_ABI_VERSION 3
 
 typedef enum {
     FY_OK = 0,
@@ -62,6 +62,9 @@ int fy_context_synchronize(fy_context*);
  * context from now on (1 = the next one) fails with FY_ERR_OUT_OF_MEMORY; 0 disarms.  A failed job leaves the context
  * usable: every stream is drained before any buffer of the job is released. */
 int fy_context_inject_alloc_failure(fy_context*, int64_t nth);
+/* The library's launch-shape knobs (FY_* environment variables: test and measurement hooks) are read from
+ * the environment once, by fy_context_create; this call reads them again.  No job reads the environment. */
+int fy_context_reload_tuning(fy_context*);
 /* The hipStream_t of the context (as void*), e.g. to order caller-side copies against the job. */
 void* fy_context_stream(fy_context*);
 
@@ -243,6 +246,8 @@ typedef struct {
     int64_t panel_clusters;      /* clusters built in column-panel mode (many clusters: only the popular columns of the co-rating matrix are stored) */
     int64_t stray_blocks;        /* panel mode: surviving (user, block) pairs behind the panel, scored exactly from the sparse data */
     int64_t bound_repairs;       /* panel mode: 64-column sub-blocks dropped by the second bound (without the user's own co-ratings) */
+    int64_t isim_candidates;     /* item similarity, symmetric build: candidates the band sweep appended to the rows' lists (of I^2 / 2 elements x 2 rows) */
+    int64_t isim_redone_rows;    /* ... rows whose list overflowed and were redone exactly from the matrix */
 } fy_stats;
 int fy_result_stats(fy_result*, fy_stats* out);
 

@@ -197,3 +197,35 @@ def check_itemsim(data, top_k=100, n_rows=5):
         np.testing.assert_allclose(got_s, lookup, rtol=2e-6)
     res.close()
     ctx.close()
+
+
+def compare_itemsim_builds(data, top_k=100):
+    """ALL rows of the symmetric build (upper triangle by the RM2 row kernel + band sweep: what the benchmark sizes take) against
+    the row-at-a-time build (fp64 accumulators in LDS, FY_ISIM_GRAM=0) on the same ratings: the same lists, similarities within
+    the 2e-6 both are held to against the oracle at small sizes; positions where the item differs must be ties."""
+    P = pkg()
+    out = []
+    for gram in ("1", "0"):
+        old = os.environ.get("FY_ISIM_GRAM")
+        os.environ["FY_ISIM_GRAM"] = gram
+        try:
+            ctx = P.Context(0)
+            res = P.RowSimilarityJob(ctx).run(P.Ratings(ctx, *data["dev"]), maxSimilaritiesPerRow=top_k)
+            out.append((res.rows(), res.stats))
+            res.close()
+            ctx.close()
+        finally:
+            if old is None:
+                del os.environ["FY_ISIM_GRAM"]
+            else:
+                os.environ["FY_ISIM_GRAM"] = old
+    (ra, sa), (rb, sb) = out
+    assert sa["isim_candidates"] > 0 and sb["isim_candidates"] == 0
+    assert len(ra["item"]) == len(rb["item"]) and np.array_equal(ra["item"], rb["item"])
+    x, y = ra["sim"].astype(np.float64), rb["sim"].astype(np.float64)
+    worst = float(np.max(np.abs(x - y) / y))
+    assert worst <= 2e-6, worst
+    differ = np.flatnonzero(ra["other"] != rb["other"])
+    # a differing position is a tie: the other build holds the same value there
+    assert len(differ) <= 1e-3 * len(x), len(differ)
+    return len(x), len(differ), worst, sa

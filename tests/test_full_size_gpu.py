@@ -4,7 +4,7 @@ See tests/fullsize_checks.py for what is checked: exact statistics (quirk Q1 on 
 list, spot checks against the fp64 definition, and -- all 8.1 M rows -- the pruned job against the plain full pass."""
 import pytest
 
-from fullsize_checks import assert_same_lists, check_itemsim, check_rm2, load_shape, run_rm2
+from fullsize_checks import assert_same_lists, check_itemsim, compare_itemsim_builds, check_rm2, load_shape, run_rm2
 
 pytestmark = pytest.mark.gpu
 LAM, TOPN = 0.1, 50
@@ -58,3 +58,9 @@ def test_rm2_panel_mode_50_clusters_equals_full_pass_all_rows(data):
 
 def test_itemsim_full_size(data):
     check_itemsim(data)
+
+
+def test_itemsim_symmetric_build_equals_row_build_all_rows(data):
+    n, n_diff, worst, st = compare_itemsim_builds(data)
+    print("item similarity, symmetric build vs row-at-a-time build: %d rows, %d positions with another item (ties), worst similarity difference %.2e; "
+          "%d candidates appended by the sweep, %d rows redone exactly" % (n, n_diff, worst, st["isim_candidates"], st["isim_redone_rows"]))

@@ -21,7 +21,7 @@ def ctx():
     c.close()
 
 
-def check(rows, ref_full, K):
+def check(rows, ref_full, K, exclude_self=True):
     full = {}
     for a, b, s in zip(ref_full["item"], ref_full["other"], ref_full["sim"]):
         full.setdefault(int(a), []).append((int(b), float(s)))
@@ -36,7 +36,7 @@ def check(rows, ref_full, K):
         lookup = dict(ref)
         sims = np.array([s for _, s in lst])
         want = np.array([lookup[b] for b, _ in lst])
-        assert len({b for b, _ in lst}) == k and all(b != a for b, _ in lst)
+        assert len({b for b, _ in lst}) == k and (not exclude_self or all(b != a for b, _ in lst))
         np.testing.assert_allclose(sims, want, rtol=RTOL)
         assert np.all(sims[:-1] >= sims[1:])
         best = np.array([s for _, s in ref[:k]])
@@ -79,6 +79,37 @@ def test_synthetic_forced_paths(ctx, monkeypatch, env):
     res = pkg().RowSimilarityJob(ctx).run((u, i, s), maxSimilaritiesPerRow=30)
     ref = oracle.itemsim(u, i, s, max_similarities_per_item=1 << 30, n_threads=8)
     check(res.rows(), ref, 30)
+
+
+SYMMETRIC = [{"FY_ISIM_GRAM": "1"},                                                        # one chunk of the walk, one piece per band
+             {"FY_ISIM_GRAM": "1", "FY_COOC_MAX_CH": "256", "FY_ISIM_PIECE": "128"},      # several chunks, several pieces per band
+             {"FY_ISIM_GRAM": "1", "FY_ISIM_CAPG": "40"}]                                 # candidate lists overflow: rows redone exactly
+
+
+@pytest.mark.parametrize("env", SYMMETRIC)
+@pytest.mark.parametrize("exclude_self,threshold", [(True, None), (False, 0.2)])
+def test_symmetric_build_forced(ctx, monkeypatch, env, exclude_self, threshold):
+    """the build the benchmark sizes take (upper triangle by the RM2 row kernel + band sweep, fy_itemsim.hip), forced onto
+    ML-100K shape: must give what the row-at-a-time build and the oracle give"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    u, i, s, _ = synth().generate("ml100k")
+    u, i, s = u.numpy(), i.numpy(), s.numpy()
+    res = pkg().RowSimilarityJob(ctx).run((u, i, s), maxSimilaritiesPerRow=30, excludeSelfSimilarity=exclude_self, threshold=threshold)
+    ref = oracle.itemsim(u, i, s, max_similarities_per_item=1 << 30, n_threads=8, exclude_self=exclude_self, threshold=threshold)
+    check(res.rows(), ref, 30, exclude_self=exclude_self)
+    assert res.stats["cooc_launches"] == 1 and res.stats["isim_candidates"] > 0
+    assert (res.stats["isim_redone_rows"] > 0) == ("FY_ISIM_CAPG" in env)
+
+
+def test_symmetric_build_reference_matrix(ctx, rm_golden, monkeypatch):
+    monkeypatch.setenv("FY_ISIM_GRAM", "1")
+    user, item, score = rm_golden["coo"]
+    keep = score > 0
+    user, item, score = user[keep], item[keep], score[keep]
+    res = pkg().RowSimilarityJob(ctx).run((user, item, score), maxSimilaritiesPerRow=10)
+    ref = oracle.itemsim(user, item, score, max_similarities_per_item=1 << 30)
+    check(res.rows(), ref, 10)
 
 
 def test_item_row_shards_partition_the_result(ctx):

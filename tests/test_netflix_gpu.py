@@ -4,7 +4,7 @@ the single-LDS-chunk row kernel.  Same checks as at ML-25M shape (tests/fullsize
 comparison of the pruned job with the plain full pass (48 M rows)."""
 import pytest
 
-from fullsize_checks import assert_same_lists, check_itemsim, check_rm2, load_shape, run_rm2
+from fullsize_checks import assert_same_lists, check_itemsim, compare_itemsim_builds, check_rm2, load_shape, run_rm2
 
 pytestmark = pytest.mark.gpu
 LAM, TOPN = 0.1, 100
@@ -49,3 +49,9 @@ def test_rm2_netflix_panel_mode_50_clusters_equals_full_pass_all_rows(data):
 
 def test_itemsim_netflix_shape(data):
     check_itemsim(data, n_rows=4)
+
+
+def test_itemsim_symmetric_build_equals_row_build_all_rows(data):
+    n, n_diff, worst, st = compare_itemsim_builds(data)
+    print("item similarity, symmetric build vs row-at-a-time build: %d rows, %d positions with another item (ties), worst similarity difference %.2e; "
+          "%d candidates appended by the sweep, %d rows redone exactly" % (n, n_diff, worst, st["isim_candidates"], st["isim_redone_rows"]))
