@@ -24,7 +24,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 L2_PEAK_GBS = 34500.0   # MI355X_MICROARCH.md, "L2 (per XCD)": ~34.5 TB/s aggregate over the 8 XCDs
-DTYPE = "f32 (scores and logs fp32 / v_log_f32, folded in fp64; co-rating sums fp64; M stored as 24-bit e8m16 floats above 4096 items; ratings fp16 in the row kernel when exactly representable)"
+DTYPE = "f32 (scores and logs fp32 / v_log_f32, folded in fp64; co-rating sums 64-bit fixed point in LDS (fp64 fallback); G stored as 24-bit e7m17 floats scaled per cluster above 4096 items; ratings fp16 in the row kernel when exactly representable)"
 
 
 def parse():
@@ -343,7 +343,10 @@ def main():
                 dt = float(tmax.item())
             out["itemsim"] = {"metric": "item-sim pairs/sec (cosine, top-100)", "value": float(pp[0].item()) / dt,
                               "unit": "pairs/s", "seconds": dt, "ms_kernel_rank0": sst["ms_cooc"],
-                              "roofline": {"bound": "hbm", "kernel": "k_cooc_itemsim",
+                              "ms_prepare": sst["ms_prepare"], "ms_tables": sst["ms_tables"], "ms_total": sst["ms_total"],
+                              "build": "symmetric (upper triangle by the RM2 row kernel + band sweep)" if sst["isim_candidates"] else "row at a time",
+                              "sweep_candidates": sst["isim_candidates"], "rows_redone_exactly": sst["isim_redone_rows"],
+                              "roofline": {"bound": "hbm", "kernel": "k_cooc_rm2 + k_isim_sweep + k_isim_finish" if sst["isim_candidates"] else "k_cooc_itemsim",
                                            "achieved": 8.0 * sst["unordered_pairs"] / world / (sst["ms_cooc"] * 1e-3) / 1e9 if sst["ms_cooc"] > 0 else 0.0,
                                            "peak": HBM_PEAK_GBS, "unit": "GB/s"}}
             out["itemsim"]["roofline"]["frac"] = out["itemsim"]["roofline"]["achieved"] / HBM_PEAK_GBS

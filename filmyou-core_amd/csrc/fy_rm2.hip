@@ -274,6 +274,7 @@ __global__ void k_csr_values(int32_t nU, const int32_t* __restrict__ rowptr, con
                              const int32_t* __restrict__ ucluster, const double* __restrict__ usum,
                              const int32_t* __restrict__ csize, const int32_t* __restrict__ pcstart,
                              const double* __restrict__ p_rank, const double* __restrict__ b_rank, double lambda,
+                             const float* __restrict__ gscale /* [cluster]: 2^-c of the packed matrix format, 1 for fp32 rows */,
                              float* __restrict__ csr_x, float* __restrict__ csr_e, float* __restrict__ csr_q) {
     const int lane = threadIdx.x & 63;
     const int wpb = blockDim.x >> 6;
@@ -282,6 +283,7 @@ __global__ void k_csr_values(int32_t nU, const int32_t* __restrict__ rowptr, con
         const int32_t c = ucluster[du];
         const double sum = usum[du];
         const double Uc1 = (double)(csize[c] - 1);
+        const double gs = (double)gscale[c];
         const int32_t pb = pcstart[c];
         for (int32_t f = rowptr[s] + lane; f < rowptr[s + 1]; f += 64) {
             const int32_t j = csr_idx[f];
@@ -289,8 +291,8 @@ __global__ void k_csr_values(int32_t nU, const int32_t* __restrict__ rowptr, con
             double e = (1.0 - lambda) * (b_rank[pb + j] - x) + lambda * Uc1 * p_rank[pb + j];
             if (!(e > 0.0)) e = 0.0;
             csr_x[f] = (float)x;
-            csr_e[f] = (float)e;
-            csr_q[f] = (float)(lambda * (1.0 - lambda) * p_rank[pb + j]);     // q_j: the rank-one part of a term is q_j b_i
+            csr_e[f] = (float)(e * gs);
+            csr_q[f] = (float)(lambda * (1.0 - lambda) * p_rank[pb + j] * gs);     // q_j: the rank-one part of a term is q_j b_i
         }
     }
 }
@@ -299,7 +301,8 @@ __global__ void k_csr_values(int32_t nU, const int32_t* __restrict__ rowptr, con
 __global__ void k_user_meta(int32_t lo, int32_t hi, const int32_t* __restrict__ slot2du, const int32_t* __restrict__ uid,
                             const int32_t* __restrict__ ucluster, const int32_t* __restrict__ udeg,
                             const int32_t* __restrict__ csize, const int32_t* __restrict__ pcstart, int32_t number_of_items,
-                            int32_t top_n, int32_t filter_users, double* __restrict__ pvpi, int32_t* __restrict__ n_out,
+                            int32_t top_n, int32_t filter_users, const int32_t* __restrict__ cshift /* [cluster]: c of the packed format */,
+                            double* __restrict__ pvpi, int32_t* __restrict__ n_out,
                             unsigned long long* __restrict__ counters /* [0] log terms, [1] users scored */) {
     unsigned long long terms = 0, scored = 0;
     for (int32_t s = lo + blockIdx.x * blockDim.x + threadIdx.x; s < hi; s += gridDim.x * blockDim.x) {
@@ -309,7 +312,9 @@ __global__ void k_user_meta(int32_t lo, int32_t hi, const int32_t* __restrict__ 
         const int32_t Ic = pcstart[c + 1] - pcstart[c];
         const int32_t unrated = Ic - n;
         // AbstractRM2Reducer.java:327-329
-        pvpi[s - lo] = (double)(n - 1) * log((double)number_of_items) - (double)n * log((double)csize[c]);
+        // (+ n c ln 2: the n log terms of a user of a cluster with a scaled matrix are each short by c bits, see FY_P24_SHIFT)
+        pvpi[s - lo] = (double)(n - 1) * log((double)number_of_items) - (double)n * log((double)csize[c]) +
+                       (double)n * (double)cshift[c] * 0.69314718055994530942;
         // :210-213 (no unrated item -> skipped with a warning), :221-223 (filterUsers)
         const bool skip = unrated <= 0 || uid[du] < filter_users;
         int32_t k = skip ? 0 : min(top_n, unrated);
@@ -487,6 +492,13 @@ void build_segments(Context* ctx, const int32_t* csc_slot, const float* csc_w, c
 // ================================================================ G build: co-rating row kernel + RM2 epilogue
 // G[j][i] = (1-l)^2 (X^T X)_ji, the pure co-rating Gram (the rank-one part l (1-l) p_j b_i of the reference's inner sum is
 // applied by the scoring kernels): symmetric, exactly zero for never co-rated pairs.
+// Packed matrix format (clusters with >= pack24_min_items items): 3 bytes per element = 7 exponent + 17 mantissa bits of the fp32
+// value, no sign (G >= 0) and no top exponent bit: every stored value is < 2.  The cluster's matrix is stored SCALED by
+// 2^-c, c from an upper bound of its largest entry (rm2_score: cluster_scale); the scoring kernels never undo the scale -- q_j
+// and e_uj are stored scaled by the same 2^-c, so every term G + q b + a e comes out scaled, its log2 is short by c, and the
+// user's pvpi carries + n c ln 2.  Round 2 stored e8m16 (one mantissa bit less): the worst relative error of a score against the
+// fp64 definition was 7.3e-6 of north_star's 1e-5; the 17th bit halves the rounding of every matrix element at the same 3 bytes.
+constexpr int FY_P24_SHIFT = 6;      // float bits = packed << 6
 struct MEpilogue {
     float* __restrict__ M;
     int64_t ldm;
@@ -529,7 +541,7 @@ __device__ __forceinline__ void cooc_rm2_epilogue(const CoocArgs& A, const MEpil
     if (E.pack24) {
         // four columns -> three dwords (c0 and c1 are multiples of 64)
         const int64_t row_cols = E.pitch ? E.pitch : (E.panel_cols ? E.panel_cols : E.ldm);
-        const uint32_t radd = E.ceil24 ? 0xFFu : 0x80u;
+        const uint32_t radd = E.ceil24 ? (1u << FY_P24_SHIFT) - 1u : 1u << (FY_P24_SHIFT - 1);
         uint32_t* __restrict__ out3 = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(E.M) + (int64_t)mrow * row_cols * 3);
         for (int c4 = (cb >> 2) + threadIdx.x; 4 * c4 < c1; c4 += blockDim.x) {
             uint32_t v[4];
@@ -543,7 +555,7 @@ __device__ __forceinline__ void cooc_rm2_epilogue(const CoocArgs& A, const MEpil
                 if constexpr (std::is_same<ACC, unsigned long long>::value) f = (float)((double)ap[q * qs] * E.fx_inv);
                 else f = E.w2 * (float)ap[q * qs];
                 ap[q * qs] = (ACC)0;
-                v[q] = ((__float_as_uint(f) << 1) + radd) >> 8;    // G >= 0: drop the sign, keep 8 exponent + 16 mantissa bits, round to nearest
+                v[q] = (__float_as_uint(f) + radd) >> FY_P24_SHIFT;    // 0 <= f < 2: 7 exponent + 17 mantissa bits, round to nearest (or up)
             }
             if (!E.panel_cols || 4 * c4 < E.panel_cols) {
                 out3[3 * c4 + 0] = v[0] | (v[1] << 24);
@@ -1145,15 +1157,37 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
     k_csc_x<<<grid_for(P.nnz), 256, 0, st>>>(P.nnz, P.csc_slot.get(), P.csc_r.get(), J->usum_slot.get(), csc_x.get(),
                                              use_pk ? csc_x_over_s.get() : nullptr);
     FY_KERNEL_CHECK();
+    // packed (24-bit) matrix rows only where bandwidth matters: small clusters keep exact fp32 rows (their scores are small, and the
+    // reference's own fixture is asserted with an ABSOLUTE 1e-4, T/util/HadoopIntegrationTest.java:53).  A packed cluster's matrix is
+    // scaled by 2^-c so that every entry is < 1 (FY_P24_SHIFT): G[j][i] = w2 sum_v (r_vj / s_v^2) r_vi <= w2 * (largest column sum
+    // of r / s^2) * (largest rating), the bounds of the fixed-point scale.
+    std::vector<float> h_gscale((size_t)K, 1.0f);
+    std::vector<int32_t> h_cshift((size_t)K, 0);
+    std::vector<char> cluster_pack24((size_t)K, 0);
+    for (int c = 0; c < K; c++) {
+        const int32_t Ic_c = P.pcstart[c + 1] - P.pcstart[c];
+        if (!pack24_allowed || Ic_c < tune.pack24_min_items || J->fx_bounds.size() < 3 * (size_t)(c + 1)) continue;
+        const double gmax = (1.0 - lambda) * (1.0 - lambda) * (double)J->fx_bounds[3 * (size_t)c] * (double)J->fx_bounds[3 * (size_t)c + 2];
+        if (!(gmax >= 0.0) || !std::isfinite(gmax)) continue;                     // unusable bound: fp32 rows
+        const int cs = gmax > 0.0 ? std::max(0, std::ilogb(gmax) + 1) : 0;
+        if (cs > 64) continue;
+        cluster_pack24[c] = 1;
+        h_cshift[c] = cs;
+        h_gscale[c] = std::ldexp(1.0f, -cs);
+    }
+    DevBuf<float> d_gscale(ctx, (size_t)K);
+    DevBuf<int32_t> d_cshift(ctx, (size_t)K);
+    h2d(ctx, d_gscale.get(), h_gscale.data(), (size_t)K);
+    h2d(ctx, d_cshift.get(), h_cshift.data(), (size_t)K);
     k_csr_values<<<grid_for((int64_t)nU * 64, 256), 256, 0, st>>>(nU, P.rowptr.get(), P.csr_idx.get(), P.csr_r.get(), P.slot2du.get(),
                                                                    P.ucluster.get(), P.usum.get(), P.d_csize.get(), P.d_pcstart.get(),
-                                                                   p_rank.get(), b_rank.get(), lambda, csr_x.get(), csr_e.get(), csr_q.get());
+                                                                   p_rank.get(), b_rank.get(), lambda, d_gscale.get(), csr_x.get(), csr_e.get(), csr_q.get());
     FY_KERNEL_CHECK();
 
     t_tables.end(span_tables);
     // ---- which users this rank emits lists for
     J->count_balanced = false;
-    if (prm.world > 1 && J->have_coll && tune.coop && tune.prune && pack24_allowed) {
+    if (prm.world > 1 && J->have_coll && tune.coop && tune.prune && pack24_allowed) {     // (a cooperative cluster must be a packed one: checked per plan below)
         int nonempty = 0, c1 = -1;
         for (int c = 0; c < K; c++)
             if (P.csize[c] > 0) { nonempty++; c1 = c; }
@@ -1175,7 +1209,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
     if (nmine > 0) {
         k_user_meta<<<grid_for(nmine), 256, 0, st>>>(lo, hi, P.slot2du.get(), P.uid.get(), P.ucluster.get(), P.udeg.get(),
                                                       P.d_csize.get(), P.d_pcstart.get(), prm.number_of_items,
-                                                      prm.number_of_recommendations, prm.filter_users, pvpi.get(), n_out.get(), counters.get());
+                                                      prm.number_of_recommendations, prm.filter_users, d_cshift.get(), pvpi.get(), n_out.get(), counters.get());
         FY_KERNEL_CHECK();
     }
     exclusive_scan_i32(ctx, n_out.get(), out_off.get(), (size_t)nmine + 1);
@@ -1228,9 +1262,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             p.b = std::min(hi, p.sbase + p.Uc);
             if (p.a >= p.b || p.Ic == 0) continue;
             p.ldm = round_up(p.Ic, 256);
-            // 24-bit rows only where bandwidth matters: small clusters keep exact fp32 rows (their scores are small, and the
-            // reference's own fixture is asserted with an ABSOLUTE 1e-4, T/util/HadoopIntegrationTest.java:53)
-            p.pack24 = pack24_allowed && p.Ic >= tune.pack24_min_items;
+            p.pack24 = cluster_pack24[c] != 0;
             pick_chunks(p.Ic, max_ch_lds, p.CH, p.nch);
             p.q0 = P.cluster_q[c];
             p.nq = P.cluster_q[c + 1] - p.q0;
@@ -1464,7 +1496,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 CoopShared X{J, R.get(), &tune, b_rank32.get(), a_rank.get(), use_pk ? csc_x_over_s.get() : csc_x.get(), csr_x.get(), csr_e.get(), csr_q.get(),
                              use_pk ? csr_pk.get() : nullptr,
                              n_out.get(), out_off.get(), pvpi.get(), lo, &t_cooc, &t_score, &t_topn, prune_counters.get(),
-                             &prune_blocks_total, &prune_seed_terms_cols, &coop_survived, &coop_pair_contribs};
+                             &prune_blocks_total, &prune_seed_terms_cols, &coop_survived, &coop_pair_contribs, d_cshift.get(), h_gscale[(size_t)c]};
                 score_cluster_coop(X, p, ls);
                 continue;
             }
@@ -1480,7 +1512,8 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                         (uint32_t)std::min<int64_t>((int64_t)P.nnz * 4, 0xFFFFFFFFll)};
             const int fxk = (use_pk && tune.cooc_fx && !J->fx_bounds.empty()) ? fx_exponent(&J->fx_bounds[3 * (size_t)c]) : -1;
             CA.fx_scale = fxk >= 0 ? std::ldexp(1.0, fxk) : 0.0;
-            MEpilogue ME{L.M.get(), ldm, (float)((1.0 - lambda) * (1.0 - lambda)), fxk >= 0 ? std::ldexp((1.0 - lambda) * (1.0 - lambda), -fxk) : 0.0,
+            const double w2s = (1.0 - lambda) * (1.0 - lambda) * (double)h_gscale[(size_t)c];     // (1-l)^2 and the packed format's 2^-c
+            MEpilogue ME{L.M.get(), ldm, (float)w2s, fxk >= 0 ? std::ldexp(w2s, -fxk) : 0.0,
                          pack24 ? 1 : 0, (p.prune && !p.panel) ? L.Bmax.get() : nullptr, p.ldb, 0,
                          p.panel ? p.panel_cols : 0, p.panel ? L.Bmax64.get() : nullptr, p.ldb64, p.panel ? L.Brep.get() : nullptr};
             if (p.panel) {
@@ -1618,7 +1651,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                     // (4b) sub-blocks that hold an item the user rated: bound again without the user's own co-ratings
                     RepairArgs RA{L.surv.get(), L.surv_mask.get(), L.n_quads.get(), bld, nb, s0, lo, p.p_eff, Ic, P.rowptr.get(), P.csr_idx.get(),
                                   csr_x.get(), csr_e.get(), csr_q.get(), L.Bmax64.get(), L.Brep.get(), p.ldb64, L.amax64.get(), L.bmax64.get(),
-                                  L.tau.get(), pvpi.get(), (float)((1.0 - lambda) * (1.0 - lambda)), prune_counters.get()};
+                                  L.tau.get(), pvpi.get(), (float)w2s, prune_counters.get()};
                     k_bound_repair<<<std::min<int>(nb, ctx->num_cus * 16), 256, 0, ls>>>(RA);
                     FY_KERNEL_CHECK();
                 }
@@ -1672,7 +1705,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                         StrayArgs ST{L.quad_prefix.get(), L.surv.get(), L.surv_mask.get(), bld, nb, s0, lo, sbase, p.Uc, panel_blocks, Ic, pbase,
                                      P.rowptr.get(), P.csr_idx.get(), csr_e.get(), csr_q.get(), P.rank_pair.get(), P.pair_start.get(), P.csc_slot.get(),
                                      csc_x.get(), a_rank.get() + pbase, b_rank32.get() + pbase, pvpi.get(),
-                                     (float)((1.0 - lambda) * (1.0 - lambda)), L.Ssurv.get(), L.strayT.get(), prune_counters.get(), L.stray_items.get(),
+                                     (float)w2s, L.Ssurv.get(), L.strayT.get(), prune_counters.get(), L.stray_items.get(),
                                      L.any_overflow.get()};
                         k_score_stray<<<sgrid, 256, slds, ls>>>(ST);
                         FY_KERNEL_CHECK();

@@ -23,6 +23,8 @@ struct CoopShared {
     EventTimer *t_cooc, *t_score, *t_topn;
     unsigned long long* prune_counters;
     int64_t *blocks_total, *seed_terms_cols, *coop_survived, *coop_pair_contribs;
+    const int32_t* cshift;            // [cluster]: c of the packed matrix format (k_user_meta)
+    float gscale;                     // 2^-c of THIS cluster
 };
 
 static void coll_all_gather(fy_rm2_job* J, const void* send, void* recv, int64_t bytes, hipStream_t st) {
@@ -130,7 +132,8 @@ static void score_cluster_coop(const CoopShared& X, const Plan& p, hipStream_t l
                         (uint32_t)std::min<int64_t>((int64_t)P.nnz * 4, 0xFFFFFFFFll)};
             const int fxk = (X.csr_pk && tune.cooc_fx && !J->fx_bounds.empty()) ? fx_exponent(&J->fx_bounds[3 * (size_t)p.c]) : -1;
             CA.fx_scale = fxk >= 0 ? std::ldexp(1.0, fxk) : 0.0;
-            MEpilogue ME{const_cast<float*>(Mshift), ldm, (float)((1.0 - lambda) * (1.0 - lambda)), fxk >= 0 ? std::ldexp((1.0 - lambda) * (1.0 - lambda), -fxk) : 0.0,
+            const double w2s = (1.0 - lambda) * (1.0 - lambda) * (double)X.gscale;      // (1-l)^2 and the packed format's 2^-c
+            MEpilogue ME{const_cast<float*>(Mshift), ldm, (float)w2s, fxk >= 0 ? std::ldexp(w2s, -fxk) : 0.0,
                          1, const_cast<float*>(Bshift), ldb, 1};
             const size_t sp = X.t_cooc->begin(ls);
             const int n_items = nrows * nch;
@@ -156,7 +159,7 @@ static void score_cluster_coop(const CoopShared& X, const Plan& p, hipStream_t l
     FY_HIP(hipMemsetAsync(dummy.get(), 0, 2 * sizeof(unsigned long long), ls));
     k_user_meta<<<grid_for(Uc), 256, 0, ls>>>(sbase, sbase + Uc, P.slot2du.get(), P.uid.get(), P.ucluster.get(), P.udeg.get(),
                                                P.d_csize.get(), P.d_pcstart.get(), prm.number_of_items, prm.number_of_recommendations,
-                                               prm.filter_users, pv_all.get(), n_out_all.get(), dummy.get());
+                                               prm.filter_users, X.cshift, pv_all.get(), n_out_all.get(), dummy.get());
     FY_KERNEL_CHECK();
     if (me != 0) FY_HIP(hipMemsetAsync(pv_all.get(), 0, (size_t)Uc * sizeof(double), ls));   // pvpi enters the sum once
 

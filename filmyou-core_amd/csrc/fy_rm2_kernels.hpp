@@ -72,12 +72,13 @@ template <> struct VecT<4> { using type = float4; };
 struct U3 {
     uint32_t a, b, c;
 };
-// four packed 24-bit values (12 bytes; exponent + 16 mantissa bits, no sign) -> four floats: v_perm_b32 + shift each
+// four packed 24-bit values (12 bytes; 7 exponent + 17 mantissa bits of a float < 2, no sign: FY_P24_SHIFT in fy_rm2.hip) -> four
+// floats: v_perm_b32 (the three bytes into the upper three of a dword) + shift each
 __device__ __forceinline__ void fy_unpack24(const U3& d, float* f) {
-    f[0] = __uint_as_float(__builtin_amdgcn_perm(0u, d.a, 0x0201000cu) >> 1);
-    f[1] = __uint_as_float(__builtin_amdgcn_perm(d.b, d.a, 0x0504030cu) >> 1);
-    f[2] = __uint_as_float(__builtin_amdgcn_perm(d.c, d.b, 0x0403020cu) >> 1);
-    f[3] = __uint_as_float(__builtin_amdgcn_perm(0u, d.c, 0x0302010cu) >> 1);
+    f[0] = __uint_as_float(__builtin_amdgcn_perm(0u, d.a, 0x0201000cu) >> (8 - FY_P24_SHIFT));
+    f[1] = __uint_as_float(__builtin_amdgcn_perm(d.b, d.a, 0x0504030cu) >> (8 - FY_P24_SHIFT));
+    f[2] = __uint_as_float(__builtin_amdgcn_perm(d.c, d.b, 0x0403020cu) >> (8 - FY_P24_SHIFT));
+    f[3] = __uint_as_float(__builtin_amdgcn_perm(0u, d.c, 0x0302010cu) >> (8 - FY_P24_SHIFT));
 }
 
 // Does a block with upper bound `ub` have to be scored exactly for a user whose N-th best seed score is `tau`?
@@ -766,7 +767,7 @@ struct RepairArgs {
 __device__ __forceinline__ float fy_load24(const float* __restrict__ base3, int64_t entry) {
     const uint8_t* __restrict__ b = reinterpret_cast<const uint8_t*>(base3) + entry * 3;
     const uint32_t v = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16);
-    return __uint_as_float(v << 7);
+    return __uint_as_float(v << FY_P24_SHIFT);
 }
 __global__ __launch_bounds__(256) void k_bound_repair(RepairArgs A) {
     // One WORKGROUP per user: its four waves take every fourth surviving block (a wave per user left a cluster of 800 users on 200
@@ -815,7 +816,7 @@ __global__ __launch_bounds__(256) void k_bound_repair(RepairArgs A) {
                                 const int col = c0 + (int)(rep & 63u);
                                 int l = r0, h = r1;                     // did the user rate the column of the maximum?
                                 while (l < h) { const int m = (l + h) >> 1; if (A.csr_idx[m] < col) l = m + 1; else h = m; }
-                                if (l < r1 && A.csr_idx[l] == col) g = __uint_as_float((rep >> 8) << 7);
+                                if (l < r1 && A.csr_idx[l] == col) g = __uint_as_float((rep >> 8) << FY_P24_SHIFT);
                             }
                         }
                         sum += (double)fy_log2(fmaf(A.csr_q[f], bm, fmaf(am, A.csr_e[f], g)));

@@ -56,6 +56,20 @@ def test_rm2_panel_mode_50_clusters_equals_full_pass_all_rows(data):
     assert n_diff <= 1e-5 * len(rows["user"])
 
 
+@pytest.mark.parametrize("clusters", [1, 50])
+def test_rm2_24bit_matrix_against_fp32_matrix_all_rows(data, pruned, clusters):
+    """The production matrix format (24-bit floats above 4096 items) against the same job with fp32 rows
+    (FY_M24=0: 14 GB at this shape, no pruning -- every log term from an fp32 matrix): ALL 8.1 M rows, one cluster and 50.
+    north_star's tolerance is 1e-5 relative; the observed maximum is printed."""
+    rows = pruned[0] if clusters == 1 else run_rm2(data, TOPN, LAM, clusters=clusters)[0]
+    rows32, _, st32 = run_rm2(data, TOPN, LAM, env={"FY_M24": "0"}, clusters=clusters)
+    assert st32["blocks_total"] == 0 and st32["panel_clusters"] == 0
+    n_diff, worst = assert_same_lists(rows, rows32, score_rtol=1e-5, tie_rtol=2e-5)
+    print("24-bit matrix vs fp32 matrix, %d cluster(s): %d rows, %d differ (ties at a cut-off), worst relative score difference %.2e"
+          % (clusters, len(rows["user"]), n_diff, worst))
+    assert n_diff <= 1e-4 * len(rows["user"])
+
+
 def test_itemsim_full_size(data):
     check_itemsim(data)
 

@@ -4,7 +4,8 @@ import numpy as np
 import pytest
 import scipy.sparse as sp
 
-from util import RTOL, pkg, synth
+import oracle
+from util import ATOL, RTOL, assert_topn_matches, pkg, synth
 
 pytestmark = pytest.mark.gpu
 
@@ -62,4 +63,38 @@ def test_all_users_against_definition(shape):
         assert np.all(np.abs(gs - best) <= RTOL * np.abs(best)), uid
     print("worst relative error vs fp64 definition %.2e (user with %d ratings)" % (worst, worst_n))
     assert worst <= RTOL
+    ctx.close()
+
+
+def test_ml1m_50_clusters_top50_against_the_oracle():
+    """BASELINE.json configs[1] (C1: MovieLens-1M shape, top-50) in the reference's own regime -- 50 clusters
+    (T/rmrecommender/TestRMRecommenderJob.java:49) -- against the BRUTE-FORCE oracle (oracle/rm2_oracle.c: the reference's dense
+    cache and triple loop, AbstractRM2Reducer.java:185-190, 332-356), not against a re-arranged formula: every row of every user."""
+    P, S = pkg(), synth()
+    u, i, s, facts = S.generate("ml1m")
+    u, i, s = u.numpy(), i.numpy(), s.numpy()
+    lam, N, K = 0.1, 50, 50
+    mu = np.arange(1, facts["n_users"] + 1, dtype=np.int32)
+    mc = S.hash_clustering(mu, K)
+    conf = P.Configuration()
+    conf.set("lambda", repr(lam))
+    conf.setInt("numberOfItems", facts["n_items"])
+    conf.setInt("numberOfClusters", K)
+    conf.setInt("numberOfRecommendations", N)
+    ctx = P.Context(0)
+    rec = P.RM2Job(conf, ctx).run((u, i, s), clustering=(mu, mc))
+    rows = rec.rows()
+    ref = oracle.rm2(u, i, s, lam=lam, number_of_items=facts["n_items"], number_of_recommendations=1 << 30, number_of_clusters=K,
+                     map_user=mu, map_cluster=mc, n_threads=16)
+    worst = assert_topn_matches(rows, ref, N)
+    # how many comparisons needed the absolute term of tests/util.py (ATOL) on top of north_star's relative 1e-5
+    want = {(int(a), int(b)): float(c) for a, b, c in zip(ref["rec_user"], ref["rec_item"], ref["rec_score"])}
+    w = np.array([want[(int(a), int(b))] for a, b in zip(rows["user"], rows["item"])])
+    g = rows["score"].astype(np.float64)
+    fin = np.isfinite(w)
+    needed_atol = int(np.sum(np.abs(g[fin] - w[fin]) > RTOL * np.abs(w[fin])))
+    print("ML-1M shape, 50 clusters, top-50 vs brute-force oracle: %d rows, worst relative error %.2e, %d comparisons beyond the pure 1e-5 "
+          "relative bound (absolute slack %.0e)" % (len(g), worst, needed_atol, ATOL))
+    assert needed_atol == 0
+    rec.close()
     ctx.close()

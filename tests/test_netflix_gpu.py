@@ -47,6 +47,15 @@ def test_rm2_netflix_panel_mode_50_clusters_equals_full_pass_all_rows(data):
     assert n_diff <= 1e-5 * len(rows["user"])
 
 
+def test_rm2_netflix_24bit_matrix_against_fp32_matrix_all_rows(data, pruned):
+    """the production matrix format against fp32 rows (FY_M24=0), all 48 M rows (see tests/test_full_size_gpu.py)"""
+    rows32, _, st32 = run_rm2(data, TOPN, LAM, env={"FY_M24": "0"})
+    assert st32["blocks_total"] == 0
+    n_diff, worst = assert_same_lists(pruned[0], rows32, score_rtol=1e-5, tie_rtol=2e-5)
+    print("24-bit matrix vs fp32 matrix: %d rows, %d differ (ties at a cut-off), worst relative score difference %.2e" % (len(rows32["user"]), n_diff, worst))
+    assert n_diff <= 1e-4 * len(rows32["user"])
+
+
 def test_itemsim_netflix_shape(data):
     check_itemsim(data, n_rows=4)
 
