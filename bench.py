@@ -416,6 +416,8 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     ratings.close()
+    if collectives is not None and hasattr(collectives, "close"):
+        collectives.close()          # before the context: the communicator drains the context's stream
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

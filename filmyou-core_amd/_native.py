@@ -21,7 +21,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
 SYMBOLS = [
     "fy_abi_version", "fy_last_error", "fy_context_create", "fy_context_destroy", "fy_context_synchronize", "fy_context_reload_tuning", "fy_context_inject_alloc_failure",
     "fy_context_stream", "fy_ratings_create", "fy_ratings_destroy", "fy_ratings_nnz", "fy_rm2_prepare",
-    "fy_rm2_partial_stats", "fy_rm2_set_global_stats", "fy_rm2_set_collectives", "fy_rccl_unique_id", "fy_rccl_create", "fy_rccl_collectives", "fy_rccl_counters", "fy_rccl_destroy", "fy_rm2_score", "fy_rm2_job_destroy", "fy_rm2_run",
+    "fy_rm2_partial_stats", "fy_rm2_set_global_stats", "fy_rm2_set_collectives", "fy_rccl_unique_id", "fy_rccl_create", "fy_rccl_collectives", "fy_rccl_counters", "fy_rccl_destroy", "fy_rccl_detach_context", "fy_rm2_score", "fy_rm2_job_destroy", "fy_rm2_run",
     "fy_itemsim_build", "fy_itemsim_run", "fy_itemcf_recommend", "fy_cluster_assign", "fy_nmf_factorize", "fy_result_size", "fy_result_key0", "fy_result_key1", "fy_result_value",
     "fy_result_aux", "fy_result_n_users", "fy_result_user_id", "fy_result_user_sum", "fy_result_n_items",
     "fy_result_item_id", "fy_result_item_coll", "fy_result_total_sum", "fy_result_free", "fy_result_stats",
@@ -183,6 +183,8 @@ def load():
     L.fy_rccl_counters.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
     L.fy_rccl_destroy.argtypes = [vp]
     L.fy_rccl_destroy.restype = None
+    L.fy_rccl_detach_context.argtypes = [vp]
+    L.fy_rccl_detach_context.restype = None
     L.fy_rm2_score.argtypes = [vp, pvp]
     L.fy_rm2_job_destroy.argtypes = [vp]
     L.fy_rm2_job_destroy.restype = None

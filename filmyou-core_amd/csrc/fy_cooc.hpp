@@ -3,8 +3,9 @@
 // One workgroup owns one row `i` of the item x item co-rating matrix (restricted to a column chunk that fits LDS):
 //     acc[j] = sum over users v who rated i of  w_vi * w_vj          (j in the chunk)
 // walking the CSC column of i (who rated it) and, for every such user, the slice of the user's CSR row that falls
-// into the chunk.  Accumulators are fp64 in LDS (ds_add_f64), so the summation order between waves changes the
-// result only below 1e-15 relative.  The epilogue turns the finished row into either a dense row of RM2's M
+// into the chunk.  Accumulators live in LDS: 64-bit FIXED POINT (ds_add_u64) in the packed walk -- the product path of both
+// jobs at the benchmark sizes: integer sums do not depend on the order of the atomics, the matrix is bit-reproducible -- and
+// fp64 (ds_add_f64) where the ratings are not fp16-exact.  The epilogue turns the finished row into either a dense row of RM2's M
 // matrix (fy_rm2.hip) or the top-K similar items of item i (fy_itemsim.hip) -- nothing but the epilogue differs,
 // which is the "same sparse co-rating Gram" observation of SURVEY.md section 8a.
 //
@@ -105,9 +106,8 @@ __device__ __forceinline__ SegBatch cooc_first_batch(const CoocArgs& A, int s_be
     return B;
 }
 
-// ACC = double: ds_add_f64 (item-item similarity: sums of up to 10^5 products compared at 2e-6); ACC = float: ds_add_f32
-// (RM2: the sums are rounded to 24 bits afterwards and enter the score through a logarithm -- DESIGN.md section 2 -- and
-// half the LDS per column lets two workgroups share a CU, one accumulating while the other is in its epilogue).
+// The unpacked walk (8-byte CSR entries: ratings that are not fp16-exact).  ACC = double: ds_add_f64.  (ACC = float, ds_add_f32,
+// is a MEASUREMENT build only, FY_COOC_F32: 193 cycles per wave instruction on gfx950 against 21 for ds_add_f64 -- 4x slower.)
 template <bool PK, class ACC>
 __device__ __forceinline__ void cooc_accumulate_segments(const CoocArgs& A, ACC* __restrict__ acc, int s_begin, int s_end, int c0, SegBatch first) {
     const int lane = threadIdx.x & 63;

@@ -11,6 +11,8 @@
 #include <dlfcn.h>
 
 #include <cstring>
+#include <mutex>
+#include <string>
 
 #include "fy_common.hpp"
 
@@ -31,29 +33,45 @@ struct Rccl {
     int (*ReduceScatter)(const void*, void*, size_t, int, int, nccl_comm, hipStream_t) = nullptr;
 };
 
-Rccl* rccl() {
-    static Rccl R;
-    static bool tried = false;
-    if (tried) return R.handle ? &R : nullptr;
-    tried = true;
-    const char* names[] = {"librccl.so.1", "librccl.so"};
-    for (const char* n : names)   // a copy already in the process (e.g. PyTorch's) is preferred
-        if ((R.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL))) break;
-    if (!R.handle)
-        for (const char* n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
-            if ((R.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
-    if (!R.handle) return nullptr;
-#define FY_SYM(field, name)                                          \
-    R.field = reinterpret_cast<decltype(R.field)>(dlsym(R.handle, name)); \
-    if (!R.field) { R.handle = nullptr; return nullptr; }
-    FY_SYM(GetUniqueId, "ncclGetUniqueId")
-    FY_SYM(CommInitRank, "ncclCommInitRank")
-    FY_SYM(CommDestroy, "ncclCommDestroy")
-    FY_SYM(GetErrorString, "ncclGetErrorString")
-    FY_SYM(AllGather, "ncclAllGather")
-    FY_SYM(ReduceScatter, "ncclReduceScatter")
+// opened once per process (std::call_once: the ThreadGroup test harness creates communicators from several threads); the
+// loader's diagnostic of a failed dlopen / dlsym is captured where it happens (dlerror() clears itself when read)
+struct RcclLoad {
+    Rccl R;
+    std::string why;
+};
+RcclLoad& rccl_load() {
+    static RcclLoad L;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        Rccl& R = L.R;
+        const char* names[] = {"librccl.so.1", "librccl.so"};
+        for (const char* n : names)   // a copy already in the process (e.g. PyTorch's) is preferred
+            if ((R.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL))) break;
+        if (!R.handle)
+            for (const char* n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+                if ((R.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+                const char* e = dlerror();
+                L.why = e ? e : "dlopen failed";
+            }
+        if (!R.handle) return;
+#define FY_SYM(field, name)                                                          \
+    if (R.handle) {                                                                  \
+        R.field = reinterpret_cast<decltype(R.field)>(dlsym(R.handle, name));        \
+        if (!R.field) { const char* e = dlerror(); L.why = e ? e : name " is missing"; R.handle = nullptr; } \
+    }
+        FY_SYM(GetUniqueId, "ncclGetUniqueId")
+        FY_SYM(CommInitRank, "ncclCommInitRank")
+        FY_SYM(CommDestroy, "ncclCommDestroy")
+        FY_SYM(GetErrorString, "ncclGetErrorString")
+        FY_SYM(AllGather, "ncclAllGather")
+        FY_SYM(ReduceScatter, "ncclReduceScatter")
 #undef FY_SYM
-    return &R;
+    });
+    return L;
+}
+Rccl* rccl() {
+    RcclLoad& L = rccl_load();
+    return L.R.handle ? &L.R : nullptr;
 }
 
 }  // namespace
@@ -83,7 +101,7 @@ extern "C" {
 int fy_rccl_unique_id(char* out128) {
     if (!out128) { fy::set_error("out128 is NULL"); return FY_ERR_INVALID_ARGUMENT; }
     Rccl* R = rccl();
-    if (!R) { fy::set_error("librccl.so could not be opened: %s", dlerror() ? dlerror() : "symbols missing"); return FY_ERR_COLLECTIVE; }
+    if (!R) { fy::set_error("librccl.so could not be opened: %s", rccl_load().why.c_str()); return FY_ERR_COLLECTIVE; }
     nccl_unique_id id;
     const int rc = R->GetUniqueId(&id);
     if (rc != NCCL_SUCCESS) { fy::set_error("ncclGetUniqueId: %s", R->GetErrorString(rc)); return FY_ERR_COLLECTIVE; }
@@ -96,7 +114,7 @@ int fy_rccl_create(fy_context* c, int rank, int world, const char* id128, fy_rcc
     *out = nullptr;
     if (!c || !id128 || world <= 0 || rank < 0 || rank >= world) { fy::set_error("fy_rccl_create: bad arguments (rank %d of %d)", rank, world); return FY_ERR_INVALID_ARGUMENT; }
     Rccl* R = rccl();
-    if (!R) { fy::set_error("librccl.so could not be opened"); return FY_ERR_COLLECTIVE; }
+    if (!R) { fy::set_error("librccl.so could not be opened: %s", rccl_load().why.c_str()); return FY_ERR_COLLECTIVE; }
     if (hipSetDevice(c->c.device) != hipSuccess) { fy::set_error("hipSetDevice(%d) failed", c->c.device); return FY_ERR_HIP; }
     nccl_unique_id id;
     std::memcpy(id.internal, id128, 128);
@@ -128,6 +146,12 @@ int fy_rccl_counters(const fy_rccl* h, int64_t* all_gathers, int64_t* reduce_sca
     if (reduce_scatters) *reduce_scatters = h->calls_reduce_scatter;
     if (payload_bytes) *payload_bytes = h->bytes;
     return FY_OK;
+}
+
+// (the context must still be alive: the communicator's queued collectives live on its stream.  A host that has already destroyed
+// the context -- interpreter teardown -- calls fy_rccl_detach_context first and only the communicator is released.)
+void fy_rccl_detach_context(fy_rccl* h) {
+    if (h) h->ctx = nullptr;
 }
 
 void fy_rccl_destroy(fy_rccl* h) {

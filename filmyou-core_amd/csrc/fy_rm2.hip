@@ -1263,7 +1263,10 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             if (p.a >= p.b || p.Ic == 0) continue;
             p.ldm = round_up(p.Ic, 256);
             p.pack24 = cluster_pack24[c] != 0;
-            pick_chunks(p.Ic, max_ch_lds, p.CH, p.nch);
+            // (the item ids of the row kernel hold the chunk in 8 bits, k_item_list: at most 255 chunks per row -- a forced
+            // FY_COOC_MAX_CH too small for that is widened)
+            pick_chunks(p.Ic, std::max<int>(max_ch_lds, (int)round_up(ceil_div(p.Ic, 255), 256)), p.CH, p.nch);
+            if (p.nch >= 256) FY_FAIL(FY_ERR_UNSUPPORTED, "cluster %d: %d items need %d column chunks (limit 255)", c, p.Ic, p.nch);
             p.q0 = P.cluster_q[c];
             p.nq = P.cluster_q[c + 1] - p.q0;
             // branch-and-bound over 256-column blocks: only where the matrix is big enough for the bound pass to pay

@@ -364,14 +364,22 @@ class RM2Job:
         ok = (ck >= 0) & (ck < len(count))
         count[ck[ok]] = cv[ok]
         rm2 = os.path.join(base, "rm2")
-        shutil.rmtree(rm2, ignore_errors=True)
+        suffix = "part-r-%05d" % rank
+        # Rank 0 alone wipes <directory>/rm2 (RM2Job.java:84), BEFORE its first collective: every other rank writes only after the
+        # job, i.e. after a collective rank 0 has joined.  mapred.output.dir is never deleted (the reference does not: Hadoop's
+        # FileOutputFormat.checkOutputSpecs refuses an existing directory and the job fails): an existing directory fails the job on
+        # a single rank; with several ranks the directory is shared, and only this rank's own part file must not exist.
+        if rank == 0:
+            shutil.rmtree(rm2, ignore_errors=True)
+        if (world == 1 and os.path.exists(outp)) or os.path.exists(os.path.join(outp, suffix)):
+            raise RuntimeError("%s failed!: output directory %s already exists" % (self.JOB_NAME, outp))
         rec = self.run((user, item, score), clustering=(cu, cc), clustering_count=count, rank=rank, world=world, **kw)
         try:
-            rows, sums = rec.rows(), rec.sums()
-            suffix = "part-r-%05d" % rank
-            seqfile.write_int_double(os.path.join(rm2, "userSum", suffix), sums["user_id"], sums["user_sum"])
-            seqfile.write_mapfile_int_double(os.path.join(rm2, "itemColl", suffix), sums["item_id"], sums["item_coll"])
-            shutil.rmtree(outp, ignore_errors=True)
+            rows = rec.rows()
+            if rank == 0:       # rm2/userSum and rm2/itemColl are the GLOBAL statistics (jobs RM2-1 / RM2-2): one copy
+                sums = rec.sums()
+                seqfile.write_int_double(os.path.join(rm2, "userSum", "part-r-00000"), sums["user_id"], sums["user_sum"])
+                seqfile.write_mapfile_int_double(os.path.join(rm2, "itemColl", "part-r-00000"), sums["item_id"], sums["item_coll"])
             seqfile.write_intpair_float(os.path.join(outp, suffix), rows["user"], rows["item"], rows["score"])
         finally:
             rec.close()

@@ -188,6 +188,8 @@ class RcclCollectives:
 
     def close(self):
         if getattr(self, "_h", None):
+            if not getattr(self._ctx, "_h", None):       # the context went first (interpreter teardown): do not touch its stream
+                self._lib.fy_rccl_detach_context(self._h)
             self._lib.fy_rccl_destroy(self._h)
             self._h = None
 

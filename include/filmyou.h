@@ -137,7 +137,8 @@ int fy_rccl_unique_id(char* out128);
 int fy_rccl_create(fy_context*, int rank, int world, const char* id128, fy_rccl** out);
 int fy_rccl_collectives(fy_rccl*, fy_collectives* out);   /* fills the callbacks; `out->user` is the fy_rccl, which must outlive the job */
 int fy_rccl_counters(const fy_rccl*, int64_t* all_gathers, int64_t* reduce_scatters, int64_t* payload_bytes);
-void fy_rccl_destroy(fy_rccl*);
+void fy_rccl_destroy(fy_rccl*);           /* the context must still exist (its stream is drained first) ... */
+void fy_rccl_detach_context(fy_rccl*);    /* ... unless this was called: the context is already gone, only the communicator is released */
 /* Stage 2 (job RM2-3): per-cluster co-rating matrix, p(i|u) scoring of this rank's users, top-N. */
 int fy_rm2_score(fy_rm2_job*, fy_result** out);
 void fy_rm2_job_destroy(fy_rm2_job*);

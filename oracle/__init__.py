@@ -10,7 +10,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "_build", "liboracle.so")
+# FY_ORACLE_LIB: another build of the same sources (tests/test_sanitizers_cpu.py loads the ASan + UBSan build)
+_SO = os.environ.get("FY_ORACLE_LIB") or os.path.join(_HERE, "_build", "liboracle.so")
 _lib = None
 
 
@@ -18,7 +19,7 @@ def build(force=False):
     """Compile liboracle.so with gcc (seconds).  Safe to call repeatedly."""
     srcs = [os.path.join(_HERE, f) for f in ("rm2_oracle.c", "itemsim_oracle.c", "itemcf_oracle.c", "cluster_oracle.c", "nmf_oracle.c", "oracle.h", "Makefile")]
     stale = force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
-    if stale:
+    if stale and not os.environ.get("FY_ORACLE_LIB"):
         subprocess.run(["make", "-C", _HERE, "-s"] + (["-B"] if force else []), check=True)
     return _SO
 

@@ -34,8 +34,9 @@ def test_rm2_pruned_equals_full_pass_all_rows(data, pruned):
     rows, _, st = pruned
     rows_full, _, st_full = run_rm2(data, TOPN, LAM, env={"FY_PRUNE": "0"})
     assert st_full["blocks_total"] == 0 and st_full["recs"] == st["recs"]
-    # (the two jobs build M separately and the fp64 LDS atomics commit in any order: an entry may round to the neighbouring 24-bit
-    # value, 1.5e-5 of ONE term; users with a dozen ratings have |score| ~ 3-30, so 1e-5 relative = the north-star tolerance)
+    # (both jobs build the same matrix bit for bit -- fixed-point accumulators -- and a surviving block is scored from the same
+    # packed rows by the same arithmetic as the full pass: since round 3 the two jobs print "0 differ, worst score difference 0";
+    # the bound below is north_star's tolerance, kept as the assertion)
     n_diff, worst = assert_same_lists(rows, rows_full, score_rtol=1e-5)
     print("pruned vs full pass: %d rows, %d differ (ties at a cut-off), worst score difference %.2e" % (len(rows["user"]), n_diff, worst))
     assert n_diff <= 1e-5 * len(rows["user"])
