@@ -842,14 +842,15 @@ static void stray_allow_lds() {   // k_score_stray: (Uc + 1) rater offsets of dy
 void launch_topn_rows(Context* ctx, hipStream_t st, const float* S, int64_t ldS, int32_t n_cols, int32_t n_rows,
                       const int32_t* n_out, const int32_t* out_off, const int32_t* rank_item_raw, const int32_t* slot2du,
                       const int32_t* uid, int32_t slot0, int32_t aux_value, int32_t* out_user, int32_t* out_item,
-                      float* out_score, int32_t* out_aux, int32_t* overflow, int32_t* any_overflow) {
+                      float* out_score, int32_t* out_aux, int32_t* overflow, int32_t* any_overflow, int32_t top_n_hint) {
     if (n_rows <= 0) return;
     if (!st) st = ctx->stream;
     // n_out / out_off are indexed by (slot - slot_lo): pass slot_lo = slot0 so that row u reads entry u
     TopNArgs TA{S, ldS, n_cols, n_out, out_off, rank_item_raw, slot2du, uid, slot0, slot0, aux_value, out_user, out_item, out_score, out_aux,
                 0, 0, nullptr, nullptr, 0, nullptr, nullptr, nullptr};
     FY_HIP(hipMemsetAsync(any_overflow, 0, sizeof(int32_t), st));
-    k_topn_fast<<<n_rows, 256, 0, st>>>(TA, overflow, any_overflow, 0);
+    if (top_n_hint > TOPN_LONG) k_topn_long<<<n_rows, 256, (size_t)fy_topn_long_cap(top_n_hint) * 8, st>>>(TA, overflow, any_overflow, 0, fy_topn_long_cap(top_n_hint));
+    else k_topn_fast<<<n_rows, 256, 0, st>>>(TA, overflow, any_overflow, 0);
     FY_KERNEL_CHECK();
     k_topn_select<<<n_rows, 256, 0, st>>>(TA, overflow, any_overflow);
     FY_KERNEL_CHECK();
@@ -1600,7 +1601,10 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                             R->d_key0.get(), R->d_key1.get(), R->d_value.get(), R->d_aux.get(), 0, 0, nullptr, nullptr, 0, nullptr, nullptr, nullptr};
                 const size_t tt = t_topn.begin(ls);
                 FY_HIP(hipMemsetAsync(L.any_overflow.get(), 0, sizeof(int32_t), ls));
-                k_topn_fast<<<nb, 256, 0, ls>>>(TA, L.overflow.get(), L.any_overflow.get(), tune.force_select);
+                if (prm.number_of_recommendations > TOPN_LONG)
+                    k_topn_long<<<nb, 256, (size_t)fy_topn_long_cap(prm.number_of_recommendations) * 8, ls>>>(TA, L.overflow.get(), L.any_overflow.get(), tune.force_select,
+                                                                                                         fy_topn_long_cap(prm.number_of_recommendations));
+                else k_topn_fast<<<nb, 256, 0, ls>>>(TA, L.overflow.get(), L.any_overflow.get(), tune.force_select);
                 FY_KERNEL_CHECK();
                 k_topn_select<<<nb, 256, 0, ls>>>(TA, L.overflow.get(), L.any_overflow.get(), prune_counters.get() + 2);
                 FY_KERNEL_CHECK();

@@ -45,5 +45,5 @@ fy_result* itemcf_recommend(Context*, const fy_itemcf_params*, const fy_ratings*
 void launch_topn_rows(Context* ctx, hipStream_t st, const float* S, int64_t ldS, int32_t n_cols, int32_t n_rows,
                       const int32_t* n_out, const int32_t* out_off, const int32_t* rank_item_raw, const int32_t* slot2du,
                       const int32_t* uid, int32_t slot0, int32_t aux_value, int32_t* out_user, int32_t* out_item,
-                      float* out_score, int32_t* out_aux, int32_t* overflow, int32_t* any_overflow);
+                      float* out_score, int32_t* out_aux, int32_t* overflow, int32_t* any_overflow, int32_t top_n_hint = 0);
 }  // namespace fy

@@ -275,9 +275,11 @@ __device__ __forceinline__ float fy_order_unkey(uint32_t k) {
     return __uint_as_float(b);
 }
 
-constexpr int TOPN_MAX = 2048;
+constexpr int TOPN_MAX = 2048;       // longest list (min(numberOfRecommendations, items of the cluster))
+constexpr int TOPN_CAP = 4096;       // candidate buffer of k_topn_fast (LDS)
 constexpr int TOPN_BINS = 4096;
-constexpr int TOPN_SAMPLE = 1024;
+constexpr int TOPN_SAMPLE = 1024;    // leading columns that give the lower bound of a short list; a long list takes 4 N (fy_topn_sample)
+constexpr int TOPN_LONG = 256;       // lists longer than this take k_topn_long
 constexpr int PRUNE_BLOCK_COLS = 256;   // candidate block of the branch and bound = one column chunk
 
 // descending bitonic sort of P2 (power of two) 64-bit keys in LDS; every thread of the block calls it
@@ -323,7 +325,8 @@ __global__ __launch_bounds__(256) void k_topn_fast(TopNArgs A, int32_t* __restri
     }
     const float* __restrict__ row = A.S + (int64_t)u * A.ldS;
     const int tid = threadIdx.x;
-    const int Ls = min(A.Ic, A.mode ? min(A.seed_cols, TOPN_SAMPLE) : TOPN_SAMPLE);
+    constexpr int sample0 = TOPN_SAMPLE;
+    const int Ls = min(A.Ic, A.mode ? min(A.seed_cols, TOPN_SAMPLE) : sample0);
     if (tid == 0) sh_nvalid = 0;
     __syncthreads();
     int myvalid = 0;
@@ -361,17 +364,9 @@ __global__ __launch_bounds__(256) void k_topn_fast(TopNArgs A, int32_t* __restri
     if (tid == 0) sh_count = (uint32_t)keep;
     __syncthreads();
     // stream the rest of the row (mode 2: only the surviving blocks, 16 float4 each)
-    const int i4_begin = A.mode == 2 ? 0 : (TOPN_SAMPLE >> 2);
+    const int i4_begin = A.mode == 2 ? 0 : (sample0 >> 2);
     const int i4_end = A.mode == 2 ? A.n_quads[u] * (PRUNE_BLOCK_COLS / 4) : (A.Ic + 3) >> 2;
-    for (int x = i4_begin + tid; x < i4_end; x += blockDim.x) {
-        int i4 = x;
-        const float* src = row + 4 * (int64_t)x;
-        if (A.mode == 2) {
-            const unsigned blk = A.surv[(int64_t)u * A.ldb + (x >> 6)];
-            i4 = (int)blk * (PRUNE_BLOCK_COLS / 4) + (x & 63);
-            src = A.Ssurv ? A.Ssurv + ((int64_t)(A.quad_prefix[u] + (x >> 6)) * PRUNE_BLOCK_COLS + 4 * (x & 63)) : row + 4 * (int64_t)i4;
-        }
-        const float4 f4 = *reinterpret_cast<const float4*>(src);
+    auto take4 = [&](const float4& f4, int i4) __attribute__((always_inline)) {
         const float fv[4] = {f4.x, f4.y, f4.z, f4.w};
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -384,6 +379,28 @@ __global__ __launch_bounds__(256) void k_topn_fast(TopNArgs A, int32_t* __restri
                     if (pos < (uint32_t)TOPN_MAX) cand[pos] = ((uint64_t)key << 32) | (uint32_t)(0x7FFFFFFF - A.rank_item_raw[i]);
                 }
             }
+        }
+    };
+    if (A.mode == 2) {
+        for (int x = i4_begin + tid; x < i4_end; x += blockDim.x) {
+            const unsigned blk = A.surv[(int64_t)u * A.ldb + (x >> 6)];
+            const int i4 = (int)blk * (PRUNE_BLOCK_COLS / 4) + (x & 63);
+            const float* src = A.Ssurv ? A.Ssurv + ((int64_t)(A.quad_prefix[u] + (x >> 6)) * PRUNE_BLOCK_COLS + 4 * (x & 63)) : row + 4 * (int64_t)i4;
+            take4(*reinterpret_cast<const float4*>(src), i4);
+        }
+    } else {
+        // whole row: four 16-byte loads in flight per thread (a row is 236 KB at ML-25M shape; one load per trip was latency-bound)
+        constexpr int UNR = 4;
+        const float4 nan4 = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
+        for (int x0 = i4_begin + tid; x0 < i4_end; x0 += UNR * (int)blockDim.x) {
+            float4 f4[UNR];
+#pragma unroll
+            for (int q = 0; q < UNR; q++) {
+                const int x = x0 + q * (int)blockDim.x;
+                f4[q] = x < i4_end ? *reinterpret_cast<const float4*>(row + 4 * (int64_t)x) : nan4;
+            }
+#pragma unroll
+            for (int q = 0; q < UNR; q++) take4(f4[q], x0 + q * (int)blockDim.x);
         }
     }
     __syncthreads();
@@ -408,6 +425,137 @@ __global__ __launch_bounds__(256) void k_topn_fast(TopNArgs A, int32_t* __restri
     }
 }
 
+
+
+// Long lists (N > TOPN_LONG; the reference's default is N = 1000, RMRecommenderDriver.java:95), whole rows.  With a 1024-column
+// sample the 1000th best is no bound at all: in round 2 every user overflowed into the multi-pass radix select below
+// (117 ms per job for 38 GB of scores, 213 ms at 50 clusters).  Here the sample is the 4 N most popular columns (at most 4096),
+// and instead of sorting it the threshold comes from a two-level histogram of the sample's keys (bits 31..24, then 23..16): the
+// largest 16-bit key prefix T with at least N sample values at or above it -- a valid lower bound of the row's N-th best, 2^-7
+// relative below the sample's own N-th best, so the sample contributes N + a few dozen candidates.  One stream over the rest of
+// the row appends what reaches T; one bitonic sort of the ~N + 100 candidates gives the list (ties by ascending raw item id).
+// More than TOPN_CAP candidates (massive ties): the user is flagged for k_topn_select, like in k_topn_fast.
+__device__ __forceinline__ void fy_topn_bin(const uint32_t* __restrict__ hist, uint32_t above, uint32_t K, uint32_t* __restrict__ out /* [0] bin, [1] count above it */) {
+    // wave 0: lane l owns bins 4 l .. 4 l + 3; the highest bin b with above + (count in bins >= b) >= K (bin 0 if none)
+    const int lane = threadIdx.x & 63;
+    const uint32_t h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+    uint32_t suf = h0 + h1 + h2 + h3;                       // -> inclusive suffix sum over lanes
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_down((int)suf, o, 64);
+        if (lane + o < 64) suf += t;
+    }
+    const uint32_t higher = above + suf - (h0 + h1 + h2 + h3);     // everything in the lanes above this one
+    const unsigned long long ok = __ballot(higher + h0 + h1 + h2 + h3 >= K);
+    if (!ok) { if (lane == 0) { out[0] = 0u; out[1] = above + suf - h0; } return; }      // fewer than K in all: bin 0 takes everything
+    const int L = 63 - __clzll((long long)ok);
+    if (lane == L) {
+        uint32_t cum = higher;
+        int b = 3;
+        const uint32_t hh[4] = {h0, h1, h2, h3};
+        for (; b > 0; b--) {
+            if (cum + hh[b] >= K) break;
+            cum += hh[b];
+        }
+        out[0] = (uint32_t)(4 * L + b);
+        out[1] = cum;
+    }
+}
+// candidate buffer (dynamic LDS): N + a few dozen entries are expected -- 2048 (16 KB, eight workgroups per CU) up to N = 1400, else 4096
+inline int fy_topn_long_cap(int top_n) { return top_n <= 1400 ? 2048 : TOPN_CAP; }
+__global__ __launch_bounds__(256) void k_topn_long(TopNArgs A, int32_t* __restrict__ overflow, int32_t* __restrict__ any_overflow, int force_select, int cap) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t fy_topn_cand[];
+    uint64_t* __restrict__ cand = fy_topn_cand;
+    __shared__ uint32_t hist[256], sh_bin[2], sh_count;
+    const int u = blockIdx.x, tid = threadIdx.x;
+    const int slot = A.slot0 + u;
+    const int K = A.n_out[slot - A.slot_lo];
+    if (tid == 0) overflow[u] = 0;
+    if (K == 0) return;
+    if (force_select) {
+        if (tid == 0) { overflow[u] = 1; atomicAdd(any_overflow, 1); }
+        return;
+    }
+    const float* __restrict__ row = A.S + (int64_t)u * A.ldS;
+    int sample = TOPN_SAMPLE;
+    while (sample < 4 * K && sample < TOPN_CAP) sample <<= 1;
+    const int Ls = min(A.Ic, sample);
+    constexpr int PER = TOPN_CAP / 256;
+    uint32_t key[PER];
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+        const int i = tid + 256 * q;
+        const float f = i < Ls ? row[i] : __builtin_nanf("");
+        key[q] = f == f ? fy_order_key(f) : 0u;              // valid keys are > 0
+    }
+    uint32_t prefix = 0, above = 0;
+    for (int level = 0; level < 2; level++) {
+        const int shift = level == 0 ? 24 : 16;
+        hist[tid] = 0u;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < PER; q++)
+            if (key[q] && (level == 0 || (key[q] >> 24) == (prefix >> 24))) atomicAdd(&hist[(key[q] >> shift) & 255u], 1u);
+        __syncthreads();
+        if (tid < 64) fy_topn_bin(hist, above, (uint32_t)K, sh_bin);
+        __syncthreads();
+        prefix |= sh_bin[0] << shift;
+        above = sh_bin[1];
+        __syncthreads();
+    }
+    const uint32_t tau = prefix ? prefix : 1u;                // fewer than K valid sample values: every valid score is a candidate
+    if (tid == 0) sh_count = 0u;
+    __syncthreads();
+    auto take = [&](uint32_t k, int i) __attribute__((always_inline)) {
+        if (k >= tau) {                                        // (invalid: key 0 < tau)
+            const uint32_t pos = atomicAdd(&sh_count, 1u);
+            if (pos < (uint32_t)cap) cand[pos] = ((uint64_t)k << 32) | (uint32_t)(0x7FFFFFFF - A.rank_item_raw[i]);
+        }
+    };
+#pragma unroll
+    for (int q = 0; q < PER; q++) take(key[q], tid + 256 * q);
+    constexpr int UNR = 4;
+    const float4 nan4 = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
+    const int i4_end = (A.Ic + 3) >> 2;
+    for (int x0 = (sample >> 2) + tid; x0 < i4_end; x0 += UNR * 256) {
+        float4 f4[UNR];
+#pragma unroll
+        for (int q = 0; q < UNR; q++) {
+            const int x = x0 + q * 256;
+            f4[q] = x < i4_end ? *reinterpret_cast<const float4*>(row + 4 * (int64_t)x) : nan4;
+        }
+#pragma unroll
+        for (int q = 0; q < UNR; q++) {
+            const float fv[4] = {f4[q].x, f4[q].y, f4[q].z, f4[q].w};
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int i = 4 * (x0 + q * 256) + e;
+                const float f = fv[e];
+                take((f == f && i < A.Ic) ? fy_order_key(f) : 0u, i);
+            }
+        }
+    }
+    __syncthreads();
+    const int n = (int)sh_count;
+    if (n > cap) {   // block-uniform
+        if (tid == 0) { overflow[u] = 1; atomicAdd(any_overflow, 1); }
+        return;
+    }
+    int P2 = 1;
+    while (P2 < n) P2 <<= 1;
+    for (int i = n + tid; i < P2; i += 256) cand[i] = 0ull;
+    __syncthreads();
+    fy_bitonic_desc(cand, P2);
+    const int off = A.out_off[slot - A.slot_lo];
+    const int user_raw = A.uid[A.slot2du[slot]];
+    for (int i = tid; i < K; i += 256) {
+        const uint64_t c = cand[i];
+        A.out_user[off + i] = user_raw;
+        A.out_item[off + i] = 0x7FFFFFFF - (int32_t)(uint32_t)c;
+        A.out_score[off + i] = fy_order_unkey((uint32_t)(c >> 32));
+        A.out_cluster[off + i] = A.cluster;
+    }
+}
 
 // Fallback: exact radix select (three histogram passes + collect).  Runs only for users k_topn_fast flagged.
 __global__ __launch_bounds__(256) void k_topn_select(TopNArgs A, const int32_t* __restrict__ overflow,

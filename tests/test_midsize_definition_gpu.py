@@ -98,3 +98,42 @@ def test_ml1m_50_clusters_top50_against_the_oracle():
     assert needed_atol == 0
     rec.close()
     ctx.close()
+
+
+@pytest.fixture(scope="module")
+def sampled_ml25m_cluster():
+    S = synth()
+    rng = np.random.Generator(np.random.PCG64(123))
+    users = np.sort(rng.choice(S.SHAPES["ml25m"][0], size=400, replace=False)) + 1
+    u, i, s, _ = S.generate("ml25m", users=users)
+    u, i, s = u.numpy(), i.numpy(), s.numpy()
+    ref = oracle.rm2_gram(u, i, s, lam=0.1, number_of_items=59047, number_of_recommendations=1 << 30, number_of_clusters=1, n_threads=16)
+    return u, i, s, ref
+
+
+@pytest.mark.parametrize("top_n", [300, 1000])
+def test_long_lists_one_cluster_of_sampled_ml25m_users(sampled_ml25m_cluster, top_n):
+    """The reference's default list length, numberOfRecommendations = 1000 (RMRecommenderDriver.java:95), on a neighbourhood with more
+    items than the top-N kernel's 4096-column sample: 400 users sampled from the ML-25M shape (about 20 000 candidate items, one
+    cluster).  Lists this long take the plain full pass and the one-pass top-N (k_topn_fast: the lower bound from the 4 N most
+    popular columns, one stream over the row).  Checked, every row, against the Gram-restructured CPU scorer (fp64,
+    oracle/rm2_oracle.c:rm2o_run_gram -- the brute-force loop would need 1e12 multiply-adds here; the two CPU scorers are held
+    equal in tests/test_oracle_golden.py)."""
+    P = pkg()
+    u, i, s, ref = sampled_ml25m_cluster
+    n_items = int(len(np.unique(i)))
+    assert n_items > 4096 + top_n
+    conf = P.Configuration()
+    conf.set("lambda", "0.1")
+    conf.setInt("numberOfItems", 59047)
+    conf.setInt("numberOfClusters", 1)
+    conf.setInt("numberOfRecommendations", top_n)
+    ctx = P.Context(0)
+    rec = P.RM2Job(conf, ctx).run((u, i, s))
+    rows, st = rec.rows(), rec.stats
+    worst = assert_topn_matches(rows, ref, top_n)
+    print("top-%d over %d items, %d users: worst relative error %.2e; %d users through the radix-select fallback"
+          % (top_n, n_items, len(np.unique(u)), worst, st["topn_select_users"]))
+    assert st["blocks_total"] == 0 and st["topn_select_users"] == 0
+    rec.close()
+    ctx.close()
