@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <string>
 #include <utility>
 #include <vector>
@@ -257,4 +258,7 @@ struct fy_ratings {
     // largest user / item id over ALL entries (-1: none >= 0), found once when the ratings are put into HBM: the jobs pack
     // their sort keys into the bits these ids need
     int32_t max_user = -1, max_item = -1;
+    // what the last RM2 job over these ratings built from them and its clustering alone (fy_rm2.hip: RM2Static): a later job
+    // with the same clustering starts from it.  Released with the ratings (before their context).
+    mutable std::shared_ptr<void> rm2_cache;
 };

@@ -861,25 +861,70 @@ void launch_topn_rows(Context* ctx, hipStream_t st, const float* S, int64_t ldS,
 // ================================================================ job orchestration
 using namespace fy;
 
-struct fy_rm2_job {
-    Context* ctx = nullptr;
-    fy_rm2_params prm{};
+// Everything about a job that depends only on the RATINGS and the CLUSTERING (and the rank's share): the CSR / CSC of fy_prep,
+// the statistics summed per (cluster, item), and -- filled by the first fy_rm2_score -- the row kernel's tables.  None of it
+// depends on lambda, the list length or numberOfItems.  The reference rebuilds all of it in every job (its mappers re-read and
+// re-shuffle the ratings, RM2Job.java:130-258); here it is kept on the fy_ratings object (fy_ratings::rm2_cache) and a later
+// job over the same ratings and the same clustering starts from it ("warm": fy_stats::prepared_from_cache).  fy_rm2_params::flags
+// & FY_RM2_NO_CACHE builds it afresh and does not keep it: the "cold" job, which bench.py times as its headline value.
+struct TableCache {
+    bool valid = false;
+    std::vector<int32_t> sig;           // what the tables were built for: per planned cluster (c, CH, nch, half, panel, p_eff, tail_chunks), + flags
+    bool have_x = false;
+    DevBuf<float> csc_x, csc_x_over_s;  // x = r / s_v (and x / s_v for the packed walk) per CSC entry: ratings only
+    DevBuf<uint32_t> csr_pk, y_pk;      // packed CSR (chunk-relative columns), block-compressed CSR of the tail rows
+    DevBuf<int32_t> csc_rank;
+    std::vector<SegTable> segs, segs_tail;
+};
+struct RM2Static {
+    // key
+    int32_t K = 0, rank = 0, world = 1;
+    bool has_count = false;
+    std::vector<int32_t> map_user, map_cluster, cluster_count;
+    // fy_rm2_prepare
     Prepared P;
     int32_t slot_lo = 0, slot_hi = 0;
     DevBuf<double> partial;     // nI + 1 : this rank's exchange buffer
-    DevBuf<double> stats;       // nI + 1 : global sums (+ counter)
-    bool have_global = false;
-    double ms_prepare = 0;
-    fy_collectives coll{};      // process-group collectives (optional)
-    bool have_coll = false;
-    DevBuf<double> gathered;    // world * (nI + 1): the statistics all-gathered by fy_rm2_score itself
     // per (cluster, item) in rank order, from the one CSC walk of fy_rm2_prepare (k_pair_pass)
     DevBuf<double> b_rank, usum_slot;
     DevBuf<long long> walk_rank;
     DevBuf<int32_t> cnt_rank, deg_slot;
     DevBuf<float> fx_rank;              // 3 per (cluster, item): see PairPass
     std::vector<float> fx_bounds;       // 3 per cluster (host): max sum of weights, max weight, max rating
+    double ms_build = 0;
+    TableCache tables;
+    bool matches(const fy_rm2_params* prm, int64_t n_map, const int32_t* mu, const int32_t* mc, const int32_t* cc) const {
+        if (K != prm->number_of_clusters || rank != prm->rank || world != prm->world || (int64_t)map_user.size() != n_map || has_count != (cc != nullptr)) return false;
+        if (n_map && (memcmp(map_user.data(), mu, (size_t)n_map * 4) || memcmp(map_cluster.data(), mc, (size_t)n_map * 4))) return false;
+        if (cc && memcmp(cluster_count.data(), cc, (size_t)K * 4)) return false;
+        return true;
+    }
+};
+
+struct fy_rm2_job {
+    Context* ctx = nullptr;
+    fy_rm2_params prm{};
+    std::shared_ptr<RM2Static> S;
+    // (the static part under the names the job code has always used)
+    Prepared& P;
+    int32_t &slot_lo, &slot_hi;
+    DevBuf<double>& partial;
+    DevBuf<double> stats;       // nI + 1 : global sums (+ counter)
+    bool have_global = false;
+    double ms_prepare = 0;
+    bool from_cache = false;
+    fy_collectives coll{};      // process-group collectives (optional)
+    bool have_coll = false;
+    DevBuf<double> gathered;    // world * (nI + 1): the statistics all-gathered by fy_rm2_score itself
+    DevBuf<double>&b_rank, &usum_slot;
+    DevBuf<long long>& walk_rank;
+    DevBuf<int32_t>&cnt_rank, &deg_slot;
+    DevBuf<float>& fx_rank;
+    std::vector<float>& fx_bounds;
     bool count_balanced = false;   // scoring ownership of the users: equal counts instead of equal work (see owner_range)
+    explicit fy_rm2_job(std::shared_ptr<RM2Static> s)
+        : S(std::move(s)), P(S->P), slot_lo(S->slot_lo), slot_hi(S->slot_hi), partial(S->partial), b_rank(S->b_rank), usum_slot(S->usum_slot),
+          walk_rank(S->walk_rank), cnt_rank(S->cnt_rank), deg_slot(S->deg_slot), fx_rank(S->fx_rank), fx_bounds(S->fx_bounds) {}
 };
 
 // Which users does rank k emit lists for?  By default the work-balanced slot range of fy_prep (the rank scores its
@@ -1037,11 +1082,32 @@ fy_rm2_job* fy::rm2_prepare(Context* ctx, const fy_rm2_params* prm, const fy_rat
                             const int32_t* map_cluster, const int32_t* cluster_count) {
     validate_params(prm);
     if (n_map < 0 || (n_map > 0 && (!map_user || !map_cluster))) FY_FAIL(FY_ERR_INVALID_ARGUMENT, "clustering map is NULL");
-    std::unique_ptr<fy_rm2_job> J(new fy_rm2_job);
-    J->ctx = ctx;
-    J->prm = *prm;
     EventTimer tm(ctx);
     const size_t span = tm.begin();
+    const bool use_cache = !(prm->flags & FY_RM2_NO_CACHE);
+    if (use_cache && R->rm2_cache) {
+        std::shared_ptr<RM2Static> have = std::static_pointer_cast<RM2Static>(R->rm2_cache);
+        if (have->matches(prm, n_map, map_user, map_cluster, cluster_count)) {      // warm: same ratings, same clustering, same share
+            std::unique_ptr<fy_rm2_job> J(new fy_rm2_job(have));
+            J->ctx = ctx;
+            J->prm = *prm;
+            J->from_cache = true;
+            tm.end(span);
+            sync(ctx);
+            J->ms_prepare = tm.total_ms();
+            return J.release();
+        }
+    }
+    std::shared_ptr<RM2Static> fresh = std::make_shared<RM2Static>();
+    fresh->K = prm->number_of_clusters;
+    fresh->rank = prm->rank;
+    fresh->world = prm->world;
+    fresh->has_count = cluster_count != nullptr;
+    if (n_map) { fresh->map_user.assign(map_user, map_user + n_map); fresh->map_cluster.assign(map_cluster, map_cluster + n_map); }
+    if (cluster_count) fresh->cluster_count.assign(cluster_count, cluster_count + prm->number_of_clusters);
+    std::unique_ptr<fy_rm2_job> J(new fy_rm2_job(fresh));
+    J->ctx = ctx;
+    J->prm = *prm;
     build_structure(ctx, R, prm->number_of_clusters, n_map, map_user, map_cluster, cluster_count, false, J->P);
     Prepared& P = J->P;
     rank_slot_range(P, prm->rank, prm->world, J->slot_lo, J->slot_hi);
@@ -1082,11 +1148,13 @@ fy_rm2_job* fy::rm2_prepare(Context* ctx, const fy_rm2_params* prm, const fy_rat
         tm.end(span);
         sync(ctx);
         J->ms_prepare = tm.total_ms();
+        if (use_cache) R->rm2_cache = fresh;
         return J.release();
     }
     tm.end(span);
     sync(ctx);
     J->ms_prepare = tm.total_ms();
+    if (use_cache) R->rm2_cache = fresh;
     return J.release();
 }
 
@@ -1122,6 +1190,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
     R->st.n_users = P.nU;
     R->st.n_items = P.nI;
     R->st.ms_prepare = J->ms_prepare;
+    R->st.prepared_from_cache = J->from_cache ? 1 : 0;
     EventTimer t_total(ctx), t_cooc(ctx), t_score(ctx), t_topn(ctx), t_tables(ctx), t_mirror(ctx);
     const size_t span_total = t_total.begin();
     size_t span_tables = t_tables.begin();
@@ -1151,13 +1220,23 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
     k_pair_p<<<grid_for(nP), 256, 0, st>>>(nP, P.rank_pair.get(), P.pair_di.get(), R->d_icoll.get(), lambda, b_rank.get(), p_rank.get(), a_rank.get(),
                                            b_rank32.get());
     FY_KERNEL_CHECK();
-    DevBuf<float> csc_x(ctx, P.nnz), csr_x(ctx, P.nnz), csr_e(ctx, P.nnz), csr_q(ctx, P.nnz);
+    DevBuf<float> csr_x(ctx, P.nnz), csr_e(ctx, P.nnz), csr_q(ctx, P.nnz);
     const bool use_pk = tune.cooc_pk && P.ratings_fp16_exact;   // packed CSR for the row kernel
-    DevBuf<float> csc_x_over_s(ctx, use_pk ? (size_t)P.nnz : 1);
-    DevBuf<uint32_t> csr_pk(ctx, use_pk ? (size_t)P.nnz : 1);
-    k_csc_x<<<grid_for(P.nnz), 256, 0, st>>>(P.nnz, P.csc_slot.get(), P.csc_r.get(), J->usum_slot.get(), csc_x.get(),
-                                             use_pk ? csc_x_over_s.get() : nullptr);
-    FY_KERNEL_CHECK();
+    // the row kernel's tables live with the static part of the job (TableCache): a warm job finds them built
+    TableCache& tc = J->S->tables;
+    DevBuf<float>&csc_x = tc.csc_x, &csc_x_over_s = tc.csc_x_over_s;
+    DevBuf<uint32_t>&csr_pk = tc.csr_pk, &y_pk = tc.y_pk;
+    DevBuf<int32_t>& csc_rank = tc.csc_rank;
+    std::vector<SegTable>&segs = tc.segs, &segs_tail = tc.segs_tail;
+    if (!tc.have_x || csc_x.size() != (size_t)P.nnz || csc_x_over_s.size() != (use_pk ? (size_t)P.nnz : 1)) {
+        tc.valid = tc.have_x = false;
+        csc_x.alloc(ctx, P.nnz);
+        csc_x_over_s.alloc(ctx, use_pk ? (size_t)P.nnz : 1);
+        k_csc_x<<<grid_for(P.nnz), 256, 0, st>>>(P.nnz, P.csc_slot.get(), P.csc_r.get(), J->usum_slot.get(), csc_x.get(),
+                                                 use_pk ? csc_x_over_s.get() : nullptr);
+        FY_KERNEL_CHECK();
+        tc.have_x = true;
+    }
     // packed (24-bit) matrix rows only where bandwidth matters: small clusters keep exact fp32 rows (their scores are small, and the
     // reference's own fixture is asserted with an ABSOLUTE 1e-4, T/util/HadoopIntegrationTest.java:53).  A packed cluster's matrix is
     // scaled by 2^-c so that every entry is < 1 (FY_P24_SHIFT): G[j][i] = w2 sum_v (r_vj / s_v^2) r_vi <= w2 * (largest column sum
@@ -1413,19 +1492,38 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
         prune_counters.zero();
         int64_t prune_blocks_total = 0, prune_seed_terms_cols = 0, coop_survived = 0, fallback_survived = 0;
         for (auto& p : plans) any_coop = any_coop || p.coop;
-        // segment tables of the row kernel, one per cluster, built on the main stream before the lanes fork
-        std::vector<SegTable> segs(plans.size()), segs_tail(plans.size());
-        bool any_tail = false;
-        for (auto& p : plans) any_tail = any_tail || p.p_eff < p.Ic;
-        DevBuf<uint32_t> y_pk(ctx, any_tail ? (size_t)P.nnz : 1);     // k_tail_blocks
-        span_tables = t_tables.begin();
+        // segment tables of the row kernel, one per cluster (built on the main stream before the lanes fork, or by the lanes): kept
+        // with the job's static part -- a job over the same ratings, clustering and launch plan re-uses them
+        bool any_tail = false, any_half = false;
         size_t co_all = 1;
-        bool any_half = false;
-        for (auto& p : plans) { co_all = std::max(co_all, (size_t)p.Uc * (p.nch + 1)); any_half = any_half || p.half || p.p_eff < p.Ic; }
-        DevBuf<int32_t> csc_rank(ctx, any_half ? (size_t)P.nnz : 1);     // row (rank inside its cluster) of every CSC entry
-        if (any_half) {
-            k_csc_rank<<<grid_for(P.nnz), 256, 0, st>>>(P.nnz, P.csc_pair.get(), P.pair_rank.get(), csc_rank.get());
-            FY_KERNEL_CHECK();
+        for (auto& p : plans) {
+            any_tail = any_tail || p.p_eff < p.Ic;
+            co_all = std::max(co_all, (size_t)p.Uc * (p.nch + 1));
+            any_half = any_half || p.half || p.p_eff < p.Ic;
+        }
+        std::vector<int32_t> sig;
+        sig.push_back(use_pk ? 1 : 0);
+        sig.push_back(NS > 1 && !any_coop && tune.bounded_tables ? 1 : 0);
+        for (auto& p : plans) {
+            const int32_t v[8] = {p.c, p.CH, p.nch, p.half ? 1 : 0, p.panel ? 1 : 0, p.p_eff, p.tail_chunks, p.coop ? 1 : 0};
+            sig.insert(sig.end(), v, v + 8);
+        }
+        const bool tables_cached = tc.valid && tc.sig == sig;
+        R->st.tables_from_cache = tables_cached ? 1 : 0;
+        span_tables = t_tables.begin();
+        if (!tables_cached) {
+            tc.valid = false;
+            segs.clear();
+            segs_tail.clear();
+            segs.resize(plans.size());
+            segs_tail.resize(plans.size());
+            csr_pk.alloc(ctx, use_pk ? (size_t)P.nnz : 1);
+            y_pk.alloc(ctx, any_tail ? (size_t)P.nnz : 1);     // k_tail_blocks
+            csc_rank.alloc(ctx, any_half ? (size_t)P.nnz : 1);     // row (rank inside its cluster) of every CSC entry
+            if (any_half) {
+                k_csc_rank<<<grid_for(P.nnz), 256, 0, st>>>(P.nnz, P.csc_pair.get(), P.pair_rank.get(), csc_rank.get());
+                FY_KERNEL_CHECK();
+            }
         }
         // first / last CSR entry of every planned cluster (slots are cluster-major): one round trip for all of them
         std::vector<int32_t> csr_range(2 * plans.size() + 2, 0);
@@ -1438,6 +1536,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
         // one-chunk table over the block-compressed CSR in panel mode).  `co` = scratch for p.Uc * (p.nch + 1) offsets.
         const bool bounded_tables = NS > 1 && !any_coop && tune.bounded_tables;     // (= lazy_tables below)
         auto build_tables = [&](size_t pi, hipStream_t ts, int32_t* co) {
+            if (tables_cached) return;
             const Plan& p = plans[pi];
             const int32_t f0 = csr_range[2 * pi], f1 = csr_range[2 * pi + 1];
             if (use_pk && f1 > f0) {
@@ -1750,6 +1849,8 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             unsigned long long hc[5];
             d2h(ctx, hc, prune_counters.get(), 5);
             sync(ctx);
+            tc.sig = sig;          // every table of the plan has been built and used: a later job with the same plan re-uses them
+            tc.valid = true;
             R->st.topn_select_users = (int64_t)hc[2];
             R->st.stray_blocks = (int64_t)hc[3];
             R->st.bound_repairs = (int64_t)hc[4];

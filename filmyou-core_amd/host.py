@@ -278,11 +278,13 @@ class RM2Job:
                                  conf.getInt("filterUsers", 0), n_clusters, int(rank), int(world), 0,
                                  int(workspace_bytes))
 
-    def prepare(self, ratings, clustering=None, clustering_count=None, rank=0, world=1, workspace_bytes=0):
+    def prepare(self, ratings, clustering=None, clustering_count=None, rank=0, world=1, workspace_bytes=0, cache=True):
         """Stage 1 (jobs RM2-1 / RM2-2 up to the exchange).  Returns a PreparedRM2 holding this rank's partial item
         statistics in HBM; see RM2Job.run for the arguments."""
         lib = _native.load()
         p = self._params(rank, world, workspace_bytes)
+        if not cache:
+            p.flags |= 1            # FY_RM2_NO_CACHE
         ctx = self.ctx or Context(0)
         self.ctx = ctx
         own_ratings = not isinstance(ratings, Ratings)
@@ -309,7 +311,7 @@ class RM2Job:
                 r.close()
 
     def run(self, ratings, clustering=None, clustering_count=None, rank=0, world=1, exchange=None,
-            workspace_bytes=0, collectives=None):
+            workspace_bytes=0, collectives=None, cache=True):
         """ratings: a ``Ratings`` or a (user, item, score) triple of arrays.
         clustering: (users, clusters) arrays = the reference's `clustering` file; None routes everyone to cluster 0.
         clustering_count: array of numberOfClusters sizes = the `clusteringCount` file (validated when given).
@@ -320,10 +322,13 @@ class RM2Job:
             all ranks are scored cooperatively (every rank builds 1/world of the co-rating matrix);
           exchange(device_ptr, length) -> device_ptr of world*length doubles: only the all-gather of the per-item
             statistics (parallel.StatsExchange); every rank then builds the whole matrix of the clusters it holds users of.
+        cache: a ``Ratings`` object keeps what the job built from the ratings and the clustering alone (CSR / CSC, per-item
+          statistics, the row kernel's tables); a later job over the same object and the same clustering starts from it
+          (stats["prepared_from_cache"]).  cache=False = FY_RM2_NO_CACHE: build everything, keep nothing (the cold job).
         Raises RuntimeError("RM2 failed!: ...") on any failure, like RM2Job.java:144-147."""
         if world > 1 and exchange is None and collectives is None:
             raise ValueError("world > 1 needs collectives (or at least an exchange for the item statistics)")
-        prepared = self.prepare(ratings, clustering, clustering_count, rank, world, workspace_bytes)
+        prepared = self.prepare(ratings, clustering, clustering_count, rank, world, workspace_bytes, cache=cache)
         try:
             if collectives is not None:
                 prepared.set_collectives(collectives)

@@ -90,9 +90,15 @@ typedef struct {
     int32_t number_of_clusters;         /* "numberOfClusters" */
     int32_t rank;                       /* this process scores user shard `rank` of `world` (1 GPU: 0 of 1) */
     int32_t world;
-    uint32_t flags;                     /* reserved, 0 */
+    uint32_t flags;                     /* FY_RM2_* below, 0 = defaults */
     int64_t workspace_bytes;            /* cap for the per-batch score scratch in HBM; 0 = default (16 GiB) */
 } fy_rm2_params;
+
+/* flags: by default a job keeps what it built from the ratings and the clustering alone (CSR / CSC, per-item statistics, the row
+ * kernel's tables) on the fy_ratings object, and a later job over the same ratings AND the same clustering (and rank / world)
+ * starts from it -- fy_stats::prepared_from_cache / tables_from_cache.  The reference has no such state: every RM2Job.run re-reads
+ * and re-shuffles the ratings (RM2Job.java:130-258).  FY_RM2_NO_CACHE: build everything in this job, keep nothing (the "cold" job). */
+#define FY_RM2_NO_CACHE 1u
 
 /* Stage 1 (jobs RM2-1/RM2-2 up to the exchange): score > 0 filter, CSR/CSC in HBM, cluster routing, user sums,
  * and this rank's PARTIAL per-item rating sums + partial floor-sum total.
@@ -249,6 +255,8 @@ typedef struct {
     int64_t bound_repairs;       /* panel mode: 64-column sub-blocks dropped by the second bound (without the user's own co-ratings) */
     int64_t isim_candidates;     /* item similarity, symmetric build: candidates the band sweep appended to the rows' lists (of I^2 / 2 elements x 2 rows) */
     int64_t isim_redone_rows;    /* ... rows whose list overflowed and were redone exactly from the matrix */
+    int64_t prepared_from_cache; /* RM2: 1 = fy_rm2_prepare found its structures on the fy_ratings object (same clustering): nothing was sorted */
+    int64_t tables_from_cache;   /* RM2: 1 = the row kernel's tables (packed CSR, segment tables) were re-used */
 } fy_stats;
 int fy_result_stats(fy_result*, fy_stats* out);
 

@@ -297,3 +297,47 @@ def test_two_ranks_from_the_references_file_layout(tmp_path, rm_golden):
     with pytest.raises(RuntimeError, match="RM2 failed!: output directory .* already exists"):
         P.RM2Job(conf_for(), ctx).run_from_files()
     ctx.close()
+
+
+def test_warm_jobs_reuse_the_static_structures_and_give_identical_rows():
+    """A Ratings object keeps what a job built from the ratings and the clustering alone (fy_rm2.hip: RM2Static / TableCache).  Warm
+    jobs -- also with another lambda and list length, which none of that depends on -- must give bit-identical rows to cold jobs
+    (cache=False = FY_RM2_NO_CACHE), and another clustering must not hit the cache."""
+    P, S = pkg(), synth()
+    u, i, s, facts = S.generate("ml100k", seed_offset=9)
+    u, i, s = u.numpy(), i.numpy(), (np.round(s.numpy() * 2) / 2).astype(np.float32)
+    uu = np.unique(u)
+    ctx = P.Context(0)
+    ratings = P.Ratings(ctx, u, i, s)
+
+    def run(lam, top_n, K, cache, seed=0):
+        conf = P.Configuration()
+        conf.set("lambda", repr(lam))
+        conf.setInt("numberOfItems", facts["n_items"])
+        conf.setInt("numberOfClusters", K)
+        conf.setInt("numberOfRecommendations", top_n)
+        clustering = (uu, ((S.hash_clustering(uu, K) + seed) % K).astype(np.int32)) if K > 1 else None
+        rec = P.RM2Job(conf, ctx).run(ratings, clustering=clustering, cache=cache)
+        rows, st = rec.rows(), dict(rec.stats)
+        rec.close()
+        return rows, st
+
+    same = lambda a, b: all(np.array_equal(a[k], b[k]) for k in ("user", "item", "score", "cluster"))
+    for K in (1, 4):
+        cold, st0 = run(0.1, 20, K, False)
+        assert st0["prepared_from_cache"] == 0 and st0["tables_from_cache"] == 0
+        first, st1 = run(0.1, 20, K, True)                   # builds and keeps
+        assert st1["prepared_from_cache"] == 0 and st1["tables_from_cache"] == 0
+        warm, st2 = run(0.1, 20, K, True)
+        assert st2["prepared_from_cache"] == 1 and st2["tables_from_cache"] == 1
+        assert same(cold, first) and same(cold, warm)
+        other, st3 = run(0.4, 35, K, True)                   # lambda and N do not enter the cached structures
+        assert st3["prepared_from_cache"] == 1
+        cold_other, _ = run(0.4, 35, K, False)
+        assert same(other, cold_other)
+    moved, st4 = run(0.1, 20, 4, True, seed=1)               # another clustering: rebuilt
+    assert st4["prepared_from_cache"] == 0
+    cold_moved, _ = run(0.1, 20, 4, False, seed=1)
+    assert same(moved, cold_moved)
+    ratings.close()
+    ctx.close()
