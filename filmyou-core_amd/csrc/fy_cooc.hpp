@@ -361,6 +361,13 @@ struct SegTable {
     DevBuf<int32_t> ptr;   // nch * (nq + 1)
     DevBuf<int2> seg;
     DevBuf<float> w;
+    // a table that is a RANGE of the job's one table over all clusters (fy_rm2.hip: build_tables_all) owns nothing: views
+    const int32_t* v_ptr = nullptr;
+    const int2* v_seg = nullptr;
+    const float* v_w = nullptr;
+    const int32_t* ptr_() const { return v_ptr ? v_ptr : ptr.get(); }
+    const int2* seg_() const { return v_seg ? v_seg : seg.get(); }
+    const float* w_() const { return v_w ? v_w : w.get(); }
 };
 // half_row_of_entry != nullptr: symmetric walk (only the columns behind the entry's own row; fy_rm2.hip, struct Half)
 // only_rows_of_entry != nullptr: CSC entries of the rows in front of only_rows_from get no segments (tail-row launches)

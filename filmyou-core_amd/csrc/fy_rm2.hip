@@ -215,10 +215,14 @@ __global__ void k_csc_rank(int64_t nnz, const int32_t* __restrict__ csc_pair, co
 }
 
 // packed CSR of one cluster for the row kernel (fy_cooc.hpp): column index relative to its chunk | fp16 raw rating
-__global__ void k_pack_csr(int32_t f0, int32_t f1, int32_t CH, const int32_t* __restrict__ csr_idx, const float* __restrict__ csr_r,
-                           uint32_t* __restrict__ pk) {
+__device__ __forceinline__ void pack_csr_body(int32_t f0, int32_t f1, int32_t CH, const int32_t* __restrict__ csr_idx, const float* __restrict__ csr_r,
+                                              uint32_t* __restrict__ pk) {
     for (int64_t f = f0 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; f < f1; f += (int64_t)gridDim.x * blockDim.x)
         pk[f] = (uint32_t)(csr_idx[f] % CH) | ((uint32_t)__half_as_ushort(__float2half(csr_r[f])) << 16);
+}
+__global__ void k_pack_csr(int32_t f0, int32_t f1, int32_t CH, const int32_t* __restrict__ csr_idx, const float* __restrict__ csr_r,
+                           uint32_t* __restrict__ pk) {
+    pack_csr_body(f0, f1, CH, csr_idx, csr_r, pk);
 }
 
 // Column-panel mode, tail rows (rows >= p_eff, few raters each): their co-ratings with the columns behind p_eff are needed only
@@ -231,9 +235,9 @@ __global__ void k_pack_csr(int32_t f0, int32_t f1, int32_t CH, const int32_t* __
 // 8192-column chunk, and no matrix element behind the panel is ever formed.
 // The user's compressed entries are written in place of the first entries of its CSR range (y_pk is as long as the CSR),
 // co2[2 k] / co2[2 k + 1] = their range: the "chunk offsets" of a one-chunk segment table.
-__global__ __launch_bounds__(256) void k_tail_blocks(int32_t slot_base, int32_t n_slots, int32_t p_eff, const int32_t* __restrict__ rowptr,
-                                                     const int32_t* __restrict__ csr_idx, const float* __restrict__ csr_r, uint32_t* __restrict__ y_pk,
-                                                     int32_t* __restrict__ co2) {
+__device__ __forceinline__ void tail_blocks_body(int32_t slot_base, int32_t n_slots, int32_t p_eff, const int32_t* __restrict__ rowptr,
+                                                const int32_t* __restrict__ csr_idx, const float* __restrict__ csr_r, uint32_t* __restrict__ y_pk,
+                                                int32_t* __restrict__ co2) {
     // One workgroup per user: the entries behind p_eff are a suffix of the row (found by a binary search), its 64-entry pieces
     // are dealt to the four waves; a piece looks one entry back for the block of its predecessor and takes its output slots
     // from an LDS counter (the order of a user's compressed entries does not matter: the sums they enter are integer sums).
@@ -266,6 +270,11 @@ __global__ __launch_bounds__(256) void k_tail_blocks(int32_t slot_base, int32_t 
         if (threadIdx.x == 0) { co2[2 * k] = base; co2[2 * k + 1] = base + sh_count; }
         __syncthreads();     // sh_count is read before the next user resets it
     }
+}
+__global__ __launch_bounds__(256) void k_tail_blocks(int32_t slot_base, int32_t n_slots, int32_t p_eff, const int32_t* __restrict__ rowptr,
+                                                     const int32_t* __restrict__ csr_idx, const float* __restrict__ csr_r, uint32_t* __restrict__ y_pk,
+                                                     int32_t* __restrict__ co2) {
+    tail_blocks_body(slot_base, n_slots, p_eff, rowptr, csr_idx, csr_r, y_pk, co2);
 }
 
 // one wave per user row: x = r / s_u and e = (1-l)(b_j - x) + l (U_c - 1) p_j  (all fp64, rounded once)
@@ -333,8 +342,8 @@ __global__ void k_user_meta(int32_t lo, int32_t hi, const int32_t* __restrict__ 
 }
 
 // ================================================================ chunk offsets for the row kernel
-__global__ void k_chunk_offsets(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ csr_idx, int32_t slot_base,
-                                int32_t n_slots, int32_t CH, int32_t nch, int32_t* __restrict__ chunk_off) {
+__device__ __forceinline__ void chunk_offsets_body(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ csr_idx, int32_t slot_base,
+                                                   int32_t n_slots, int32_t CH, int32_t nch, int32_t* __restrict__ chunk_off) {
     const int64_t total = (int64_t)n_slots * (nch + 1);
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
         const int32_t v = (int32_t)(t / (nch + 1)), ch = (int32_t)(t % (nch + 1));
@@ -347,6 +356,10 @@ __global__ void k_chunk_offsets(const int32_t* __restrict__ rowptr, const int32_
         }
         chunk_off[t] = (ch == nch) ? b : lo;
     }
+}
+__global__ void k_chunk_offsets(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ csr_idx, int32_t slot_base,
+                                int32_t n_slots, int32_t CH, int32_t nch, int32_t* __restrict__ chunk_off) {
+    chunk_offsets_body(rowptr, csr_idx, slot_base, n_slots, CH, nch, chunk_off);
 }
 
 void build_chunk_offsets(Context* ctx, const int32_t* rowptr, const int32_t* csr_idx, int32_t slot_base, int32_t n_slots,
@@ -371,8 +384,8 @@ struct Half {
     const int32_t* __restrict__ only_rows;      // [q0 + q]: row of the entry; nullptr = all rows
     int32_t only_from;
 };
-__global__ void k_seg_counts(const int32_t* __restrict__ csc_slot, const int32_t* __restrict__ chunk_off, int32_t slot_base,
-                             int32_t q0, int32_t nq, int32_t nch, int32_t* __restrict__ cnt, Half H) {
+__device__ __forceinline__ void seg_counts_body(const int32_t* __restrict__ csc_slot, const int32_t* __restrict__ chunk_off, int32_t slot_base,
+                                                int32_t q0, int32_t nq, int32_t nch, int32_t* __restrict__ cnt, const Half& H) {
     // one thread per CSC entry: the rater's nch + 1 chunk offsets are one contiguous gather
     for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q <= nq; q += (int64_t)gridDim.x * blockDim.x) {
         const bool live = q < nq && !(H.only_rows && H.only_rows[q0 + q] < H.only_from);
@@ -402,14 +415,34 @@ __global__ void k_seg_counts(const int32_t* __restrict__ csc_slot, const int32_t
         }
     }
 }
+__global__ void k_seg_counts(const int32_t* __restrict__ csc_slot, const int32_t* __restrict__ chunk_off, int32_t slot_base,
+                             int32_t q0, int32_t nq, int32_t nch, int32_t* __restrict__ cnt, Half H) {
+    seg_counts_body(csc_slot, chunk_off, slot_base, q0, nq, nch, cnt, H);
+}
+// The tables of ALL clusters of a job in one pass (many clusters, the reference's regime): blockIdx.y = table.  A table's counts /
+// prefixes are a range of one array (cnt_off), so ONE scan numbers the segments of all tables and one fill writes them -- built
+// cluster by cluster the same 25 M CSC entries cost ~15 small launches and a host round trip per cluster: 20 ms at 50 clusters
+// against 4.6 ms for the one-cluster job.
+struct SegDesc {
+    int32_t slot_base, q0, nq, nch, CH, half, only_from, co_stride;
+    int64_t co_off, cnt_off;      // first entry of the table's chunk offsets / of its counts and prefixes
+    int32_t use_only_rows, pad;
+};
+__global__ void k_seg_counts_multi(const SegDesc* __restrict__ D, const int32_t* __restrict__ csc_slot, const int32_t* __restrict__ co_all,
+                                   int32_t* __restrict__ cnt_all, const int32_t* __restrict__ row_of_entry, const int32_t* __restrict__ csr_idx,
+                                   int32_t* __restrict__ start_all) {
+    const SegDesc d = D[blockIdx.y];
+    const Half H{d.half ? row_of_entry : nullptr, csr_idx, d.CH, start_all + d.q0, d.use_only_rows ? row_of_entry : nullptr, d.only_from};
+    seg_counts_body(csc_slot, co_all + d.co_off, d.slot_base, d.q0, d.nq, d.nch, cnt_all + d.cnt_off, H);
+}
 
 // One wave fills the segments of 64 consecutive CSC entries of one chunk cooperatively: the group's segments are
 // contiguous in the table (exclusive prefix `ptr`), lane l writes segment base + l, base + l + 64, ... after finding its
 // owner among the 64 entries with a binary search over shuffled prefix values -- every store of the 3 GB table is
 // coalesced (one thread per entry writing its own run of segments reached 1.1 TB/s).
-__global__ void k_seg_fill(const int32_t* __restrict__ csc_slot, const float* __restrict__ csc_w, const int32_t* __restrict__ chunk_off,
-                           int32_t slot_base, int32_t q0, int32_t nq, int32_t nch, const int32_t* __restrict__ ptr,
-                           int2* __restrict__ seg, float* __restrict__ seg_w, Half H) {
+__device__ __forceinline__ void seg_fill_body(const int32_t* __restrict__ csc_slot, const float* __restrict__ csc_w, const int32_t* __restrict__ chunk_off,
+                                              int32_t slot_base, int32_t q0, int32_t nq, int32_t nch, const int32_t* __restrict__ ptr,
+                                              int2* __restrict__ seg, float* __restrict__ seg_w, const Half& H) {
     const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
     const int64_t n_groups = ((int64_t)nq + 63) >> 6;
     const int64_t total_work = n_groups * nch;
@@ -459,6 +492,38 @@ __global__ void k_seg_fill(const int32_t* __restrict__ csc_slot, const float* __
     }
 }
 
+__global__ void k_seg_fill(const int32_t* __restrict__ csc_slot, const float* __restrict__ csc_w, const int32_t* __restrict__ chunk_off,
+                           int32_t slot_base, int32_t q0, int32_t nq, int32_t nch, const int32_t* __restrict__ ptr,
+                           int2* __restrict__ seg, float* __restrict__ seg_w, Half H) {
+    seg_fill_body(csc_slot, csc_w, chunk_off, slot_base, q0, nq, nch, ptr, seg, seg_w, H);
+}
+__global__ void k_seg_fill_multi(const SegDesc* __restrict__ D, const int32_t* __restrict__ csc_slot, const float* __restrict__ csc_w,
+                                 const int32_t* __restrict__ co_all, const int32_t* __restrict__ ptr_all, int2* __restrict__ seg, float* __restrict__ seg_w,
+                                 const int32_t* __restrict__ row_of_entry, const int32_t* __restrict__ csr_idx, int32_t* __restrict__ start_all) {
+    const SegDesc d = D[blockIdx.y];
+    const Half H{d.half ? row_of_entry : nullptr, csr_idx, d.CH, start_all + d.q0, d.use_only_rows ? row_of_entry : nullptr, d.only_from};
+    seg_fill_body(csc_slot, csc_w, co_all + d.co_off, d.slot_base, d.q0, d.nq, d.nch, ptr_all + d.cnt_off, seg, seg_w, H);
+}
+// chunk offsets / packed CSR / block-compressed tail CSR of all planned clusters: blockIdx.y = cluster of the plan
+struct CoDesc {
+    int32_t slot_base, n_slots, CH, nch, f0, f1, p_eff, has_tail;
+    int64_t co_off, co_tail_off;
+};
+__global__ void k_chunk_offsets_multi(const CoDesc* __restrict__ D, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ csr_idx,
+                                      int32_t* __restrict__ co_all) {
+    const CoDesc d = D[blockIdx.y];
+    chunk_offsets_body(rowptr, csr_idx, d.slot_base, d.n_slots, d.CH, d.nch, co_all + d.co_off);
+}
+__global__ void k_pack_csr_multi(const CoDesc* __restrict__ D, const int32_t* __restrict__ csr_idx, const float* __restrict__ csr_r, uint32_t* __restrict__ pk) {
+    const CoDesc d = D[blockIdx.y];
+    pack_csr_body(d.f0, d.f1, d.CH, csr_idx, csr_r, pk);
+}
+__global__ __launch_bounds__(256) void k_tail_blocks_multi(const CoDesc* __restrict__ D, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ csr_idx,
+                                                           const float* __restrict__ csr_r, uint32_t* __restrict__ y_pk, int32_t* __restrict__ co_tail_all) {
+    const CoDesc d = D[blockIdx.y];
+    if (!d.has_tail) return;       // block-uniform
+    tail_blocks_body(d.slot_base, d.n_slots, d.p_eff, rowptr, csr_idx, csr_r, y_pk, co_tail_all + d.co_tail_off);
+}
 void build_segments(Context* ctx, const int32_t* csc_slot, const float* csc_w, const int32_t* chunk_off, int32_t slot_base,
                     int32_t q0, int32_t nq, int32_t nch, SegTable& out, hipStream_t st, const int32_t* half_row_of_entry,
                     const int32_t* csr_idx, int32_t CH, const int32_t* only_rows_of_entry, int32_t only_rows_from, int64_t max_segments) {
@@ -875,6 +940,10 @@ struct TableCache {
     DevBuf<uint32_t> csr_pk, y_pk;      // packed CSR (chunk-relative columns), block-compressed CSR of the tail rows
     DevBuf<int32_t> csc_rank;
     std::vector<SegTable> segs, segs_tail;
+    // many clusters: ONE table over all of them (build_tables_all); segs / segs_tail are then views into these
+    DevBuf<int32_t> g_co, g_co_tail, g_cnt, g_ptr, g_start;
+    DevBuf<int2> g_seg;
+    DevBuf<float> g_w;
 };
 struct RM2Static {
     // key
@@ -1076,6 +1145,114 @@ static void validate_params(const fy_rm2_params* p) {
     if (!(p->lambda >= 0.0 && p->lambda <= 1.0)) FY_FAIL(FY_ERR_INVALID_ARGUMENT, "lambda must be in [0, 1]");
     if (p->world <= 0 || p->rank < 0 || p->rank >= p->world) FY_FAIL(FY_ERR_INVALID_ARGUMENT, "rank %d of world %d", p->rank, p->world);
     if (p->number_of_recommendations < 0) FY_FAIL(FY_ERR_INVALID_ARGUMENT, "numberOfRecommendations must be >= 0");
+}
+
+// The row kernel's tables of ALL planned clusters in one pass over the CSR / CSC (no cooperative cluster among them): packed CSR,
+// chunk offsets, the tail rows' block-compressed CSR, and both segment tables (main walk; tail-row bounds) of every cluster as
+// ranges of ONE table -- one count launch, ONE scan, one host round trip for the size, one fill.  tc.segs / tc.segs_tail become views.
+static void build_tables_all(Context* ctx, const Prepared& P, const std::vector<Plan>& plans, const std::vector<int32_t>& csr_range, bool use_pk,
+                             TableCache& tc, hipStream_t st) {
+    const size_t np = plans.size();
+    std::vector<CoDesc> hco(np);
+    std::vector<SegDesc> hsd;
+    std::vector<int64_t> main_of(np, -1), tail_of(np, -1);
+    int64_t co_total = 0, co_tail_total = 0, cnt_total = 0;
+    int32_t max_slots = 1, max_f = 1, max_nq = 1;
+    for (size_t pi = 0; pi < np; pi++) {
+        const Plan& p = plans[pi];
+        const bool tail = p.p_eff < p.Ic;
+        hco[pi] = CoDesc{p.sbase, p.Uc, p.CH, p.nch, csr_range[2 * pi], csr_range[2 * pi + 1], p.p_eff, tail ? 1 : 0, co_total, co_tail_total};
+        SegDesc m{p.sbase, p.q0, p.nq, p.nch, p.CH, p.half ? 1 : 0, 0, p.nch + 1, co_total, cnt_total, 0, 0};
+        main_of[pi] = (int64_t)hsd.size();
+        hsd.push_back(m);
+        cnt_total += (int64_t)p.nch * ((int64_t)p.nq + 1);
+        co_total += (int64_t)p.Uc * (p.nch + 1);
+        max_slots = std::max(max_slots, p.Uc);
+        max_f = std::max(max_f, csr_range[2 * pi + 1] - csr_range[2 * pi]);
+        max_nq = std::max(max_nq, p.nq);
+    }
+    for (size_t pi = 0; pi < np; pi++) {      // the tail tables behind the main ones (their chunk offsets are the k_tail_blocks ranges)
+        const Plan& p = plans[pi];
+        if (p.p_eff >= p.Ic) continue;
+        SegDesc t{p.sbase, p.q0, p.nq, 1, 0, 0, p.p_eff, 2, hco[pi].co_tail_off, cnt_total, 1, 0};
+        tail_of[pi] = (int64_t)hsd.size();
+        hsd.push_back(t);
+        cnt_total += (int64_t)p.nq + 1;
+    }
+    for (size_t pi = 0; pi < np; pi++)
+        if (plans[pi].p_eff < plans[pi].Ic) { /* co_tail offsets were assigned above in plan order */ }
+    // (co_tail_off: two entries per slot of every plan with tail rows, in plan order)
+    {
+        int64_t off = 0;
+        for (size_t pi = 0; pi < np; pi++) {
+            hco[pi].co_tail_off = off;
+            if (plans[pi].p_eff < plans[pi].Ic) off += 2 * (int64_t)plans[pi].Uc;
+        }
+        co_tail_total = off;
+        for (size_t pi = 0; pi < np; pi++)
+            if (tail_of[pi] >= 0) hsd[(size_t)tail_of[pi]].co_off = hco[pi].co_tail_off;
+    }
+    if (cnt_total + 1 >= (int64_t)0x7FFFFFF0) FY_FAIL(FY_ERR_UNSUPPORTED, "segment tables of %zu clusters need %lld prefix entries (limit 2^31)", np, (long long)cnt_total);
+    DevBuf<CoDesc> d_co(ctx, np);
+    DevBuf<SegDesc> d_sd(ctx, hsd.size());
+    FY_HIP(hipMemcpyAsync(d_co.get(), hco.data(), np * sizeof(CoDesc), hipMemcpyHostToDevice, st));
+    FY_HIP(hipMemcpyAsync(d_sd.get(), hsd.data(), hsd.size() * sizeof(SegDesc), hipMemcpyHostToDevice, st));
+    tc.g_co.alloc(ctx, (size_t)std::max<int64_t>(1, co_total));
+    tc.g_co_tail.alloc(ctx, (size_t)std::max<int64_t>(1, co_tail_total));
+    tc.g_cnt.alloc(ctx, (size_t)cnt_total + 1);
+    tc.g_ptr.alloc(ctx, (size_t)cnt_total + 1);
+    tc.g_start.alloc(ctx, (size_t)P.nnz + 1);
+    const dim3 g_slots((unsigned)grid_for((int64_t)max_slots * 8, 256, 1024), (unsigned)np);
+    if (use_pk) {
+        k_pack_csr_multi<<<dim3((unsigned)grid_for(max_f, 256, 1024), (unsigned)np), 256, 0, st>>>(d_co.get(), P.csr_idx.get(), P.csr_r.get(), tc.csr_pk.get());
+        FY_KERNEL_CHECK();
+    }
+    k_chunk_offsets_multi<<<g_slots, 256, 0, st>>>(d_co.get(), P.rowptr.get(), P.csr_idx.get(), tc.g_co.get());
+    FY_KERNEL_CHECK();
+    if (co_tail_total > 0) {
+        k_tail_blocks_multi<<<dim3((unsigned)std::min<int>(max_slots, ctx->num_cus * 4), (unsigned)np), 256, 0, st>>>(d_co.get(), P.rowptr.get(), P.csr_idx.get(), P.csr_r.get(),
+                                                                                                                  tc.y_pk.get(), tc.g_co_tail.get());
+        FY_KERNEL_CHECK();
+    }
+    // main tables read g_co, tail tables g_co_tail: two launches of the count / fill kernels (the offsets are relative to either array)
+    const unsigned n_main = (unsigned)np, n_tail = (unsigned)(hsd.size() - np);
+    const dim3 g_q((unsigned)grid_for((int64_t)max_nq + 1, 256, 2048), n_main), g_qt((unsigned)grid_for((int64_t)max_nq + 1, 256, 2048), std::max(1u, n_tail));
+    k_seg_counts_multi<<<g_q, 256, 0, st>>>(d_sd.get(), P.csc_slot.get(), tc.g_co.get(), tc.g_cnt.get(), tc.csc_rank.get(), P.csr_idx.get(), tc.g_start.get());
+    FY_KERNEL_CHECK();
+    if (n_tail) {
+        k_seg_counts_multi<<<g_qt, 256, 0, st>>>(d_sd.get() + np, P.csc_slot.get(), tc.g_co_tail.get(), tc.g_cnt.get(), tc.csc_rank.get(), P.csr_idx.get(), tc.g_start.get());
+        FY_KERNEL_CHECK();
+    }
+    FY_HIP(hipMemsetAsync(tc.g_cnt.get() + cnt_total, 0, sizeof(int32_t), st));
+    exclusive_scan_i32(ctx, tc.g_cnt.get(), tc.g_ptr.get(), (size_t)cnt_total + 1, st);
+    int32_t total = 0;
+    FY_HIP(hipMemcpyAsync(&total, tc.g_ptr.get() + cnt_total, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    FY_HIP(hipStreamSynchronize(st));       // the ONE host round trip of the job's tables (d_co / d_sd's host copies are done too)
+    tc.g_seg.alloc(ctx, (size_t)std::max(1, total));
+    tc.g_w.alloc(ctx, (size_t)std::max(1, total));
+    const float* csc_w = use_pk ? tc.csc_x_over_s.get() : tc.csc_x.get();
+    const dim3 g_f((unsigned)grid_for((((int64_t)max_nq + 63) >> 6) * 64 * 4, 256, 4096), n_main), g_ft((unsigned)grid_for((((int64_t)max_nq + 63) >> 6) * 64, 256, 4096), std::max(1u, n_tail));
+    k_seg_fill_multi<<<g_f, 256, 0, st>>>(d_sd.get(), P.csc_slot.get(), csc_w, tc.g_co.get(), tc.g_ptr.get(), tc.g_seg.get(), tc.g_w.get(), tc.csc_rank.get(),
+                                          P.csr_idx.get(), tc.g_start.get());
+    FY_KERNEL_CHECK();
+    if (n_tail) {
+        k_seg_fill_multi<<<g_ft, 256, 0, st>>>(d_sd.get() + np, P.csc_slot.get(), tc.csc_x_over_s.get(), tc.g_co_tail.get(), tc.g_ptr.get(), tc.g_seg.get(), tc.g_w.get(),
+                                               tc.csc_rank.get(), P.csr_idx.get(), tc.g_start.get());
+        FY_KERNEL_CHECK();
+    }
+    FY_HIP(hipStreamSynchronize(st));       // d_co / d_sd go back to the allocator
+    for (size_t pi = 0; pi < np; pi++) {
+        SegTable& m = tc.segs[pi];
+        m.v_ptr = tc.g_ptr.get() + hsd[(size_t)main_of[pi]].cnt_off;
+        m.v_seg = tc.g_seg.get();
+        m.v_w = tc.g_w.get();
+        if (tail_of[pi] >= 0) {
+            SegTable& t = tc.segs_tail[pi];
+            t.v_ptr = tc.g_ptr.get() + hsd[(size_t)tail_of[pi]].cnt_off;
+            t.v_seg = tc.g_seg.get();
+            t.v_w = tc.g_w.get();
+        }
+    }
 }
 
 fy_rm2_job* fy::rm2_prepare(Context* ctx, const fy_rm2_params* prm, const fy_ratings* R, int64_t n_map, const int32_t* map_user,
@@ -1441,6 +1618,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                     gp_el = std::max(gp_el, (size_t)p.Ic * p.panel_cols * 3 / 4 + 4);
                     b64_el = std::max(b64_el, (size_t)p.Ic * p.ldb64 * 3 / 4 + 4);
                     a64_el = std::max(a64_el, (size_t)p.ldb64);
+
                     s_el = std::max(s_el, (size_t)(p.B * seed_cols));
                     ov_el = std::max(ov_el, (size_t)p.B);
                     ub_el = std::max(ub_el, (size_t)(p.B * p.ldb64));
@@ -1503,7 +1681,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
         }
         std::vector<int32_t> sig;
         sig.push_back(use_pk ? 1 : 0);
-        sig.push_back(NS > 1 && !any_coop && tune.bounded_tables ? 1 : 0);
+        sig.push_back(plans.size() > 1 && !any_coop ? 1 : 0);
         for (auto& p : plans) {
             const int32_t v[8] = {p.c, p.CH, p.nch, p.half ? 1 : 0, p.panel ? 1 : 0, p.p_eff, p.tail_chunks, p.coop ? 1 : 0};
             sig.insert(sig.end(), v, v + 8);
@@ -1534,7 +1712,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
         sync(ctx);
         // One cluster's tables: packed CSR with chunk-relative indices for its CH, chunk offsets, segment table (+ the tail rows'
         // one-chunk table over the block-compressed CSR in panel mode).  `co` = scratch for p.Uc * (p.nch + 1) offsets.
-        const bool bounded_tables = NS > 1 && !any_coop && tune.bounded_tables;     // (= lazy_tables below)
+        const bool bounded_tables = false;     // (round 2: tables sized by upper bounds inside the lanes; the lanes build no tables any more)
         auto build_tables = [&](size_t pi, hipStream_t ts, int32_t* co) {
             if (tables_cached) return;
             const Plan& p = plans[pi];
@@ -1562,10 +1740,17 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
         // With several lanes and no cooperative cluster the tables are built by the lane that uses them, right before the row
         // kernel: table building is mostly host round trips (sizes of the segment tables), 23 ms for 50 clusters during which the
         // chip idled; in a lane they hide behind the other lanes' kernels.  (A cooperative job packs every cluster's CSR up front.)
-        const bool lazy_tables = NS > 1 && !any_coop;
+        // Several clusters and none of them cooperative: ONE table over all of them, built here on the main stream (build_tables_all).
+        // (Round 2 let every lane build its cluster's tables right before the row kernel, to hide their host round trips behind the
+        // other lanes: 20 ms of tables at 50 clusters.)
+        const bool all_at_once = plans.size() > 1 && !any_coop;
+        const bool lazy_tables = false;
         std::vector<DevBuf<int32_t>> co_lane((size_t)NS);
-        for (auto& b : co_lane) b.alloc(ctx, co_all);
-        if (!lazy_tables)
+        if (!all_at_once)
+            for (auto& b : co_lane) b.alloc(ctx, co_all);
+        if (all_at_once) {
+            if (!tables_cached) build_tables_all(ctx, P, plans, csr_range, use_pk, tc, st);
+        } else if (!lazy_tables)
             for (size_t pi = 0; pi < plans.size(); pi++) build_tables(pi, st, co_lane[0].get());
         t_tables.end(span_tables);
         // Error path: anything thrown below (an allocation, a launch, a collective) unwinds the lanes' buffers, the segment
@@ -1610,7 +1795,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 t_tables.end(stb, ls);
             }
             // -- M build
-            CoocArgs CA{P.rank_pair.get(), P.pair_start.get(), segs[pi].ptr.get(), segs[pi].seg.get(), segs[pi].w.get(), P.csr_idx.get(),
+            CoocArgs CA{P.rank_pair.get(), P.pair_start.get(), segs[pi].ptr_(), segs[pi].seg_(), segs[pi].w_(), P.csr_idx.get(),
                         csr_x.get(), pbase, sbase, Ic, CH, nch, 0, Ic, p.q0, p.nq, nullptr, 0, use_pk ? csr_pk.get() : nullptr, nullptr,
                         (uint32_t)std::min<int64_t>((int64_t)P.nnz * 4, 0xFFFFFFFFll)};
             const int fxk = (use_pk && tune.cooc_fx && !J->fx_bounds.empty()) ? fx_exponent(&J->fx_bounds[3 * (size_t)c]) : -1;
@@ -1633,7 +1818,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             }
             const size_t sp = t_cooc.begin(ls);
             if (p.p_eff < Ic) {   // panel mode: bounds of the tail rows behind p_eff (one item per row, see k_tail_blocks)
-                CoocArgs CB{P.rank_pair.get(), P.pair_start.get(), segs_tail[pi].ptr.get(), segs_tail[pi].seg.get(), segs_tail[pi].w.get(), P.csr_idx.get(),
+                CoocArgs CB{P.rank_pair.get(), P.pair_start.get(), segs_tail[pi].ptr_(), segs_tail[pi].seg_(), segs_tail[pi].w_(), P.csr_idx.get(),
                             csr_x.get(), pbase, sbase, Ic, p.tail_width, 1, p.p_eff, Ic - p.p_eff, p.q0, p.nq, nullptr, 0, y_pk.get(), nullptr, CA.pk_bytes};
                 CB.fx_scale = CA.fx_scale;
                 MEpilogue MB{reinterpret_cast<float*>(reinterpret_cast<char*>(L.Bmax64.get()) + (size_t)(p.p_eff / 64) * 3), p.tail_width, ME.w2, ME.fx_inv, 1,
@@ -1724,6 +1909,10 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 // panel mode: the stored rows are panel_cols wide and the bound matrix has one column per 64-column sub-block
                 const float* Gmat = p.panel ? L.Gp.get() : L.M.get();
                 const int64_t gld = p.panel ? (int64_t)p.panel_cols : ldm;
+                // (A two-level bound -- 256-column block maxima first, the 64-column sub-block bounds only for the surviving blocks -- was
+                // built and measured in round 3: the first level reads a quarter of the bytes, but five times as many blocks reach the
+                // second level, whose per-(user, block) gathers of Bmax64 rows cost more than the streamed pass saved: 113 -> 129 ms at 50
+                // clusters.  Removed.)
                 const int64_t bld = p.panel ? p.ldb64 : p.ldb;           // pitch of the bound matrix, of UB and of the survivor lists
                 const int bchunks = (int)(bld / 256);
                 ScoreArgs SA = score_args(Gmat, gld, Ic, a_rank.get() + pbase, s0, nb, L.S.get(), SC, n_slices, seed_chunks + bchunks);
