@@ -135,20 +135,36 @@ __global__ __launch_bounds__(256) void k_score(const float* __restrict__ M_, con
     const float qnan = __builtin_nanf("");
     const int row_mul = A.row_mul ? A.row_mul : 1;
     // the log terms of the rows [beg, end) of one user's list, added to t / mask
+    // Batches of SB rows.  The (idx, e, q) triplets of a batch are fetched by THREE vector loads (lane l < SB holds row k + l) one
+    // batch ahead and handed out with v_readlane.  (Until round 3 they were wave-uniform loads: the compiler issued the SB index
+    // loads one at a time, each behind its own s_waitcnt lgkmcnt(0), and two more scalar loads per row for e and q in front of its
+    // logs -- 24 dependent scalar round trips per batch of 8 rows, which is what "bound by scalar-load latency" meant.)
+    // All SB row-segment loads are issued before the first use, also for a short tail (out-of-range slots re-load the last valid
+    // row -- an L1 hit -- and are skipped by a wave-uniform test).
     auto walk = [&](int beg, int end, double* t, unsigned& mask) __attribute__((always_inline)) {
-        // batches of 8 rows: all eight segment loads are issued before the first use, also for a short tail
-        // (out-of-range slots re-load the last valid row -- an L1 hit -- and are skipped by a wave-uniform test)
+        if (beg >= end) return;
+        static_assert(SB <= 64, "one lane per row of a batch");
+        const int sub = lane & (SB - 1);     // (SB is a power of two)
+        int vi, vi_n;
+        float ve, vq, ve_n, vq_n;
+        {
+            const int kk = min(beg + sub, end - 1);
+            vi = csr_idx_[kk]; ve = csr_e_[kk]; vq = csr_q_[kk];
+        }
         for (int k = beg; k < end; k += SB) {
             G g[SB];
             float e[SB], qq[SB];
             int jj[SB];
 #pragma unroll
             for (int q = 0; q < SB; q++) {
-                const int kk = min(k + q, end - 1);
-                jj[q] = csr_idx_[kk];
-                e[q] = csr_e_[kk];
-                qq[q] = csr_q_[kk];
+                jj[q] = __builtin_amdgcn_readlane(vi, q);
+                e[q] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ve), q));
+                qq[q] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(vq), q));
                 g[q] = *reinterpret_cast<const G*>(Mcol + (int64_t)jj[q] * pitch);
+            }
+            {   // the next batch's triplets (clamped: the last batch re-reads the list's last row)
+                const int kk = min(k + SB + sub, end - 1);
+                vi_n = csr_idx_[kk]; ve_n = csr_e_[kk]; vq_n = csr_q_[kk];
             }
             float p[VEC];
 #pragma unroll
@@ -171,6 +187,7 @@ __global__ __launch_bounds__(256) void k_score(const float* __restrict__ M_, con
             }
 #pragma unroll
             for (int v = 0; v < VEC; v++) t[v] += (double)p[v];
+            vi = vi_n; ve = ve_n; vq = vq_n;
         }
     };
     auto store = [&](int u, int slot, const double* t, unsigned mask) __attribute__((always_inline)) {
@@ -782,18 +799,29 @@ __global__ __launch_bounds__(256) void k_score_blocks(const float* __restrict__ 
         const int beg = min(row_end, row_beg + wave * quarter), end = min(row_end, beg + quarter);
         double t[4] = {0.0, 0.0, 0.0, 0.0};
         unsigned mask = 0;
+        // (idx, e, q) of a batch by three vector loads, one batch ahead, handed out with v_readlane: see k_score's walk
+        const int sub = lane & (SB - 1);
+        int vi = 0, vi_n;
+        float ve = 0.f, vq = 0.f, ve_n, vq_n;
+        if (beg < end) {
+            const int kk = min(beg + sub, end - 1);
+            vi = csr_idx_[kk]; ve = csr_e_[kk]; vq = csr_q_[kk];
+        }
         for (int k = beg; k < end; k += SB) {
             U3 g[SB];
             float e[SB], qq[SB];
             int jj[SB];
 #pragma unroll
             for (int x = 0; x < SB; x++) {
-                const int kk = min(k + x, end - 1);
-                jj[x] = csr_idx_[kk];
-                e[x] = csr_e_[kk];
-                qq[x] = csr_q_[kk];
+                jj[x] = __builtin_amdgcn_readlane(vi, x);
+                e[x] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ve), x));
+                qq[x] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(vq), x));
                 g[x] = U3{0u, 0u, 0u};
                 if (live) g[x] = *reinterpret_cast<const U3*>(Mcol + (int64_t)jj[x] * pitch);
+            }
+            {
+                const int kk = min(k + SB + sub, end - 1);
+                vi_n = csr_idx_[kk]; ve_n = csr_e_[kk]; vq_n = csr_q_[kk];
             }
             float p[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -809,6 +837,7 @@ __global__ __launch_bounds__(256) void k_score_blocks(const float* __restrict__ 
             }
 #pragma unroll
             for (int v = 0; v < 4; v++) t[v] += (double)p[v];
+            vi = vi_n; ve = ve_n; vq = vq_n;
         }
         if (wave > 0) {
 #pragma unroll
@@ -1373,17 +1402,28 @@ __global__ __launch_bounds__(256) void k_score_entries(const float* __restrict__
         const int beg = range_off_[slot - slot_base], end = range_off_[slot - slot_base + 1];
         double t[4] = {0.0, 0.0, 0.0, 0.0};
         unsigned mask = 0;
+        // (idx, e, q) of a batch by three vector loads, one batch ahead, handed out with v_readlane: see k_score's walk
+        const int sub = lane & (SB - 1);
+        int vi = 0, vi_n;
+        float ve = 0.f, vq = 0.f, ve_n, vq_n;
+        if (beg < end) {
+            const int kk = min(beg + sub, end - 1);
+            vi = csr_idx_[kk]; ve = csr_e_[kk]; vq = csr_q_[kk];
+        }
         for (int kk0 = beg; kk0 < end; kk0 += SB) {
             U3 g[SB];
             float e[SB], qq[SB];
             int jj[SB];
 #pragma unroll
             for (int x = 0; x < SB; x++) {
-                const int kk = min(kk0 + x, end - 1);
-                jj[x] = csr_idx_[kk];
-                e[x] = csr_e_[kk];
-                qq[x] = csr_q_[kk];
+                jj[x] = __builtin_amdgcn_readlane(vi, x);
+                e[x] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ve), x));
+                qq[x] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(vq), x));
                 g[x] = *reinterpret_cast<const U3*>(Mcol + (int64_t)jj[x] * pitch);
+            }
+            {
+                const int kk = min(kk0 + SB + sub, end - 1);
+                vi_n = csr_idx_[kk]; ve_n = csr_e_[kk]; vq_n = csr_q_[kk];
             }
             float p[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1399,6 +1439,7 @@ __global__ __launch_bounds__(256) void k_score_entries(const float* __restrict__
             }
 #pragma unroll
             for (int v = 0; v < 4; v++) t[v] += (double)p[v];
+            vi = vi_n; ve = ve_n; vq = vq_n;
         }
         const double base = pvpi_[slot - slot_base];
         float4 o;
