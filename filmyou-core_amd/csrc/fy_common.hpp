@@ -89,6 +89,7 @@ struct Tuning {
     int isim_gram_min_items = 4096;
     int isim_capg = 2040;              // candidates a row of the band sweep may collect before it is redone exactly (<= 2040: k_isim_finish sorts them in LDS)
     int isim_piece = 8192;             // columns per piece of the band sweep
+    int isim_acc32 = 1;                // 32-bit fixed-point accumulators in the symmetric build's walk when the products are exact integers
 };
 
 // ---------------------------------------------------------------- context

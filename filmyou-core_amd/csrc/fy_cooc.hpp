@@ -73,6 +73,7 @@ struct CoocArgs {
     // the columns stored linearly its four 32-byte-strided ds_read_b64 ran four ways bank-conflicted: SQ_LDS_BANK_CONFLICT was
     // 57 % of the LDS cycles of a 50-cluster job).  0 = linear (item-item similarity: its top-K epilogue walks single columns).
     int32_t acc_quarter;
+    int32_t acc32;       // 1: 32-bit fixed-point accumulators (the launch picks the instantiation)
 };
 __device__ __forceinline__ int cooc_acc_index(int c, int quarter) { return quarter ? (c & 3) * quarter + (c >> 2) : c; }
 
@@ -235,7 +236,12 @@ __device__ __forceinline__ void cooc_accumulate_pk(const CoocArgs& A, ACC* __res
 #pragma unroll
         for (int q = 0; q < NB; q++) {
             const float x = __half2float(__ushort_as_half((unsigned short)(G.pk[q] >> 16)));
-            if constexpr (std::is_same<ACC, unsigned long long>::value) {
+            if constexpr (std::is_same<ACC, uint32_t>::value) {
+                // 32-bit fixed point (item similarity on ratings that are multiples of 2^-m, fx_scale = 2^2m): every product is an
+                // integer below 2^24 -- exact in fp32 -- and every sum stays below 2^32 (fy_rm2.hip: gram_half_build): ds_add_u32
+                const uint32_t v = (uint32_t)(G.W[q] * x * (float)fx);
+                if (lane < G.L[q]) atomicAdd(&acc[cooc_acc_index((int)(G.pk[q] & 0xFFFFu), A.acc_quarter)], v);   // ds_add_u32
+            } else if constexpr (std::is_same<ACC, unsigned long long>::value) {
                 // round(p * 2^k) without a 64-bit conversion: p * 2^k + 2^52 has the integer in its mantissa (0 <= p * 2^k < 2^52)
                 const double d = fma((double)(G.W[q] * x), fx, 4503599627370496.0);
                 const unsigned long long v = (unsigned long long)__double_as_longlong(d) & 0xFFFFFFFFFFFFFull;

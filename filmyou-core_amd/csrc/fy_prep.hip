@@ -104,6 +104,7 @@ __global__ void k_user_item_keys(int64_t n, const int32_t* __restrict__ user, co
                                  uint64_t* __restrict__ keys, unsigned long long* __restrict__ kept, int* __restrict__ err) {
     unsigned long long local = 0;
     bool not_half = false, not_pos = false;
+    unsigned frac = 0;          // bit 8 + m: some kept rating needs m fractional bits (m = 9: more than eight)
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
         const float s = score[t];
         const bool keep = keep_nonpositive ? (s == s) : (s > 0.0f);   // NaN never passes "score > 0"
@@ -113,6 +114,12 @@ __global__ void k_user_item_keys(int64_t n, const int32_t* __restrict__ user, co
             if (u < 0 || i < 0) atomicOr(err, ERR_NEG_ID);
             if (__half2float(__float2half(s)) != s) not_half = true;
             if (!(s > 0.0f)) not_pos = true;
+            {
+                float t = fabsf(s);
+                int m = 0;
+                while (m < 9 && t != floorf(t)) { t *= 2.0f; m++; }
+                frac |= 1u << (8 + m);
+            }
             k = ((uint64_t)(uint32_t)u << ib) | (uint32_t)i;
             local++;
         }
@@ -123,6 +130,8 @@ __global__ void k_user_item_keys(int64_t n, const int32_t* __restrict__ user, co
     if ((threadIdx.x & 63) == 0 && local) atomicAdd(kept, local);
     if (__ballot(not_half) && (threadIdx.x & 63) == 0) atomicOr(err, NOTE_NOT_FP16);
     if (__ballot(not_pos) && (threadIdx.x & 63) == 0) atomicOr(err, NOTE_NONPOSITIVE);
+    for (int o = 32; o > 0; o >>= 1) frac |= (unsigned)__shfl_down((int)frac, o, 64);
+    if ((threadIdx.x & 63) == 0 && frac) atomicOr(err, (int)frac);
 }
 
 __global__ void k_heads_hi32(int64_t n, const uint64_t* __restrict__ keys, uint32_t* __restrict__ head, int check_dup,
@@ -385,6 +394,9 @@ void build_structure(Context* ctx, const fy_ratings* R, int32_t K, int64_t n_map
         if (flags & ERR_NEG_ID) FY_FAIL(FY_ERR_NEGATIVE_ID, "negative user or item id in the ratings");
         P.ratings_fp16_exact = !(flags & NOTE_NOT_FP16);
         P.ratings_positive = !(flags & NOTE_NONPOSITIVE);
+        P.ratings_frac_bits = 0;
+        for (int m = 0; m <= 9; m++)
+            if (flags & (1 << (8 + m))) P.ratings_frac_bits = m;
     }
     if (nnz == 0) {
         P.nU = P.nI = P.nP = 0;

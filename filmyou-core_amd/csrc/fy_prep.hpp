@@ -23,6 +23,7 @@ struct Prepared {
     int64_t sum_deg2 = 0;     // sum_u n_u^2
     std::vector<int64_t> cluster_deg2;   // [c]: sum of n_u^2 over the users of cluster c (host; upper bounds of the segment tables)
     bool ratings_fp16_exact = false;   // every kept rating is exactly representable in fp16 (enables the packed CSR of fy_cooc.hpp)
+    int ratings_frac_bits = 0;         // every kept rating is a multiple of 2^-this (half stars: 1; 9 = finer than 2^-8)
     bool ratings_positive = false;     // every kept rating is > 0 (always in RM2; the item-similarity job keeps ratings <= 0): the
                                        // fixed-point accumulators of the row kernel add unsigned contributions
     // users, dense (ascending raw id)

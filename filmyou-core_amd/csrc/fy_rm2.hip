@@ -617,7 +617,7 @@ __device__ __forceinline__ void cooc_rm2_epilogue(const CoocArgs& A, const MEpil
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 float f;                                      // columns >= Ic were never touched: 0
-                if constexpr (std::is_same<ACC, unsigned long long>::value) f = (float)((double)ap[q * qs] * E.fx_inv);
+                if constexpr (std::is_integral<ACC>::value) f = (float)((double)ap[q * qs] * E.fx_inv);
                 else f = E.w2 * (float)ap[q * qs];
                 ap[q * qs] = (ACC)0;
                 v[q] = (__float_as_uint(f) + radd) >> FY_P24_SHIFT;    // 0 <= f < 2: 7 exponent + 17 mantissa bits, round to nearest (or up)
@@ -677,7 +677,7 @@ __device__ __forceinline__ void cooc_rm2_epilogue(const CoocArgs& A, const MEpil
         float* __restrict__ out = E.M + (int64_t)mrow * E.ldm;
         for (int col = cb + threadIdx.x; col < c1; col += blockDim.x) {
             const int at = cooc_acc_index(col - c0, A.acc_quarter);
-            if constexpr (std::is_same<ACC, unsigned long long>::value) out[col] = (float)((double)acc[at] * E.fx_inv);
+            if constexpr (std::is_integral<ACC>::value) out[col] = (float)((double)acc[at] * E.fx_inv);
             else out[col] = E.w2 * (float)acc[at];
             acc[at] = (ACC)0;
         }
@@ -894,6 +894,7 @@ static void cooc_rm2_allow_lds() {
     FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cooc_rm2<false, float>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cooc_rm2<true, float>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cooc_rm2<true, unsigned long long>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cooc_rm2<true, uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cooc_rm2<true, unsigned long long, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
 }
 static void stray_allow_lds();
@@ -1034,13 +1035,16 @@ static void launch_cooc_rm2(Context* ctx, const ScoreTune& tune, bool use_pk, co
     if (n_items <= 0) return;
     CoocArgs CA = CA_;
     CA.acc_quarter = tune.cooc_planes ? cooc_lds_columns(CA.CH) / 4 : 0;
-    const size_t lds = (size_t)cooc_lds_columns(CA.CH) * (tune.cooc_f32 ? 4 : 8);
+    const bool acc32 = CA.acc32 && use_pk && CA.fx_scale > 0.0 && !tune.cooc_f32;
+    const size_t lds = (size_t)cooc_lds_columns(CA.CH) * ((tune.cooc_f32 || acc32) ? 4 : 8);
     const int by_lds = (int)std::max<size_t>(1, (160 * 1024 - 512) / (lds + 64));
     int block = tune.cooc_block;
     if (!block) block = by_lds >= 4 ? 256 : (by_lds >= 2 ? 512 : 1024);
     const int per_cu = std::max(1, std::min(by_lds, 2048 / block));
     const int grid = std::min(n_items, ctx->num_cus * per_cu);
-    if (use_pk && CA.fx_scale > 0.0 && !tune.cooc_f32) {
+    if (acc32) {
+        k_cooc_rm2<true, uint32_t><<<grid, block, lds, st>>>(CA, ME, n_items, counter);
+    } else if (use_pk && CA.fx_scale > 0.0 && !tune.cooc_f32) {
         if (ME.ceil24) k_cooc_rm2<true, unsigned long long, 1><<<grid, block, lds, st>>>(CA, ME, n_items, counter);
         else k_cooc_rm2<true, unsigned long long><<<grid, block, lds, st>>>(CA, ME, n_items, counter);
     } else if (!tune.cooc_f32) {
@@ -1065,10 +1069,18 @@ bool fy::gram_half_build(Context* ctx, const Prepared& P, const float* csc_w, co
     const ScoreTune tune = score_tune(ctx);
     const int32_t Ic = P.nP;
     if (P.K != 1 || !P.ratings_fp16_exact || !P.ratings_positive || Ic <= 0) return false;
-    const int fxk = fx_exponent(bounds3);
+    int fxk = fx_exponent(bounds3);
     if (fxk < 0) return false;
+    // Ratings that are multiples of 2^-m (half stars: m = 1): every product r r' 2^2m is an integer.  When the largest product
+    // stays below 2^24 and the largest possible sum below 2^32 the walk accumulates in 32 bits (ds_add_u32: 6.5 cycles per wave
+    // instruction at random addresses against 10.8 for ds_add_u64, profiles/r2/micro_lds_atomic_rate.txt) and a chunk holds
+    // twice the columns: two column chunks instead of three at ML-25M shape.  Exact, like the 64-bit sums.
+    const int m = P.ratings_frac_bits;
+    const bool acc32 = tune.isim_acc32 && m <= 4 && (double)bounds3[2] * bounds3[2] * std::ldexp(1.0, 2 * m) < 16777216.0 &&
+                       (double)bounds3[0] * bounds3[2] * std::ldexp(1.0, 2 * m) < 4294967296.0;
+    if (acc32) fxk = 2 * m;
     int32_t CH, nch;
-    pick_chunks(Ic, tune.cooc_max_ch, CH, nch);
+    pick_chunks(Ic, acc32 && !tune.cooc_max_ch_forced ? 2 * tune.cooc_max_ch : tune.cooc_max_ch, CH, nch);
     if (nch >= 256) return false;                      // (the item ids of the row kernel hold the chunk in 8 bits)
     hipStream_t st = ctx->stream;
     cooc_rm2_allow_lds();
@@ -1087,6 +1099,7 @@ bool fy::gram_half_build(Context* ctx, const Prepared& P, const float* csc_w, co
                 0, Ic, 0, (int32_t)P.nnz, nullptr, 0, csr_pk.get(), nullptr, (uint32_t)std::min<int64_t>((int64_t)P.nnz * 4, 0xFFFFFFFFll)};
     CA.half = 1;
     CA.fx_scale = std::ldexp(1.0, fxk);
+    CA.acc32 = acc32 ? 1 : 0;
     const int n_items = (int)cooc_item_count(Ic, CH, nch, true);
     DevBuf<int2> item_seg(ctx, (size_t)Ic * nch);
     DevBuf<int32_t> item_id(ctx, (size_t)Ic * nch), counter(ctx, 1);

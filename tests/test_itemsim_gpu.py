@@ -83,7 +83,8 @@ def test_synthetic_forced_paths(ctx, monkeypatch, env):
 
 SYMMETRIC = [{"FY_ISIM_GRAM": "1"},                                                        # one chunk of the walk, one piece per band
              {"FY_ISIM_GRAM": "1", "FY_COOC_MAX_CH": "256", "FY_ISIM_PIECE": "128"},      # several chunks, several pieces per band
-             {"FY_ISIM_GRAM": "1", "FY_ISIM_CAPG": "40"}]                                 # candidate lists overflow: rows redone exactly
+             {"FY_ISIM_GRAM": "1", "FY_ISIM_CAPG": "40"},                                 # candidate lists overflow: rows redone exactly
+             {"FY_ISIM_GRAM": "1", "FY_ISIM_ACC32": "0", "FY_COOC_MAX_CH": "512"}]        # 64-bit fixed-point accumulators (32-bit is the default where exact)
 
 
 @pytest.mark.parametrize("env", SYMMETRIC)
