@@ -343,10 +343,10 @@ __global__ void k_cooc_itemsim(CoocArgs A, ISimEpilogue E, int* __restrict__ nex
 //   * "along the row": for every row of the band, G[i][max(c0, i0) .. c1) in 1 KB tiles -- all lanes look at candidates of one row.
 // Every element of the triangle is read exactly once by each of the two rows it belongs to; a band's pieces have equal size.
 // Running top-K without a sort: a candidate must reach the row's threshold key tau (float bits order like the floats: all
-// similarities here are > 0).  Passing candidates are appended to the row's list in HBM and counted in a 64-bucket histogram of
-// their keys in LDS (8 buckets per octave below 1.0); when a row has collected K more, tau rises to the lower edge of the
-// highest bucket with K candidates at or above it -- a valid lower bound of the row's final K-th best (they are K real
-// candidates of the row), shared with the band's other pieces through tau_g.  After warm-up a few candidates per thousand
+// similarities here are > 0).  Passing candidates are appended to the row's list in HBM and counted in the row's 64-bucket
+// histogram of their keys (8 buckets per octave below 1.0; in HBM / L2, shared by the band's pieces); every 8th candidate of a
+// row that has K, tau rises to the lower edge of the highest bucket with K candidates at or above it -- a valid lower bound of
+// the row's final K-th best (they are K real candidates of the row), published to the band's other pieces through tau_g.  After warm-up a few candidates per thousand
 // pass; k_isim_finish selects and sorts the lists.  A row whose list overflows (massive ties inside one bucket) is redone
 // exactly by k_isim_finish from the matrix.
 constexpr int SWEEP_KEY_SHIFT = 20, SWEEP_KEY_BASE = 1016 - 63;   // bucket = (key >> 20) - base: 63 <-> [1, 1.125), 0 <-> everything below 2^-7.875
@@ -362,6 +362,7 @@ struct SweepArgs {
     uint64_t* __restrict__ glist;              // [Ic][capg]: key << 32 | (0x7FFFFFFF - raw item id)
     int32_t capg;
     int32_t* __restrict__ overflow;            // [Ic]
+    uint32_t* __restrict__ hist_g;             // [Ic][64]: the row's candidates by key bucket (all pieces of the band add to it)
     int32_t nbands, piece;
     uint32_t tau0;                             // the job's own threshold as a key (1 = "similarity > 0")
     int32_t exclude_self;
@@ -372,8 +373,7 @@ struct SweepArgs {
 
 // wave-level: lanes with `pass` hold a candidate (row i = band row rl, column col, raw Gram value v) that survived the fp32
 // prefilter; exact value, append, histogram, and -- every 8th candidate of a row once it has K -- a new threshold for the row
-__device__ __forceinline__ void sweep_take(const SweepArgs& A, uint32_t (*H)[64], uint32_t* tau_l, uint32_t* cnt_l, bool pass, int rl, int i, int col,
-                                           float v, int i0) {
+__device__ __forceinline__ void sweep_take(const SweepArgs& A, uint32_t* tau_l, bool pass, int rl, int i, int col, float v, int i0) {
     const int lane = threadIdx.x & 63;
     bool trig = false;
     if (pass) {
@@ -382,12 +382,11 @@ __device__ __forceinline__ void sweep_take(const SweepArgs& A, uint32_t (*H)[64]
         if (sf > 0.0f && key >= tau_l[rl]) {
             int bk = (int)(key >> SWEEP_KEY_SHIFT) - SWEEP_KEY_BASE;
             bk = bk < 0 ? 0 : (bk > 63 ? 63 : bk);
-            atomicAdd(&H[rl][bk], 1u);
-            const uint32_t n = atomicAdd(&cnt_l[rl], 1u) + 1u;
+            atomicAdd(&A.hist_g[(int64_t)i * 64 + bk], 1u);
             const int pos = atomicAdd(&A.gcnt[i], 1);
             if (pos < A.capg) A.glist[(int64_t)i * A.capg + pos] = ((uint64_t)key << 32) | (uint32_t)(0x7FFFFFFF - A.rank_item_raw[col]);
             else A.overflow[i] = 1;
-            trig = n >= (uint32_t)A.K && (n & 7u) == 0u;
+            trig = pos + 1 >= A.K && ((pos + 1) & 7) == 0;
         }
     }
     unsigned long long m = __ballot(trig);
@@ -395,7 +394,10 @@ __device__ __forceinline__ void sweep_take(const SweepArgs& A, uint32_t (*H)[64]
         const int src = __ffsll((long long)m) - 1;
         const int r = __shfl(rl, src, 64);
         m &= ~__ballot(rl == r);                       // (along a row every lane holds the same row)
-        uint32_t h = H[r][lane];                       // suffix sums over the buckets: candidates at or above bucket `lane`
+        // suffix sums over the row's buckets: candidates at or above bucket `lane`, over ALL pieces of the band (the histogram
+        // is the row's, in HBM / L2: the first version kept one per piece in LDS, and a piece sees a seventh of the row -- its K-th
+        // best is the row's 7 K-th: 1157 candidates per row for K = 100)
+        uint32_t h = A.hist_g[(int64_t)(i0 + r) * 64 + lane];
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const uint32_t t = (uint32_t)__shfl_down((int)h, o, 64);
@@ -414,17 +416,12 @@ __device__ __forceinline__ void sweep_take(const SweepArgs& A, uint32_t (*H)[64]
 }
 
 __global__ __launch_bounds__(256) void k_isim_sweep(SweepArgs A) {
-    __shared__ uint32_t H[64][64];
-    __shared__ uint32_t tau_l[64], cnt_l[64];
+    __shared__ uint32_t tau_l[64];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int p = blockIdx.x / A.nbands, b = blockIdx.x - p * A.nbands;
     const int i0 = b * 64;
     const int c0 = p * A.piece, c1 = min(c0 + A.piece, (int)A.ldm);
-    for (int t = tid; t < 64 * 64; t += 256) (&H[0][0])[t] = 0u;
-    if (tid < 64) {
-        tau_l[tid] = i0 + tid < A.Ic ? A.tau_g[i0 + tid] : 0xFFFFFFFFu;
-        cnt_l[tid] = 0u;
-    }
+    if (tid < 64) tau_l[tid] = i0 + tid < A.Ic ? A.tau_g[i0 + tid] : 0xFFFFFFFFu;
     __syncthreads();
     // The fast path of both parts is straight-line: U loads in flight, one compare per element against the row's threshold in
     // fp32 with a margin, the outcome kept as one bit per element.  Only when some lane of the wave holds a set bit does the
@@ -460,7 +457,7 @@ __global__ __launch_bounds__(256) void k_isim_sweep(SweepArgs A) {
                     float vu = v[0];
 #pragma unroll
                     for (int q = 1; q < U; q++) vu = u == q ? v[q] : vu;
-                    sweep_take(A, H, tau_l, cnt_l, pm != 0, lane, i, jb + 4 * (k0 + u), vu, i0);
+                    sweep_take(A, tau_l, pm != 0, lane, i, jb + 4 * (k0 + u), vu, i0);
                     pm &= pm - 1;
                 }
             }
@@ -501,7 +498,7 @@ __global__ __launch_bounds__(256) void k_isim_sweep(SweepArgs A) {
                     float vx = vv[0];
 #pragma unroll
                     for (int q = 1; q < 4 * U; q++) vx = x == q ? vv[q] : vx;
-                    sweep_take(A, H, tau_l, cnt_l, pm != 0, r, i, t0 + 256 * (x >> 2) + (x & 3), vx, i0);
+                    sweep_take(A, tau_l, pm != 0, r, i, t0 + 256 * (x >> 2) + (x & 3), vx, i0);
                     pm &= pm - 1;
                 }
             }
@@ -762,8 +759,10 @@ static bool itemsim_symmetric(Context* ctx, const fy_itemsim_params* prm, const 
     }
     k_fill_u32<<<grid_for(Ic), 256, 0, st>>>(Ic, tau0, tau_g.get());
     FY_KERNEL_CHECK();
+    DevBuf<uint32_t> hist_g(ctx, (size_t)round_up(Ic, 64) * 64);
+    hist_g.zero();
     SweepArgs SA{G.get(), ldm, Ic, K, invn32.get(), invn.get(), P.rank_item_raw.get(), tau_g.get(), gcnt.get(), glist.get(), capg, overflow.get(),
-                 (int32_t)ceil_div(Ic, 64), tune.isim_piece, tau0, prm->exclude_self, cnt, other, sim};
+                 hist_g.get(), (int32_t)ceil_div(Ic, 64), tune.isim_piece, tau0, prm->exclude_self, cnt, other, sim};
     const int npieces = (int)ceil_div(Ic, SA.piece);
     k_isim_sweep<<<SA.nbands * npieces, 256, 0, st>>>(SA);
     FY_KERNEL_CHECK();

@@ -1879,7 +1879,11 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 SA.pvpi = pvpi.get(); SA.n_out = n_out.get(); SA.slot_lo = lo; SA.slot_base = sbase; SA.slot0 = s0; SA.n_users = nb;
                 SA.S = Sx; SA.ldS = ldSx; SA.n_slices = n_slices; SA.n_chunks = nchunks;
                 if (tune.score_heavy > 0) {     // (stream order: every scoring launch of the batch follows)
-                    k_count_heavy<<<1, 64, 0, ls>>>(P.rowptr.get() + s0, nb, tune.score_heavy, L.n_heavy.get());
+                    // a small batch (one cluster of many) cannot fill the chip with a wave per user and its launch lasts as long as its
+                    // longest list on ONE wave (ML-1M shape in 50 clusters: 0.14 ms per cluster for 120 users): there every user with
+                    // more than a few batches is walked by a whole workgroup
+                    const int heavy = (int64_t)nb * nchunks < 8 * (int64_t)ctx->num_cus ? std::min(tune.score_heavy, 32) : tune.score_heavy;
+                    k_count_heavy<<<1, 64, 0, ls>>>(P.rowptr.get() + s0, nb, heavy, L.n_heavy.get());
                     SA.n_heavy = L.n_heavy.get();
                 }
                 return SA;

@@ -166,9 +166,12 @@ __global__ __launch_bounds__(256) void k_score(const float* __restrict__ M_, con
                 const int kk = min(k + SB + sub, end - 1);
                 vi_n = csr_idx_[kk]; ve_n = csr_e_[kk]; vq_n = csr_q_[kk];
             }
-            float p[VEC];
+            // fp32 sums of FOUR logs (|log2| ~ 13..40: partial sums below ~160, ulp 1.5e-5), folded into fp64: sums of eight had twice
+            // the magnitude and twice the roundings -- for users whose log sum nearly cancels pvpi (|score| ~ 1, every multi-cluster
+            // job) that fp32 noise, not the matrix format, was the largest term of the all-rows error (tests/test_full_size_gpu.py)
+            float p[VEC], p2[VEC];
 #pragma unroll
-            for (int v = 0; v < VEC; v++) p[v] = 0.f;
+            for (int v = 0; v < VEC; v++) p[v] = p2[v] = 0.f;
 #pragma unroll
             for (int q = 0; q < SB; q++) {
                 if (k + q < end) {
@@ -180,13 +183,16 @@ __global__ __launch_bounds__(256) void k_score(const float* __restrict__ M_, con
                         for (int v = 0; v < VEC; v++) gv[v] = gp[v];
                     }
 #pragma unroll
-                    for (int v = 0; v < VEC; v++) p[v] += fy_log2(fmaf(qq[q], bb[v], fmaf(a[v], e[q], gv[v])));
+                    for (int v = 0; v < VEC; v++) {
+                        const float lg = fy_log2(fmaf(qq[q], bb[v], fmaf(a[v], e[q], gv[v])));
+                        if (q < SB / 2) p[v] += lg; else p2[v] += lg;
+                    }
                     const unsigned d = (unsigned)(jj[q] * row_mul + A.row_add - col0);
                     if (!no_mask && d < (unsigned)CW && (int)(d / VEC) == lane) mask |= 1u << (d % VEC);
                 }
             }
 #pragma unroll
-            for (int v = 0; v < VEC; v++) t[v] += (double)p[v];
+            for (int v = 0; v < VEC; v++) t[v] += (double)p[v] + (double)p2[v];
             vi = vi_n; ve = ve_n; vq = vq_n;
         }
     };
@@ -823,20 +829,23 @@ __global__ __launch_bounds__(256) void k_score_blocks(const float* __restrict__ 
                 const int kk = min(k + SB + sub, end - 1);
                 vi_n = csr_idx_[kk]; ve_n = csr_e_[kk]; vq_n = csr_q_[kk];
             }
-            float p[4] = {0.f, 0.f, 0.f, 0.f};
+            float p[4] = {0.f, 0.f, 0.f, 0.f}, p2[4] = {0.f, 0.f, 0.f, 0.f};     // (two fp32 sums of SB / 2 logs each: see k_score's walk)
 #pragma unroll
             for (int x = 0; x < SB; x++) {
                 if (k + x < end) {
                     float gv[4];
                     fy_unpack24(g[x], gv);
 #pragma unroll
-                    for (int v = 0; v < 4; v++) p[v] += fy_log2(fmaf(qq[x], bb[v], fmaf(a[v], e[x], gv[v])));
+                    for (int v = 0; v < 4; v++) {
+                        const float lg = fy_log2(fmaf(qq[x], bb[v], fmaf(a[v], e[x], gv[v])));
+                        if (x < SB / 2) p[v] += lg; else p2[v] += lg;
+                    }
                     const unsigned d = (unsigned)(jj[x] - col);
                     if (d < 4u) mask |= 1u << d;
                 }
             }
 #pragma unroll
-            for (int v = 0; v < 4; v++) t[v] += (double)p[v];
+            for (int v = 0; v < 4; v++) t[v] += (double)p[v] + (double)p2[v];
             vi = vi_n; ve = ve_n; vq = vq_n;
         }
         if (wave > 0) {
@@ -1425,20 +1434,23 @@ __global__ __launch_bounds__(256) void k_score_entries(const float* __restrict__
                 const int kk = min(kk0 + SB + sub, end - 1);
                 vi_n = csr_idx_[kk]; ve_n = csr_e_[kk]; vq_n = csr_q_[kk];
             }
-            float p[4] = {0.f, 0.f, 0.f, 0.f};
+            float p[4] = {0.f, 0.f, 0.f, 0.f}, p2[4] = {0.f, 0.f, 0.f, 0.f};     // (two fp32 sums of SB / 2 logs each: see k_score's walk)
 #pragma unroll
             for (int x = 0; x < SB; x++) {
                 if (kk0 + x < end) {
                     float gv[4];
                     fy_unpack24(g[x], gv);
 #pragma unroll
-                    for (int v = 0; v < 4; v++) p[v] += fy_log2(fmaf(qq[x], bb[v], fmaf(a[v], e[x], gv[v])));
+                    for (int v = 0; v < 4; v++) {
+                        const float lg = fy_log2(fmaf(qq[x], bb[v], fmaf(a[v], e[x], gv[v])));
+                        if (x < SB / 2) p[v] += lg; else p2[v] += lg;
+                    }
                     const unsigned d = (unsigned)(jj[x] * row_mul + row_add - col);
                     if (d < 4u) mask |= 1u << d;
                 }
             }
 #pragma unroll
-            for (int v = 0; v < 4; v++) t[v] += (double)p[v];
+            for (int v = 0; v < 4; v++) t[v] += (double)p[v] + (double)p2[v];
             vi = vi_n; ve = ve_n; vq = vq_n;
         }
         const double base = pvpi_[slot - slot_base];
