@@ -57,7 +57,7 @@ void fy::load_tuning_from_env(Tuning& t) {
     if (const char* e = getenv("FY_ISIM_GRAM_MIN_ITEMS")) t.isim_gram_min_items = std::max(0, atoi(e));
     if (const char* e = getenv("FY_ISIM_CAPG")) { int v = atoi(e); if (v >= 1 && v <= 2040) t.isim_capg = v; }
     if (const char* e = getenv("FY_ISIM_ACC32")) t.isim_acc32 = atoi(e) != 0;
-    if (const char* e = getenv("FY_ISIM_PIECE")) { int v = atoi(e); if (v >= 64 && v % 64 == 0) t.isim_piece = v; }
+    if (const char* e = getenv("FY_ISIM_PIECE")) { int v = atoi(e); if (v >= 64 && v <= 8192 && v % 64 == 0) t.isim_piece = v; }
 }
 
 // every entry point: no exception may cross the ABI

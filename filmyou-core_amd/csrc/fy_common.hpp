@@ -88,7 +88,7 @@ struct Tuning {
     int isim_gram = -1;                // symmetric Gram + band sweep: -1 = by size (cosine, >= isim_gram_min_items items), 0 = never, 1 = whenever possible
     int isim_gram_min_items = 4096;
     int isim_capg = 2040;              // candidates a row of the band sweep may collect before it is redone exactly (<= 2040: k_isim_finish sorts them in LDS)
-    int isim_piece = 8192;             // columns per piece of the band sweep
+    int isim_piece = 4096;             // columns per piece of the band sweep (measured, ML-25M shape, build ms: 2048 11.90, 4096 11.90, 8192 12.2, 16384 12.0, 32768 12.5, 65536 14.1)
     int isim_acc32 = 1;                // 32-bit fixed-point accumulators in the symmetric build's walk when the products are exact integers
 };
 

@@ -416,12 +416,21 @@ __device__ __forceinline__ void sweep_take(const SweepArgs& A, uint32_t* tau_l, 
 }
 
 __global__ __launch_bounds__(256) void k_isim_sweep(SweepArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float fy_sweep_lds[];      // [piece + 256]: 1 / norm of the piece's columns, then 64: of the band's rows
     __shared__ uint32_t tau_l[64];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int p = blockIdx.x / A.nbands, b = blockIdx.x - p * A.nbands;
     const int i0 = b * 64;
     const int c0 = p * A.piece, c1 = min(c0 + A.piece, (int)A.ldm);
-    if (tid < 64) tau_l[tid] = i0 + tid < A.Ic ? A.tau_g[i0 + tid] : 0xFFFFFFFFu;
+    float* __restrict__ nrm_cols = fy_sweep_lds;
+    float* __restrict__ nrm_rows = fy_sweep_lds + A.piece + 256;
+    // the norms the piece needs, once: every element used to bring its column's norm along from L2 (a second 16-byte load per
+    // 16 bytes of the matrix), and every row of the band began with a dependent load of its own norm
+    for (int t = tid; t < A.piece + 256; t += 256) nrm_cols[t] = c0 + t < (int)A.ldm ? A.invn32[c0 + t] : 0.0f;
+    if (tid < 64) {
+        nrm_rows[tid] = A.invn32[i0 + tid];
+        tau_l[tid] = i0 + tid < A.Ic ? A.tau_g[i0 + tid] : 0xFFFFFFFFu;
+    }
     __syncthreads();
     // The fast path of both parts is straight-line: U loads in flight, one compare per element against the row's threshold in
     // fp32 with a margin, the outcome kept as one bit per element.  Only when some lane of the wave holds a set bit does the
@@ -430,14 +439,14 @@ __global__ __launch_bounds__(256) void k_isim_sweep(SweepArgs A) {
     // wave-uniform loads that the compiler turned into dependent vector loads behind s_waitcnt vmcnt(0): 8.6 ms for 14 GB.)
     // ---- down the column: rows j of the matrix in [c0, jend), segment [i0, i0 + 64); wave w takes j = c0 + w, c0 + w + 4, ...
     const int jend = min(min(c1, i0 + 64), A.Ic);
-    if (c0 < jend) {
+    if (c0 < jend && A.exclude_self != 3) {
         const int i = i0 + lane;
         const bool valid = i < A.Ic;
-        const float my_inv = valid ? A.invn32[i] : 0.0f;
+        const float my_inv = valid ? nrm_rows[lane] : 0.0f;
         const float* __restrict__ gp = A.G + i0 + lane;
         constexpr int U = 8;
-        for (int jb = c0 + wave; jb < jend; jb += 4 * 64) {     // 64 of the wave's rows per block: their norms in one load, lane k <-> row jb + 4 k
-            const float nj_vec = A.invn32[min(jb + 4 * lane, jend - 1)];
+        for (int jb = c0 + wave; jb < jend; jb += 4 * 64) {     // 64 of the wave's rows per block: their norms in one read, lane k <-> row jb + 4 k
+            const float nj_vec = nrm_cols[min(jb + 4 * lane, jend - 1) - c0];
             for (int k0 = 0; k0 < 64 && jb + 4 * k0 < jend; k0 += U) {     // wave-uniform
                 float v[U];
 #pragma unroll
@@ -463,44 +472,56 @@ __global__ __launch_bounds__(256) void k_isim_sweep(SweepArgs A) {
             }
         }
     }
-    // ---- along the row: columns [cs, c1) of the band's rows (a row's candidates are the columns behind it)
+    // ---- along the row: columns [cs, c1) of the band's rows (a row's candidates are the columns behind it).  ONE loop over the
+    // (row, 256-column tile) pairs of this wave -- rows wave, wave + 4, ... -- four tiles in flight, also across the end of a row
     const int cs = max(c0, i0);
-    if (cs < c1) {
+    const int n_rows = min(64, A.Ic - i0);
+    if (cs < c1 && wave < n_rows && A.exclude_self != 2) {
         constexpr int U = 4;
-        for (int r = wave; r < 64; r += 4) {
-            const int i = i0 + r;
-            if (i >= A.Ic) break;                            // wave-uniform
-            const float ri = A.invn32[i];
-            const float* __restrict__ grow = A.G + (int64_t)i * A.ldm;
-            for (int t0 = cs + 4 * lane; t0 < c1 + 4 * lane; t0 += 256 * U) {     // (t0 - 4 lane is wave-uniform)
-                float4 v[U], n4[U];
-#pragma unroll
-                for (int u = 0; u < U; u++) {                // tiles behind c1 read the slack behind the row / the matrix: masked below
-                    v[u] = *reinterpret_cast<const float4*>(grow + t0 + 256 * u);
-                    n4[u] = *reinterpret_cast<const float4*>(A.invn32 + t0 + 256 * u);
-                }
-                const float tauf = __uint_as_float(tau_l[r]) * 0.999999f;
-                float vv[4 * U];
-                uint32_t pm = 0;
+        const int tiles_per_row = (c1 - cs + 255) >> 8;
+        const int total = ((n_rows - wave + 3) >> 2) * tiles_per_row;
+        int rr = wave, tt = 0;                                  // row / tile of pair T0 (wave-uniform)
+        for (int T0 = 0; T0 < total; T0 += U) {
+            float4 v[U];
+            int r_of[U], col_of[U];
+            {
+                int r2 = rr, t2 = tt;
 #pragma unroll
                 for (int u = 0; u < U; u++) {
-                    vv[4 * u + 0] = v[u].x; vv[4 * u + 1] = v[u].y; vv[4 * u + 2] = v[u].z; vv[4 * u + 3] = v[u].w;
-                    const float nn[4] = {n4[u].x, n4[u].y, n4[u].z, n4[u].w};
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const int col = t0 + 256 * u + e;
-                        const float s = vv[4 * u + e] * ri * nn[e];
-                        pm |= ((uint32_t)(col < c1) & (uint32_t)(col > i) & (uint32_t)(col < A.Ic) & (uint32_t)(s > 0.0f) & (uint32_t)(s >= tauf)) << (4 * u + e);
-                    }
+                    r_of[u] = r2;
+                    col_of[u] = cs + 256 * t2 + 4 * lane;      // (a tile that overshoots c1 reads the slack behind the row / the matrix: masked below)
+                    v[u] = *reinterpret_cast<const float4*>(A.G + (int64_t)(i0 + r2) * A.ldm + col_of[u]);
+                    if (T0 + u + 1 < total) { if (++t2 == tiles_per_row) { t2 = 0; r2 += 4; } }     // (the last pairs repeat: masked by T0 + u < total)
                 }
-                while (__ballot(pm != 0)) {
-                    const int x = pm ? __ffs((int)pm) - 1 : 0;
-                    float vx = vv[0];
+                rr = r2; tt = t2;                             // = pair T0 + U
+            }
+            float vv[4 * U];
+            uint32_t pm = 0;
 #pragma unroll
-                    for (int q = 1; q < 4 * U; q++) vx = x == q ? vv[q] : vx;
-                    sweep_take(A, tau_l, pm != 0, r, i, t0 + 256 * (x >> 2) + (x & 3), vx, i0);
-                    pm &= pm - 1;
+            for (int u = 0; u < U; u++) {
+                const int i = i0 + r_of[u];
+                const float ri = nrm_rows[r_of[u]];
+                const float tauf = __uint_as_float(tau_l[r_of[u]]) * 0.999999f;
+                const float4 n4 = *reinterpret_cast<const float4*>(nrm_cols + (col_of[u] - c0));
+                vv[4 * u + 0] = v[u].x; vv[4 * u + 1] = v[u].y; vv[4 * u + 2] = v[u].z; vv[4 * u + 3] = v[u].w;
+                const float nn[4] = {n4.x, n4.y, n4.z, n4.w};
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int col = col_of[u] + e;
+                    const float s = vv[4 * u + e] * ri * nn[e];
+                    pm |= ((uint32_t)(T0 + u < total) & (uint32_t)(col < c1) & (uint32_t)(col > i) & (uint32_t)(col < A.Ic) & (uint32_t)(s > 0.0f) & (uint32_t)(s >= tauf)) << (4 * u + e);
                 }
+            }
+            while (__ballot(pm != 0)) {
+                const int x = pm ? __ffs((int)pm) - 1 : 0;
+                float vx = vv[0];
+#pragma unroll
+                for (int q = 1; q < 4 * U; q++) vx = x == q ? vv[q] : vx;
+                int rx = r_of[0], cx = col_of[0];
+#pragma unroll
+                for (int q = 1; q < U; q++) { rx = (x >> 2) == q ? r_of[q] : rx; cx = (x >> 2) == q ? col_of[q] : cx; }
+                sweep_take(A, tau_l, pm != 0, rx, i0 + rx, cx + (x & 3), vx, i0);
+                pm &= pm - 1;
             }
         }
     }
@@ -764,7 +785,7 @@ static bool itemsim_symmetric(Context* ctx, const fy_itemsim_params* prm, const 
     SweepArgs SA{G.get(), ldm, Ic, K, invn32.get(), invn.get(), P.rank_item_raw.get(), tau_g.get(), gcnt.get(), glist.get(), capg, overflow.get(),
                  hist_g.get(), (int32_t)ceil_div(Ic, 64), tune.isim_piece, tau0, prm->exclude_self, cnt, other, sim};
     const int npieces = (int)ceil_div(Ic, SA.piece);
-    k_isim_sweep<<<SA.nbands * npieces, 256, 0, st>>>(SA);
+    k_isim_sweep<<<SA.nbands * npieces, 256, (size_t)(SA.piece + 256 + 64) * sizeof(float), st>>>(SA);
     FY_KERNEL_CHECK();
     DevBuf<int32_t> redo_list(ctx, (size_t)Ic), n_redo(ctx, 1);
     n_redo.zero();
