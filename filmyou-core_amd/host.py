@@ -538,7 +538,7 @@ class RowSimilarityJob:
         if similarityClassname not in _SIMILARITY:
             raise ValueError("similarityClassname must be SIMILARITY_COSINE or SIMILARITY_COOCCURRENCE")
         p = _native.ItemSimParams(_SIMILARITY[similarityClassname], int(maxSimilaritiesPerRow),
-                                  (excludeSelfSimilarity if isinstance(excludeSelfSimilarity, int) and not isinstance(excludeSelfSimilarity, bool) else (1 if excludeSelfSimilarity else 0)), 0 if threshold is None else 1,
+                                  1 if excludeSelfSimilarity else 0, 0 if threshold is None else 1,
                                   0.0 if threshold is None else float(threshold), int(rank), int(world), 0,
                                   int(minPrefsPerUser), 0 if maxPrefsPerUser is None else int(maxPrefsPerUser))
         ctx = self.ctx or Context(0)
