@@ -179,8 +179,8 @@ __global__ void k_user_sums(int32_t nU, const int32_t* __restrict__ ustart, cons
 
 // cluster of a user: last entry of the (stably sorted) clustering map with that user id, 0 when absent (Q2)
 __global__ void k_lookup_cluster(int32_t nU, const int32_t* __restrict__ uid, int64_t n_map,
-                                 const uint64_t* __restrict__ map_sorted /* user:cluster */, int32_t K,
-                                 int32_t* __restrict__ ucluster, int* __restrict__ err) {
+                                 const uint64_t* __restrict__ map_sorted /* user : position in the file */, const uint32_t* __restrict__ map_cluster_sorted,
+                                 int32_t K, int32_t* __restrict__ ucluster, int* __restrict__ err) {
     for (int32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < nU; u += gridDim.x * blockDim.x) {
         const uint32_t id = (uint32_t)uid[u];
         int64_t lo = 0, hi = n_map;            // upper bound of id in the hi32 part
@@ -189,7 +189,7 @@ __global__ void k_lookup_cluster(int32_t nU, const int32_t* __restrict__ uid, in
             if ((uint32_t)(map_sorted[mid] >> 32) <= id) lo = mid + 1; else hi = mid;
         }
         int32_t c = 0;
-        if (lo > 0 && (uint32_t)(map_sorted[lo - 1] >> 32) == id) c = (int32_t)(uint32_t)map_sorted[lo - 1];
+        if (lo > 0 && (uint32_t)(map_sorted[lo - 1] >> 32) == id) c = (int32_t)map_cluster_sorted[lo - 1];
         if (c < 0 || c >= K) { atomicOr(err, ERR_CLUSTER_RANGE); c = 0; }
         ucluster[u] = c;
     }
@@ -434,18 +434,24 @@ void build_structure(Context* ctx, const fy_ratings* R, int32_t K, int64_t n_map
     // ---- cluster routing
     P.ucluster.alloc(ctx, nU);
     {
+        if (n_map >= ((int64_t)1 << 32)) FY_FAIL(FY_ERR_UNSUPPORTED, "clustering map with more than 2^32 entries");
         std::vector<uint64_t> hm((size_t)n_map);
+        std::vector<uint32_t> hv((size_t)n_map);
         for (int64_t m = 0; m < n_map; m++) {
-            if (map_user[m] < 0) { hm[m] = ~0ull; continue; }   // can never match a kept rating
-            hm[m] = ((uint64_t)(uint32_t)map_user[m] << 32) | (uint32_t)map_cluster[m];
+            // key = (user : position in the file): sorted by it, the pairs of one user keep their order -- a later pair of the same
+            // user wins, like successive TIntIntHashMap.put calls.  (A negative id can never match a kept rating.)
+            hm[m] = ((uint64_t)(map_user[m] < 0 ? 0xFFFFFFFFu : (uint32_t)map_user[m]) << 32) | (uint32_t)m;
+            hv[m] = (uint32_t)map_cluster[m];
         }
-        // stable by user: a later pair of the same user wins, like successive TIntIntHashMap.put calls
-        std::stable_sort(hm.begin(), hm.end(), [](uint64_t a, uint64_t b) { return (a >> 32) < (b >> 32); });
-        DevBuf<uint64_t> dm(ctx, (size_t)n_map);
-        h2d(ctx, dm.get(), hm.data(), (size_t)n_map);
-        k_lookup_cluster<<<grid_for(nU), 256, 0, st>>>(nU, P.uid.get(), n_map, dm.get(), K, P.ucluster.get(), err.get());
+        // sorted on the device: std::stable_sort of 162 541 pairs on the host was 3-4 ms of every cold multi-cluster prepare
+        DevBuf<uint64_t> dm_in(ctx, (size_t)n_map), dm(ctx, (size_t)n_map);
+        DevBuf<uint32_t> dv_in(ctx, (size_t)n_map), dv(ctx, (size_t)n_map);
+        h2d(ctx, dm_in.get(), hm.data(), (size_t)n_map);
+        h2d(ctx, dv_in.get(), hv.data(), (size_t)n_map);
+        sort_pairs_u64_u32(ctx, dm_in.get(), dm.get(), dv_in.get(), dv.get(), (size_t)n_map);
+        k_lookup_cluster<<<grid_for(nU), 256, 0, st>>>(nU, P.uid.get(), n_map, dm.get(), dv.get(), K, P.ucluster.get(), err.get());
         FY_KERNEL_CHECK();
-        sync(ctx);   // hm must outlive the copy
+        sync(ctx);   // hm / hv must outlive the copies
     }
     if (fetch(ctx, err.get()) & ERR_CLUSTER_RANGE)
         FY_FAIL(FY_ERR_CLUSTER_RANGE, "a rated user is routed to a cluster outside [0, %d)", K);

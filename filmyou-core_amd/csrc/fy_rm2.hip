@@ -696,8 +696,8 @@ __device__ __forceinline__ void cooc_rm2_epilogue(const CoocArgs& A, const MEpil
 // the load of its first 64 segment descriptors of the NEXT item, and only then runs the epilogue: of the three round
 // trips in front of an item's first slice load none is exposed any more.  (3) The epilogue no longer reads b and p.
 // ROLE only names the instantiation (kernel traces): 0 = matrix rows, 1 = the tail rows' block bounds of panel mode (k_tail_blocks)
-template <bool PK, class ACC, int ROLE = 0>
-__global__ void k_cooc_rm2(CoocArgs A, MEpilogue E, int n_items, int* __restrict__ next_item) {
+template <bool PK, class ACC>
+__device__ __forceinline__ void cooc_rm2_body(const CoocArgs& A, const MEpilogue& E, int n_items, int* __restrict__ next_item) {
     ACC* __restrict__ acc = reinterpret_cast<ACC*>(fy_cooc_acc);
     __shared__ int sh_item, sh_s0, sh_s1, sh_id;
     const int CHp = cooc_lds_columns(A.CH);   // allocated (and zeroed) columns: the epilogue reads whole 256-column blocks
@@ -765,6 +765,25 @@ __global__ void k_cooc_rm2(CoocArgs A, MEpilogue E, int n_items, int* __restrict
         if (threadIdx.x == 0) next = next2;
         __syncthreads();   // the accumulators are clean again before the next item's atomics
     }
+}
+template <bool PK, class ACC, int ROLE = 0>
+__global__ void k_cooc_rm2(CoocArgs A, MEpilogue E, int n_items, int* __restrict__ next_item) {
+    cooc_rm2_body<PK, ACC>(A, E, n_items, next_item);
+}
+// The matrix builds of SEVERAL clusters in one launch (panel mode, many clusters): blockIdx.y = cluster; its arguments and its item
+// counter come from device memory.  The workgroups of cluster c + 1 start on the CUs that cluster c's workgroups leave: no launch
+// gap and no idle tail between two clusters' row kernels (50 clusters at ML-25M shape: 100 launches back to back were 41 ms).
+struct CoocLaunch {
+    CoocArgs A;
+    MEpilogue E;
+    int32_t n_items, pad;
+};
+template <bool PK, class ACC, int ROLE = 0>
+__global__ void k_cooc_rm2_multi(const CoocLaunch* __restrict__ D, int* __restrict__ counters) {
+    const CoocLaunch& d = D[blockIdx.y];
+    const CoocArgs A = d.A;
+    const MEpilogue E = d.E;
+    cooc_rm2_body<PK, ACC>(A, E, d.n_items, counters + blockIdx.y);
 }
 
 // ================================================================ mirror pass of the symmetric (half) walk
@@ -896,6 +915,8 @@ static void cooc_rm2_allow_lds() {
     FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cooc_rm2<true, unsigned long long>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cooc_rm2<true, uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cooc_rm2<true, unsigned long long, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cooc_rm2_multi<true, unsigned long long, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cooc_rm2_multi<true, unsigned long long, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
 }
 static void stray_allow_lds();
 
@@ -1122,6 +1143,33 @@ bool fy::gram_half_build(Context* ctx, const Prepared& P, const float* csc_w, co
     if (ms_tables) *ms_tables = t_tab.total_ms();
     if (ms_walk) *ms_walk = t_walk.total_ms();
     return true;
+}
+
+// one launch for the row kernels of several clusters (two-phase panel mode; fixed-point packed walk only): `L` = one CoocLaunch per
+// cluster on the host, uploaded here; the launch shape (workgroup size, LDS) is that of the widest chunk among them
+static void launch_cooc_rm2_multi(Context* ctx, const ScoreTune& tune, std::vector<CoocLaunch>& L, bool tail_role, DevBuf<CoocLaunch>& d_launch,
+                                  DevBuf<int32_t>& d_counters, hipStream_t st) {
+    if (L.empty()) return;
+    int max_chp = 0, max_items = 0;
+    for (auto& x : L) {
+        x.A.acc_quarter = tune.cooc_planes ? cooc_lds_columns(x.A.CH) / 4 : 0;
+        max_chp = std::max(max_chp, cooc_lds_columns(x.A.CH));
+        max_items = std::max(max_items, x.n_items);
+    }
+    const size_t lds = (size_t)max_chp * 8;
+    const int by_lds = (int)std::max<size_t>(1, (160 * 1024 - 512) / (lds + 64));
+    int block = tune.cooc_block;
+    if (!block) block = by_lds >= 4 ? 256 : (by_lds >= 2 ? 512 : 1024);
+    const int per_cu = std::max(1, std::min(by_lds, 2048 / block));
+    const int gx = std::max(1, std::min(max_items, ctx->num_cus * per_cu));
+    d_launch.alloc(ctx, L.size());
+    d_counters.alloc(ctx, L.size());
+    FY_HIP(hipMemcpyAsync(d_launch.get(), L.data(), L.size() * sizeof(CoocLaunch), hipMemcpyHostToDevice, st));
+    FY_HIP(hipMemsetAsync(d_counters.get(), 0, L.size() * sizeof(int32_t), st));
+    const dim3 grid((unsigned)gx, (unsigned)L.size());
+    if (tail_role) k_cooc_rm2_multi<true, unsigned long long, 1><<<grid, block, lds, st>>>(d_launch.get(), d_counters.get());
+    else k_cooc_rm2_multi<true, unsigned long long, 0><<<grid, block, lds, st>>>(d_launch.get(), d_counters.get());
+    FY_KERNEL_CHECK();
 }
 
 // user slices (workgroups per column chunk) of a scoring launch over `nb` users and `chunks` column chunks: a wave walks up to
@@ -1595,7 +1643,19 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
         }
         bool any_panel = false;
         for (auto& p : plans) any_panel = any_panel || p.panel;
-        const int want_lanes = any_panel && !tune.lanes_forced ? std::min(tune.lanes, tune.panel_lanes) : tune.lanes;
+        // Two phases for panel-mode jobs (round 3): the matrix panels of ALL clusters are built first, back to back on the main stream
+        // (persistent row kernels that fill every CU's LDS gain nothing from running beside another cluster's), each into its own
+        // buffers; then the clusters' light scoring kernels overlap on the lanes.  With one set of buffers per LANE (round 2) two lanes
+        // were the optimum and mostly waited for each other's row kernels.  Needs every cluster's panel resident: 45 GB at 50 clusters
+        // of ML-25M shape.
+        int64_t panel_bytes = 0;
+        int n_panel = 0;
+        for (auto& p : plans)
+            if (p.panel) { n_panel++; panel_bytes += (int64_t)p.Ic * p.panel_cols * 3 + (int64_t)p.Ic * p.ldb64 * 7 + 64; }
+        const bool two_phase = tune.panel_two_phase && n_panel >= 2 && (uint64_t)panel_bytes < ctx->total_mem / 3;
+        // (lanes: one-phase panel mode 2 -- more lanes only queue behind each other's row kernels; two-phase 8 -- only light kernels are left
+        // on the lanes: measured at 50 clusters, ms per job: 2 lanes 98.0, 4: 95.9, 8: 93.1)
+        const int want_lanes = tune.lanes_forced ? tune.lanes : (two_phase ? std::max(tune.lanes, 8) : (any_panel ? std::min(tune.lanes, tune.panel_lanes) : tune.lanes));
         const int NS = (int)std::min<size_t>(plans.size() > 1 ? (size_t)want_lanes : 1, plans.size());
         struct Lane {
             hipStream_t st;
@@ -1611,8 +1671,8 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             DevBuf<int2> stray_items;
             DevBuf<int32_t> n_heavy;       // k_count_heavy
             DevBuf<int32_t> n_quads, quad_prefix;
-            DevBuf<int2> item_seg;
-            DevBuf<int32_t> item_id;
+            DevBuf<int2> item_seg, item_seg_t;      // (_t: the tail-row bound launch of a cluster whose row kernels are batched)
+            DevBuf<int32_t> item_id, item_id_t;
             DevBuf<float> Ssurv;   // packed scores of the surviving blocks (pruned clusters)
         };
         std::vector<Lane> lanes((size_t)NS);
@@ -1664,11 +1724,11 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 L.Bmax.alloc(ctx, bm_el);
                 L.amax.alloc(ctx, am_el);
                 L.bmax.alloc(ctx, am_el);
-                L.Gp.alloc(ctx, gp_el);
-                L.Bmax64.alloc(ctx, b64_el);
-                L.Brep.alloc(ctx, gp_el > 1 ? b64_el * 4 / 3 + 4 : 1);     // (b64_el counts floats for 3-byte entries)
-                L.amax64.alloc(ctx, a64_el);
-                L.bmax64.alloc(ctx, a64_el);
+                L.Gp.alloc(ctx, two_phase ? 1 : gp_el);
+                L.Bmax64.alloc(ctx, two_phase ? 1 : b64_el);
+                L.Brep.alloc(ctx, gp_el > 1 && !two_phase ? b64_el * 4 / 3 + 4 : 1);     // (b64_el counts floats for 3-byte entries)
+                L.amax64.alloc(ctx, two_phase ? 1 : a64_el);
+                L.bmax64.alloc(ctx, two_phase ? 1 : a64_el);
                 L.UB.alloc(ctx, ub_el);
                 L.tau.alloc(ctx, ov_el);
                 L.surv.alloc(ctx, ub_el);
@@ -1770,16 +1830,77 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
         // tables and the per-job arrays back into the caching allocator while kernels of OTHER lanes may still be reading
         // them.  The guard drains every lane and the main stream first (members are destroyed in reverse order of
         // declaration: `lanes`, `segs` and the DevBufs above were declared before it, so it runs before they are released).
+        struct PanelBuf {
+            DevBuf<float> Gp, Bmax64, amax64, bmax64;
+            DevBuf<uint32_t> Brep;
+        };
+        struct PanelPtrs {
+            float *Gp, *Bmax64;
+            uint32_t* Brep;
+            float *amax64, *bmax64;
+        };
+        std::vector<PanelBuf> pbuf(two_phase ? plans.size() : 0);
+        if (two_phase)
+            for (size_t pi = 0; pi < plans.size(); pi++) {
+                const Plan& p = plans[pi];
+                if (!p.panel) continue;
+                pbuf[pi].Gp.alloc(ctx, (size_t)p.Ic * p.panel_cols * 3 / 4 + 4);
+                pbuf[pi].Bmax64.alloc(ctx, (size_t)p.Ic * p.ldb64 * 3 / 4 + 4);
+                pbuf[pi].Brep.alloc(ctx, (size_t)p.Ic * p.ldb64 + 4);
+                pbuf[pi].amax64.alloc(ctx, (size_t)p.ldb64);
+                pbuf[pi].bmax64.alloc(ctx, (size_t)p.ldb64);
+            }
+        // ... and its own scoring scratch, so that NO host round trip separates the clusters: phase 2 queues seed + bound pass, select, second
+        // bound and the survivor count of every cluster, ONE wait reads all counts (pinned host memory), phase 3 queues the survivor
+        // passes and top-N.  (With one scratch set per lane the host waited for every cluster's count before it could queue the next
+        // cluster of that lane: 50 round trips during which the other lanes ran dry.)
+        std::vector<Lane> plane(two_phase ? plans.size() : 0);
+        if (two_phase)
+            for (size_t pi = 0; pi < plans.size(); pi++) {
+                const Plan& p = plans[pi];
+                if (!p.panel) continue;
+                Lane& W = plane[pi];
+                const size_t nbp = (size_t)(p.b - p.a);
+                const size_t seed_cols = (size_t)std::min<int64_t>(ceil_div(p.Ic, 256), tune.seed_chunks) * 256;
+                W.st = lanes[pi % NS].st;
+                W.M.alloc(ctx, 1); W.Bmax.alloc(ctx, 1); W.amax.alloc(ctx, 1); W.bmax.alloc(ctx, 1);
+                W.Gp.alloc(ctx, 1); W.Bmax64.alloc(ctx, 1); W.Brep.alloc(ctx, 1); W.amax64.alloc(ctx, 1); W.bmax64.alloc(ctx, 1);
+                W.item_seg.alloc(ctx, (size_t)p.Ic * p.nch); W.item_id.alloc(ctx, (size_t)p.Ic * p.nch);
+                W.item_seg_t.alloc(ctx, (size_t)std::max(1, p.Ic - p.p_eff)); W.item_id_t.alloc(ctx, (size_t)std::max(1, p.Ic - p.p_eff));
+                W.S.alloc(ctx, nbp * seed_cols);
+                W.overflow.alloc(ctx, nbp);
+                W.any_overflow.alloc(ctx, 1);
+                W.n_heavy.alloc(ctx, 1);
+                W.UB.alloc(ctx, nbp * (size_t)p.ldb64);
+                W.tau.alloc(ctx, nbp);
+                W.surv.alloc(ctx, nbp * (size_t)p.ldb64);
+                W.surv_mask.alloc(ctx, nbp * (size_t)p.ldb64);
+                W.n_quads.alloc(ctx, nbp + 1);
+                W.quad_prefix.alloc(ctx, nbp + 1);
+            }
         struct LaneGuard {
             Context* ctx;
             hipEvent_t fork = nullptr;
+            int32_t* pinned = nullptr;
             ~LaneGuard() {
                 for (hipStream_t x : ctx->aux) (void)hipStreamSynchronize(x);
                 (void)hipStreamSynchronize(ctx->stream);
                 if (fork) (void)hipEventDestroy(fork);
+                if (pinned) (void)hipHostFree(pinned);
             }
         } guard{ctx};
-        if (NS > 1) {   // the lanes start after everything queued on the main stream so far
+        if (two_phase) FY_HIP(hipHostMalloc(reinterpret_cast<void**>(&guard.pinned), plans.size() * sizeof(int32_t), hipHostMallocDefault));
+        // phase 0: every cluster start to end on its lane.  two_phase: phase 1 = the panels of all panel-mode clusters on the main stream,
+        // phase 2 = everything else on the lanes.
+        std::vector<CoocLaunch> batch_main, batch_tail;      // phase 1: the row kernels of all panel clusters, launched together
+        DevBuf<CoocLaunch> d_batch_main, d_batch_tail;
+        DevBuf<int32_t> d_cnt_main, d_cnt_tail;
+        for (int phase = two_phase ? 1 : 0; phase <= (two_phase ? 3 : 0); phase++) {
+        if (phase == 3) {             // every cluster's survivor count has been queued: one wait for all of them
+            for (int l = 0; l < NS; l++) FY_HIP(hipStreamSynchronize(lanes[l].st));
+            FY_HIP(hipStreamSynchronize(st));
+        }
+        if ((phase == 0 || phase == 2) && NS > 1) {   // the lanes start after everything queued on the main stream so far
             FY_HIP(hipEventCreateWithFlags(&guard.fork, hipEventDisableTiming));
             FY_HIP(hipEventRecord(guard.fork, st));
             for (int l = 0; l < NS; l++) FY_HIP(hipStreamWaitEvent(lanes[l].st, guard.fork, 0));
@@ -1787,8 +1908,12 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
 
         for (size_t pi = 0; pi < plans.size(); pi++) {
             const Plan& p = plans[pi];
-            Lane& L = lanes[pi % NS];
-            hipStream_t ls = L.st;
+            if ((phase == 1 || phase == 3) && !p.panel) continue;
+            Lane& L = phase == 1 ? lanes[0] : (two_phase && p.panel ? plane[pi] : lanes[pi % NS]);
+            hipStream_t ls = phase == 1 ? st : L.st;
+            const bool do_build = !(phase >= 2 && p.panel), do_score = phase != 1;
+            const PanelPtrs PP = two_phase && p.panel ? PanelPtrs{pbuf[pi].Gp.get(), pbuf[pi].Bmax64.get(), pbuf[pi].Brep.get(), pbuf[pi].amax64.get(), pbuf[pi].bmax64.get()}
+                                                      : PanelPtrs{L.Gp.get(), L.Bmax64.get(), L.Brep.get(), L.amax64.get(), L.bmax64.get()};
             const int c = p.c;
             const int32_t sbase = p.sbase, pbase = p.pbase, Ic = p.Ic, a = p.a, b = p.b, CH = p.CH, nch = p.nch;
             const int64_t ldm = p.ldm;
@@ -1816,13 +1941,14 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             const double w2s = (1.0 - lambda) * (1.0 - lambda) * (double)h_gscale[(size_t)c];     // (1-l)^2 and the packed format's 2^-c
             MEpilogue ME{L.M.get(), ldm, (float)w2s, fxk >= 0 ? std::ldexp(w2s, -fxk) : 0.0,
                          pack24 ? 1 : 0, (p.prune && !p.panel) ? L.Bmax.get() : nullptr, p.ldb, 0,
-                         p.panel ? p.panel_cols : 0, p.panel ? L.Bmax64.get() : nullptr, p.ldb64, p.panel ? L.Brep.get() : nullptr};
+                         p.panel ? p.panel_cols : 0, p.panel ? PP.Bmax64 : nullptr, p.ldb64, p.panel ? PP.Brep : nullptr};
+            if (p.panel) ME.M = PP.Gp;
+            if (do_build) {
             if (p.panel) {
                 R->st.panel_clusters++;
-                ME.M = L.Gp.get();
-                FY_HIP(hipMemsetAsync(L.Bmax64.get(), 0, (size_t)Ic * p.ldb64 * 3, ls));
-                k_block_amax<<<grid_for(p.ldb64), 256, 0, ls>>>(Ic, (int32_t)p.ldb64, a_rank.get() + pbase, b_rank32.get() + pbase, L.amax64.get(),
-                                                               L.bmax64.get(), 64);
+                FY_HIP(hipMemsetAsync(PP.Bmax64, 0, (size_t)Ic * p.ldb64 * 3, ls));
+                k_block_amax<<<grid_for(p.ldb64), 256, 0, ls>>>(Ic, (int32_t)p.ldb64, a_rank.get() + pbase, b_rank32.get() + pbase, PP.amax64,
+                                                               PP.bmax64, 64);
                 FY_KERNEL_CHECK();
             } else if (p.prune) {
                 FY_HIP(hipMemsetAsync(L.Bmax.get(), 0, (size_t)Ic * p.ldb * 3, ls));
@@ -1830,20 +1956,26 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 FY_KERNEL_CHECK();
             }
             const size_t sp = t_cooc.begin(ls);
+            const bool batched = phase == 1 && tune.panel_multi_launch && use_pk && fxk >= 0 && !tune.cooc_f32;     // (k_cooc_rm2_multi)
             if (p.p_eff < Ic) {   // panel mode: bounds of the tail rows behind p_eff (one item per row, see k_tail_blocks)
                 CoocArgs CB{P.rank_pair.get(), P.pair_start.get(), segs_tail[pi].ptr_(), segs_tail[pi].seg_(), segs_tail[pi].w_(), P.csr_idx.get(),
                             csr_x.get(), pbase, sbase, Ic, p.tail_width, 1, p.p_eff, Ic - p.p_eff, p.q0, p.nq, nullptr, 0, y_pk.get(), nullptr, CA.pk_bytes};
                 CB.fx_scale = CA.fx_scale;
-                MEpilogue MB{reinterpret_cast<float*>(reinterpret_cast<char*>(L.Bmax64.get()) + (size_t)(p.p_eff / 64) * 3), p.tail_width, ME.w2, ME.fx_inv, 1,
+                MEpilogue MB{reinterpret_cast<float*>(reinterpret_cast<char*>(PP.Bmax64) + (size_t)(p.p_eff / 64) * 3), p.tail_width, ME.w2, ME.fx_inv, 1,
                              nullptr, 0, 0, 0, nullptr, 0, nullptr, p.ldb64, 1};
-                k_item_list<<<grid_for((int64_t)(Ic - p.p_eff)), 256, 0, ls>>>(CB, L.item_seg.get(), L.item_id.get());
+                int2* const tseg = batched ? plane[pi].item_seg_t.get() : L.item_seg.get();
+                int32_t* const tid = batched ? plane[pi].item_id_t.get() : L.item_id.get();
+                k_item_list<<<grid_for((int64_t)(Ic - p.p_eff)), 256, 0, ls>>>(CB, tseg, tid);
                 FY_KERNEL_CHECK();
-                CB.item_seg = L.item_seg.get();
-                CB.item_id = L.item_id.get();
-                FY_HIP(hipMemsetAsync(L.any_overflow.get(), 0, sizeof(int32_t), ls));
+                CB.item_seg = tseg;
+                CB.item_id = tid;
                 CB.item_grab = 8;      // a tail row's bound item is a handful of segments
-                launch_cooc_rm2(ctx, tune, use_pk, CB, MB, Ic - p.p_eff, L.any_overflow.get(), ls);
-                R->st.cooc_launches++;
+                if (batched) batch_tail.push_back(CoocLaunch{CB, MB, Ic - p.p_eff, 0});
+                else {
+                    FY_HIP(hipMemsetAsync(L.any_overflow.get(), 0, sizeof(int32_t), ls));
+                    launch_cooc_rm2(ctx, tune, use_pk, CB, MB, Ic - p.p_eff, L.any_overflow.get(), ls);
+                    R->st.cooc_launches++;
+                }
                 CA.tail_row0 = p.p_eff;
                 CA.tail_chunks = p.tail_chunks;
             }
@@ -1851,21 +1983,28 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 CA.half = p.half ? 1 : 0;
                 const int n_items = CA.tail_chunks > 0 ? (int)((int64_t)p.p_eff * nch + (int64_t)(Ic - p.p_eff) * p.tail_chunks)
                                                        : (int)cooc_item_count(Ic, CH, nch, p.half);
-                k_item_list<<<grid_for((int64_t)Ic * nch), 256, 0, ls>>>(CA, L.item_seg.get(), L.item_id.get());
+                int2* const mseg = batched ? plane[pi].item_seg.get() : L.item_seg.get();
+                int32_t* const mid = batched ? plane[pi].item_id.get() : L.item_id.get();
+                k_item_list<<<grid_for((int64_t)Ic * nch), 256, 0, ls>>>(CA, mseg, mid);
                 FY_KERNEL_CHECK();
-                CA.item_seg = L.item_seg.get();
-                CA.item_id = L.item_id.get();
-                FY_HIP(hipMemsetAsync(L.any_overflow.get(), 0, sizeof(int32_t), ls));   // reused as the item counter
+                CA.item_seg = mseg;
+                CA.item_id = mid;
                 CA.item_grab = cooc_item_grab(((size_t)c < P.cluster_deg2.size() ? P.cluster_deg2[c] : P.sum_deg2) / (p.half ? 2 : 1), n_items);
-                launch_cooc_rm2(ctx, tune, use_pk, CA, ME, n_items, L.any_overflow.get(), ls);
+                if (batched) batch_main.push_back(CoocLaunch{CA, ME, n_items, 0});
+                else {
+                    FY_HIP(hipMemsetAsync(L.any_overflow.get(), 0, sizeof(int32_t), ls));   // reused as the item counter
+                    launch_cooc_rm2(ctx, tune, use_pk, CA, ME, n_items, L.any_overflow.get(), ls);
+                }
             }
             t_cooc.end(sp, ls);
-            R->st.cooc_launches++;
+            if (!batched) R->st.cooc_launches++;
             if (p.half) {    // lower triangle + the block maxima in front of / on the diagonal
                 const size_t sm = t_mirror.begin(ls);
                 launch_mirror(ctx, L.M.get(), ldm, Ic, p.prune ? L.Bmax.get() : nullptr, p.ldb, ls);
                 t_mirror.end(sm, ls);
             }
+            }      // do_build
+            if (!do_score) continue;
 
             // -- scoring + top-N in user batches that fit the score scratch
             const int64_t ldS = ldm, B = p.B;
@@ -1916,6 +2055,9 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 if (!p.prune) { full_pass(s0, nb, L.S.get()); continue; }
                 const int seed_chunks = std::min(n_chunks, tune.seed_chunks);
                 const int n_slices = score_slices(ctx, tune, nb, seed_chunks + (int)(p.ldb / 256));
+                // front in phase 2, back in phase 3 (the whole cluster in one batch: its CSR range is on the host already)
+                const bool split = two_phase && p.panel && s0 == sbase && nb == p.Uc;
+                if (phase == 3 && !split) continue;
                 size_t ss = t_score.begin(ls);
                 const int seed_blocks = seed_chunks;
                 const int64_t SC = (int64_t)seed_chunks * 256;   // pitch of the compact score rows: seed columns only
@@ -1924,7 +2066,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 // of all 256-column blocks (the same kernel on the block-maximum matrix); the grid's tail -- the waves
                 // that walk the heaviest users -- is paid once instead of twice
                 // panel mode: the stored rows are panel_cols wide and the bound matrix has one column per 64-column sub-block
-                const float* Gmat = p.panel ? L.Gp.get() : L.M.get();
+                const float* Gmat = p.panel ? PP.Gp : L.M.get();
                 const int64_t gld = p.panel ? (int64_t)p.panel_cols : ldm;
                 // (A two-level bound -- 256-column block maxima first, the 64-column sub-block bounds only for the surviving blocks -- was
                 // built and measured in round 3: the first level reads a quarter of the bytes, but five times as many blocks reach the
@@ -1932,13 +2074,15 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 // clusters.  Removed.)
                 const int64_t bld = p.panel ? p.ldb64 : p.ldb;           // pitch of the bound matrix, of UB and of the survivor lists
                 const int bchunks = (int)(bld / 256);
+                int32_t hv[3] = {0, 0, 0};   // survivors, first / last CSR entry of the batch
+                if (phase != 3) {
                 ScoreArgs SA = score_args(Gmat, gld, Ic, a_rank.get() + pbase, s0, nb, L.S.get(), SC, n_slices, seed_chunks + bchunks);
                 SA.chunks1 = seed_chunks;
-                SA.M2 = p.panel ? L.Bmax64.get() : L.Bmax.get();
+                SA.M2 = p.panel ? PP.Bmax64 : L.Bmax.get();
                 SA.ldm2 = bld;
                 SA.Ic2 = p.panel ? p.nsub : p.nblk;
-                SA.a2 = p.panel ? L.amax64.get() : L.amax.get();
-                SA.b2 = p.panel ? L.bmax64.get() : L.bmax.get();
+                SA.a2 = p.panel ? PP.amax64 : L.amax.get();
+                SA.b2 = p.panel ? PP.bmax64 : L.bmax.get();
                 SA.S2 = L.UB.get();
                 SA.ldS2 = bld;
                 SA.no_mask2 = 1;
@@ -1962,15 +2106,21 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 if (p.panel && tune.panel_repair) {
                     // (4b) sub-blocks that hold an item the user rated: bound again without the user's own co-ratings
                     RepairArgs RA{L.surv.get(), L.surv_mask.get(), L.n_quads.get(), bld, nb, s0, lo, p.p_eff, Ic, P.rowptr.get(), P.csr_idx.get(),
-                                  csr_x.get(), csr_e.get(), csr_q.get(), L.Bmax64.get(), L.Brep.get(), p.ldb64, L.amax64.get(), L.bmax64.get(),
+                                  csr_x.get(), csr_e.get(), csr_q.get(), PP.Bmax64, PP.Brep, p.ldb64, PP.amax64, PP.bmax64,
                                   L.tau.get(), pvpi.get(), (float)w2s, prune_counters.get()};
                     k_bound_repair<<<std::min<int>(nb, ctx->num_cus * 16), 256, 0, ls>>>(RA);
                     FY_KERNEL_CHECK();
                 }
                 exclusive_scan_i32(ctx, L.n_quads.get(), L.quad_prefix.get(), (size_t)nb + 1, ls);
+                if (split) {      // the count goes to pinned memory; the host does not wait here
+                    FY_HIP(hipMemcpyAsync(&guard.pinned[pi], L.quad_prefix.get() + nb, sizeof(int32_t), hipMemcpyDeviceToHost, ls));
+                    t_score.end(ss, ls);
+                    continue;
+                }
+                }      // phase != 3
                 // (5) exact scores of the survivors, packed: 256 floats per surviving block at entry quad_prefix[u] + k
-                int32_t hv[3] = {0, 0, 0};   // survivors, first / last CSR entry of the batch
-                FY_HIP(hipMemcpyAsync(&hv[0], L.quad_prefix.get() + nb, sizeof(int32_t), hipMemcpyDeviceToHost, ls));
+                if (!split) FY_HIP(hipMemcpyAsync(&hv[0], L.quad_prefix.get() + nb, sizeof(int32_t), hipMemcpyDeviceToHost, ls));
+                else hv[0] = guard.pinned[pi];
                 if (s0 == sbase && nb == p.Uc) {      // the whole cluster: its CSR range is on the host already
                     hv[1] = csr_range[2 * pi];
                     hv[2] = csr_range[2 * pi + 1];
@@ -1978,7 +2128,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                     FY_HIP(hipMemcpyAsync(&hv[1], P.rowptr.get() + s0, sizeof(int32_t), hipMemcpyDeviceToHost, ls));
                     FY_HIP(hipMemcpyAsync(&hv[2], P.rowptr.get() + s0 + nb, sizeof(int32_t), hipMemcpyDeviceToHost, ls));
                 }
-                FY_HIP(hipStreamSynchronize(ls));   // (everything queued on this lane before has finished: Ssurv may be re-sized)
+                if (!split) FY_HIP(hipStreamSynchronize(ls));   // (everything queued on this lane before has finished: Ssurv may be re-sized)
                 const int32_t n_surv_total = hv[0];
                 const int64_t blocks_checked = (int64_t)nb * std::max(0, p.nblk - seed_blocks);
                 if (!p.panel && (double)n_surv_total > tune.max_surv_frac * (double)blocks_checked) {     // (panel mode has no full matrix to fall back on)
@@ -2041,6 +2191,14 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 t_topn.end(tt, ls);
             }
         }
+        if (phase == 1 && (!batch_main.empty() || !batch_tail.empty())) {     // the row kernels of all panel clusters: two launches
+            const size_t sp = t_cooc.begin(st);
+            launch_cooc_rm2_multi(ctx, tune, batch_tail, true, d_batch_tail, d_cnt_tail, st);
+            launch_cooc_rm2_multi(ctx, tune, batch_main, false, d_batch_main, d_cnt_main, st);
+            t_cooc.end(sp, st);
+            R->st.cooc_launches += (batch_tail.empty() ? 0 : 1) + 1;
+        }
+        }      // phase
         if (NS > 1) {   // join: the main stream continues after every lane has drained
             for (int l = 0; l < NS; l++) {
                 hipEvent_t done;
