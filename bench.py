@@ -367,6 +367,10 @@ def main():
                                            "achieved": 8.0 * sst["unordered_pairs"] / world / (sst["ms_cooc"] * 1e-3) / 1e9 if sst["ms_cooc"] > 0 else 0.0,
                                            "peak": HBM_PEAK_GBS, "unit": "GB/s"}}
             out["itemsim"]["roofline"]["frac"] = out["itemsim"]["roofline"]["achieved"] / HBM_PEAK_GBS
+            if traffic and sst["isim_candidates"]:
+                fam = [traffic.get(k, {}).get("hbm_bytes_per_launch") for k in ("itemsim_walk", "k_isim_sweep", "k_isim_finish")]
+                out["itemsim"]["roofline"]["traffic"] = sum(fam) if all(x is not None for x in fam) else None
+                out["itemsim"]["roofline"]["algorithmic_bytes"] = 8.0 * sst["unordered_pairs"]
         except RuntimeError as e:
             out["itemsim"] = {"error": str(e)}
 

@@ -16,6 +16,7 @@ w = open(d + "/summary_pmc_write.txt").read()
 def family(prefix):
     fs = ws = 0.0
     n = 0
+    prefix = re.escape(prefix)
     for m in re.finditer(r"^(?:void )?fy::(%s[^\s]*(?: [^\s=]+)*?)\s+FETCH_SIZE=([0-9.e+]+) \(n=(\d+)\)" % prefix, f, re.M):
         fs += float(m.group(2))
         n += int(m.group(3))
@@ -36,7 +37,9 @@ def source_rev():
 
 
 out = {"source_rev": sys.argv[2] if len(sys.argv) > 2 else source_rev(),
-       "k_cooc_rm2": family("k_cooc_rm2"), "k_mirror": family("k_mirror"), "k_score": family("k_score"),
+       # the RM2 matrix build (64-bit fixed point) and the item-similarity walk (32-bit) are two instantiations of one kernel
+       "k_cooc_rm2": family("k_cooc_rm2<true, unsigned long long"), "k_mirror": family("k_mirror"), "k_score": family("k_score"),
+       "itemsim_walk": family("k_cooc_rm2<true, unsigned int"), "k_isim_sweep": family("k_isim_sweep"), "k_isim_finish": family("k_isim_finish"),
        "note": "FETCH_SIZE (KB) doubled per MI355X_MICROARCH.md; summed over the launches of the profiled jobs and divided by "
                "their number; config: ml25m shape, numberOfClusters 1, top-50 (python3 bench.py --steps 1 --warmup 1 --no-cpu)"}
 json.dump(out, open(d + "/traffic.json", "w"), indent=1)
