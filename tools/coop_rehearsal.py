@@ -93,6 +93,7 @@ def main():
                     report[rep] = {"busy_ms": [round(1e3 * x, 2) for x in group.busy_s],
                                    "ms_cooc": [round(o[1]["ms_cooc"], 2) for o in out],
                                    "ms_prepare": [round(o[1]["ms_prepare"], 2) for o in out],
+                                   "prepared_from_cache": [int(o[1]["prepared_from_cache"]) for o in out],   # rep 0 = cold jobs, later reps warm
                                    "comm_MB_sent_per_rank": round(comms[0].calls["bytes"] / 1e6, 1), "calls": dict(comms[0].calls),
                                    "phases_rank0": [(w, round(1e3 * d, 2)) for w, d in group.busy_log[0]],
                                    "phases_last_rank": [(w, round(1e3 * d, 2)) for w, d in group.busy_log[W - 1]]}
