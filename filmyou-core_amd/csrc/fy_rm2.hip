@@ -2092,7 +2092,11 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 TopNArgs T1{L.S.get(), SC, Ic, n_out.get(), out_off.get(), P.rank_item_raw.get() + pbase, P.slot2du.get(), P.uid.get(),
                             lo, s0, c, R->d_key0.get(), R->d_key1.get(), R->d_value.get(), R->d_aux.get(),
                             1, seed_chunks * 256, L.surv.get(), L.n_quads.get(), bld, L.tau.get()};
-                k_topn_fast<<<nb, 256, 0, ls>>>(T1, L.overflow.get(), L.any_overflow.get(), 0);
+                {
+                    int lp2 = 64;                   // the sort's size: the seed columns, at most TOPN_SAMPLE
+                    while (lp2 < std::min<int>(std::min<int>(Ic, seed_chunks * 256), TOPN_SAMPLE)) lp2 <<= 1;
+                    k_topn_seed<<<(nb + 3) / 4, 256, (size_t)4 * lp2 * sizeof(uint64_t), ls>>>(T1, nb, L.overflow.get(), lp2);
+                }
                 FY_KERNEL_CHECK();
                 // (4) the blocks whose bound reaches tau_u, in ascending order
                 FY_HIP(hipMemsetAsync(L.n_quads.get(), 0, ((size_t)nb + 1) * sizeof(int32_t), ls));
