@@ -110,7 +110,8 @@ __device__ __forceinline__ SegBatch cooc_first_batch(const CoocArgs& A, int s_be
 // The unpacked walk (8-byte CSR entries: ratings that are not fp16-exact).  ACC = double: ds_add_f64.  (ACC = float, ds_add_f32,
 // is a MEASUREMENT build only, FY_COOC_F32: 193 cycles per wave instruction on gfx950 against 21 for ds_add_f64 -- 4x slower.)
 template <bool PK, class ACC>
-__device__ __forceinline__ void cooc_accumulate_segments(const CoocArgs& A, ACC* __restrict__ acc, int s_begin, int s_end, int c0, SegBatch first) {
+__device__ __forceinline__ void cooc_accumulate_segments(const CoocArgs& A, ACC* __restrict__ acc, int s_begin, int s_end, int c0, SegBatch first,
+                                                         int rmask = -1 /* symmetric walk, own chunk: only columns > rmask (chunk-relative) count */) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = blockDim.x >> 6;
@@ -159,7 +160,7 @@ __device__ __forceinline__ void cooc_accumulate_segments(const CoocArgs& A, ACC*
         }
 #pragma unroll
         for (int q = 0; q < NB; q++)
-            if (lane < G.L[q]) atomicAdd(&acc[cooc_acc_index(G.idx[q], A.acc_quarter)], (ACC)G.W[q] * (ACC)G.x[q]);   // ds_add_f64 / ds_add_f32
+            if (lane < G.L[q] && G.idx[q] > rmask) atomicAdd(&acc[cooc_acc_index(G.idx[q], A.acc_quarter)], (ACC)G.W[q] * (ACC)G.x[q]);   // ds_add_f64 / ds_add_f32
     };
     int batch = 0;
     if (cooc_seg_slot(s_begin, 0, wave, nwaves, 0) >= s_end) return;
@@ -222,7 +223,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t cooc_pk_rsrc(const CoocArgs& A
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(A.csr_pk), 0, (int)A.pk_bytes, 0x00020000);
 }
 template <class ACC>
-__device__ __forceinline__ void cooc_accumulate_pk(const CoocArgs& A, ACC* __restrict__ acc, int s_begin, int s_end, SegBatch first) {
+__device__ __forceinline__ void cooc_accumulate_pk(const CoocArgs& A, ACC* __restrict__ acc, int s_begin, int s_end, SegBatch first,
+                                                   int rmask = -1 /* symmetric walk, own chunk: only columns > rmask (chunk-relative) count */) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = blockDim.x >> 6;
@@ -240,15 +242,15 @@ __device__ __forceinline__ void cooc_accumulate_pk(const CoocArgs& A, ACC* __res
                 // 32-bit fixed point (item similarity on ratings that are multiples of 2^-m, fx_scale = 2^2m): every product is an
                 // integer below 2^24 -- exact in fp32 -- and every sum stays below 2^32 (fy_rm2.hip: gram_half_build): ds_add_u32
                 const uint32_t v = (uint32_t)(G.W[q] * x * (float)fx);
-                if (lane < G.L[q]) atomicAdd(&acc[cooc_acc_index((int)(G.pk[q] & 0xFFFFu), A.acc_quarter)], v);   // ds_add_u32
+                if (lane < G.L[q] && (int)(G.pk[q] & 0xFFFFu) > rmask) atomicAdd(&acc[cooc_acc_index((int)(G.pk[q] & 0xFFFFu), A.acc_quarter)], v);   // ds_add_u32
             } else if constexpr (std::is_same<ACC, unsigned long long>::value) {
                 // round(p * 2^k) without a 64-bit conversion: p * 2^k + 2^52 has the integer in its mantissa (0 <= p * 2^k < 2^52)
                 const double d = fma((double)(G.W[q] * x), fx, 4503599627370496.0);
                 const unsigned long long v = (unsigned long long)__double_as_longlong(d) & 0xFFFFFFFFFFFFFull;
-                if (lane < G.L[q]) atomicAdd(&acc[cooc_acc_index((int)(G.pk[q] & 0xFFFFu), A.acc_quarter)], v);   // ds_add_u64
+                if (lane < G.L[q] && (int)(G.pk[q] & 0xFFFFu) > rmask) atomicAdd(&acc[cooc_acc_index((int)(G.pk[q] & 0xFFFFu), A.acc_quarter)], v);   // ds_add_u64
             } else {
                 const ACC v = (ACC)(G.W[q] * x);
-                if (lane < G.L[q]) atomicAdd(&acc[cooc_acc_index((int)(G.pk[q] & 0xFFFFu), A.acc_quarter)], v);   // ds_add_f64
+                if (lane < G.L[q] && (int)(G.pk[q] & 0xFFFFu) > rmask) atomicAdd(&acc[cooc_acc_index((int)(G.pk[q] & 0xFFFFu), A.acc_quarter)], v);   // ds_add_f64
             }
         }
     };
@@ -382,7 +384,10 @@ struct SegTable {
 void build_segments(Context* ctx, const int32_t* csc_slot, const float* csc_w, const int32_t* chunk_off, int32_t slot_base,
                     int32_t q0, int32_t nq, int32_t nch, SegTable& out, hipStream_t st = nullptr,
                     const int32_t* half_row_of_entry = nullptr, const int32_t* csr_idx = nullptr, int32_t CH = 0,
-                    const int32_t* only_rows_of_entry = nullptr, int32_t only_rows_from = 0, int64_t max_segments = 0);
+                    const int32_t* only_rows_of_entry = nullptr, int32_t only_rows_from = 0, int64_t max_segments = 0,
+                    const int32_t* samples = nullptr);
+// every 64th entry of csr_idx: what the symmetric cut of the segment tables searches instead of the rows themselves
+void build_csr_samples(Context* ctx, int64_t nnz, const int32_t* csr_idx, DevBuf<int32_t>& samp, hipStream_t st = nullptr);
 
 // chunk_off table for one cluster: one thread per (slot, boundary)
 void build_chunk_offsets(Context* ctx, const int32_t* rowptr, const int32_t* csr_idx, int32_t slot_base, int32_t n_slots,

@@ -375,11 +375,16 @@ void build_chunk_offsets(Context* ctx, const int32_t* rowptr, const int32_t* csr
 // fills the lower triangle (k_mirror_*).  For the CSC entry (rater v, row i) the chunks in front of i's own chunk have no
 // segments, and in i's chunk the rater's slice starts behind the position of i in the rater's CSR row (`Half::start`,
 // found once by a binary search in k_seg_counts and re-used by k_seg_fill).
+#ifndef FY_SAMPLE_SHIFT
+#define FY_SAMPLE_SHIFT 6     // the symmetric cut searches every 64th CSR entry (measured, ML-25M job, tables / row kernel ms: exact cut 4.57 / 7.84; stride 64: 2.96 / 8.48 = 25.6 ms per job; stride 16: 3.23 / 8.21 = 25.7; Netflix shape 77.1 / 79.1 ms per job)
+#endif
 struct Half {
     const int32_t* __restrict__ row_of_entry;   // [q0 + q]: the row (rank inside the cluster) of CSC entry q; nullptr = full walk
     const int32_t* __restrict__ csr_idx;
     int32_t CH;
-    int32_t* __restrict__ start;                // [q]: first CSR entry behind (v, i) (scratch, nq entries)
+    int32_t* __restrict__ start;                // [q]: where the slice of CSC entry q starts in the row's own chunk: the 64-entry-aligned CSR
+                                                // position in front of (v, i) -- the row kernel masks the entries at or before column i
+    const int32_t* __restrict__ samp;           // [k] = csr_idx[64 k]: every 64th CSR entry (k_csr_samples)
     // tail-row launches (column-panel mode): entries of the rows in front of only_from get no segments
     const int32_t* __restrict__ only_rows;      // [q0 + q]: row of the entry; nullptr = all rows
     int32_t only_from;
@@ -395,11 +400,17 @@ __device__ __forceinline__ void seg_counts_body(const int32_t* __restrict__ csc_
         if (live && H.row_of_entry) {
             const int32_t r = H.row_of_entry[q0 + q];
             own = r / H.CH;
-            int32_t lo = co[own], hi = co[own + 1];          // first entry with idx > r (r itself is in this range)
-            while (lo < hi) {
-                const int32_t mid = (lo + hi) >> 1;
-                if (H.csr_idx[mid] <= r) lo = mid + 1; else hi = mid;
+            // Where does the slice behind (v, i) start?  Exactly: behind the position of i in the rater's row -- a binary search over the
+            // row slice in the 100-400 MB csr_idx per CSC entry (1.6 ms of the ML-25M job, 10.6 ms at Netflix shape, round 2).  Now: the
+            // last aligned CSR position inside the slice whose entry is <= r, found in the SAMPLES (every 2^FY_SAMPLE_SHIFT-th entry: a few MB,
+            // cache-resident, a handful of probes); the few entries between it and i are masked by the row kernel (column <= row).
+            constexpr int SS = FY_SAMPLE_SHIFT;
+            int32_t klo = (co[own] + (1 << SS) - 1) >> SS, khi = (co[own + 1] + (1 << SS) - 1) >> SS;      // samples inside the slice: [klo, khi)
+            while (klo < khi) {                                                    // first k with samp[k] > r
+                const int32_t mid = (klo + khi) >> 1;
+                if (H.samp[mid] <= r) klo = mid + 1; else khi = mid;
             }
+            const int32_t lo = max(co[own], (klo - 1) << SS);                     // (no sample <= r inside the slice: its beginning)
             behind = lo;
             H.start[q] = lo;
         }
@@ -430,9 +441,9 @@ struct SegDesc {
 };
 __global__ void k_seg_counts_multi(const SegDesc* __restrict__ D, const int32_t* __restrict__ csc_slot, const int32_t* __restrict__ co_all,
                                    int32_t* __restrict__ cnt_all, const int32_t* __restrict__ row_of_entry, const int32_t* __restrict__ csr_idx,
-                                   int32_t* __restrict__ start_all) {
+                                   int32_t* __restrict__ start_all, const int32_t* __restrict__ samples) {
     const SegDesc d = D[blockIdx.y];
-    const Half H{d.half ? row_of_entry : nullptr, csr_idx, d.CH, start_all + d.q0, d.use_only_rows ? row_of_entry : nullptr, d.only_from};
+    const Half H{d.half ? row_of_entry : nullptr, csr_idx, d.CH, start_all + d.q0, samples, d.use_only_rows ? row_of_entry : nullptr, d.only_from};
     seg_counts_body(csc_slot, co_all + d.co_off, d.slot_base, d.q0, d.nq, d.nch, cnt_all + d.cnt_off, H);
 }
 
@@ -501,7 +512,7 @@ __global__ void k_seg_fill_multi(const SegDesc* __restrict__ D, const int32_t* _
                                  const int32_t* __restrict__ co_all, const int32_t* __restrict__ ptr_all, int2* __restrict__ seg, float* __restrict__ seg_w,
                                  const int32_t* __restrict__ row_of_entry, const int32_t* __restrict__ csr_idx, int32_t* __restrict__ start_all) {
     const SegDesc d = D[blockIdx.y];
-    const Half H{d.half ? row_of_entry : nullptr, csr_idx, d.CH, start_all + d.q0, d.use_only_rows ? row_of_entry : nullptr, d.only_from};
+    const Half H{d.half ? row_of_entry : nullptr, csr_idx, d.CH, start_all + d.q0, nullptr, d.use_only_rows ? row_of_entry : nullptr, d.only_from};
     seg_fill_body(csc_slot, csc_w, co_all + d.co_off, d.slot_base, d.q0, d.nq, d.nch, ptr_all + d.cnt_off, seg, seg_w, H);
 }
 // chunk offsets / packed CSR / block-compressed tail CSR of all planned clusters: blockIdx.y = cluster of the plan
@@ -524,15 +535,27 @@ __global__ __launch_bounds__(256) void k_tail_blocks_multi(const CoDesc* __restr
     if (!d.has_tail) return;       // block-uniform
     tail_blocks_body(d.slot_base, d.n_slots, d.p_eff, rowptr, csr_idx, csr_r, y_pk, co_tail_all + d.co_tail_off);
 }
+__global__ void k_csr_samples(int64_t n_samples, const int32_t* __restrict__ csr_idx, int32_t* __restrict__ samp) {
+    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n_samples; k += (int64_t)gridDim.x * blockDim.x) samp[k] = csr_idx[k << FY_SAMPLE_SHIFT];
+}
+// every 64th entry of csr_idx (what the symmetric cut of the segment tables searches, Half::samp)
+void build_csr_samples(Context* ctx, int64_t nnz, const int32_t* csr_idx, DevBuf<int32_t>& samp, hipStream_t st) {
+    const int64_t n = (nnz + (1 << FY_SAMPLE_SHIFT) - 1) >> FY_SAMPLE_SHIFT;
+    samp.alloc(ctx, (size_t)n + 1);
+    if (n) k_csr_samples<<<grid_for(n), 256, 0, st ? st : ctx->stream>>>(n, csr_idx, samp.get());
+    FY_KERNEL_CHECK();
+}
 void build_segments(Context* ctx, const int32_t* csc_slot, const float* csc_w, const int32_t* chunk_off, int32_t slot_base,
                     int32_t q0, int32_t nq, int32_t nch, SegTable& out, hipStream_t st, const int32_t* half_row_of_entry,
-                    const int32_t* csr_idx, int32_t CH, const int32_t* only_rows_of_entry, int32_t only_rows_from, int64_t max_segments) {
+                    const int32_t* csr_idx, int32_t CH, const int32_t* only_rows_of_entry, int32_t only_rows_from, int64_t max_segments,
+                    const int32_t* samples) {
+    if (half_row_of_entry && !samples) FY_FAIL(FY_ERR_STATE, "internal: the symmetric segment table needs the CSR samples");
     if (!st) st = ctx->stream;
     const size_t np = (size_t)nch * ((size_t)nq + 1);
     out.ptr.alloc(ctx, np);
     out.cnt.alloc(ctx, np);
     out.scratch.alloc(ctx, half_row_of_entry ? (size_t)nq + 1 : 1);
-    const Half H{half_row_of_entry, csr_idx, CH, out.scratch.get(), only_rows_of_entry, only_rows_from};
+    const Half H{half_row_of_entry, csr_idx, CH, out.scratch.get(), samples, only_rows_of_entry, only_rows_from};
     k_seg_counts<<<grid_for((int64_t)nq + 1), 256, 0, st>>>(csc_slot, chunk_off, slot_base, q0, nq, nch, out.cnt.get(), H);
     FY_KERNEL_CHECK();
     exclusive_scan_i32(ctx, out.cnt.get(), out.ptr.get(), np, st);
@@ -749,8 +772,12 @@ __device__ __forceinline__ void cooc_rm2_body(const CoocArgs& A, const MEpilogue
             if (next < n_items) { se_next = A.item_seg[next]; id_next = A.item_id[next]; }   // address known since the previous item
         }
         const int c0 = (id & 255) * A.CH;
-        if constexpr (PK) cooc_accumulate_pk<ACC>(A, acc, s0, s1, batch);
-        else cooc_accumulate_segments<false, ACC>(A, acc, s0, s1, c0, batch);
+        // symmetric walk: in the row's OWN chunk the slices start at a 64-aligned position in front of the row's column (segment
+        // table: Half::start); the entries at or before it are masked here -- row i accumulates only the columns j > i
+        const int row_of_item = A.row0 + (id >> 8) * (A.row_stride ? A.row_stride : 1);
+        const int rmask = (A.half && row_of_item >= c0 && row_of_item < c0 + A.CH) ? row_of_item - c0 : -1;
+        if constexpr (PK) cooc_accumulate_pk<ACC>(A, acc, s0, s1, batch, rmask);
+        else cooc_accumulate_segments<false, ACC>(A, acc, s0, s1, c0, batch, rmask);
         // (every thread read sh_* of THIS item before the barrier that ended the previous epilogue)
         if (threadIdx.x == 0) { sh_item = next; sh_s0 = se_next.x; sh_s1 = se_next.y; sh_id = id_next; }
         __syncthreads();     // all atomics of this item are done; the next item is published
@@ -960,7 +987,7 @@ struct TableCache {
     bool have_x = false;
     DevBuf<float> csc_x, csc_x_over_s;  // x = r / s_v (and x / s_v for the packed walk) per CSC entry: ratings only
     DevBuf<uint32_t> csr_pk, y_pk;      // packed CSR (chunk-relative columns), block-compressed CSR of the tail rows
-    DevBuf<int32_t> csc_rank;
+    DevBuf<int32_t> csc_rank, samples;      // row of every CSC entry; every 64th CSR entry (symmetric cut)
     std::vector<SegTable> segs, segs_tail;
     // many clusters: ONE table over all of them (build_tables_all); segs / segs_tail are then views into these
     DevBuf<int32_t> g_co, g_co_tail, g_cnt, g_ptr, g_start;
@@ -1115,7 +1142,9 @@ bool fy::gram_half_build(Context* ctx, const Prepared& P, const float* csc_w, co
     k_csc_rank<<<grid_for(P.nnz), 256, 0, st>>>(P.nnz, P.csc_pair.get(), P.pair_rank.get(), csc_rank.get());
     FY_KERNEL_CHECK();
     SegTable segs;
-    build_segments(ctx, P.csc_slot.get(), csc_w, co.get(), 0, 0, (int32_t)P.nnz, nch, segs, st, csc_rank.get(), P.csr_idx.get(), CH);
+    DevBuf<int32_t> samples;
+    build_csr_samples(ctx, P.nnz, P.csr_idx.get(), samples, st);
+    build_segments(ctx, P.csc_slot.get(), csc_w, co.get(), 0, 0, (int32_t)P.nnz, nch, segs, st, csc_rank.get(), P.csr_idx.get(), CH, nullptr, 0, 0, samples.get());
     CoocArgs CA{P.rank_pair.get(), P.pair_start.get(), segs.ptr.get(), segs.seg.get(), segs.w.get(), P.csr_idx.get(), nullptr, 0, 0, Ic, CH, nch,
                 0, Ic, 0, (int32_t)P.nnz, nullptr, 0, csr_pk.get(), nullptr, (uint32_t)std::min<int64_t>((int64_t)P.nnz * 4, 0xFFFFFFFFll)};
     CA.half = 1;
@@ -1278,10 +1307,10 @@ static void build_tables_all(Context* ctx, const Prepared& P, const std::vector<
     // main tables read g_co, tail tables g_co_tail: two launches of the count / fill kernels (the offsets are relative to either array)
     const unsigned n_main = (unsigned)np, n_tail = (unsigned)(hsd.size() - np);
     const dim3 g_q((unsigned)grid_for((int64_t)max_nq + 1, 256, 2048), n_main), g_qt((unsigned)grid_for((int64_t)max_nq + 1, 256, 2048), std::max(1u, n_tail));
-    k_seg_counts_multi<<<g_q, 256, 0, st>>>(d_sd.get(), P.csc_slot.get(), tc.g_co.get(), tc.g_cnt.get(), tc.csc_rank.get(), P.csr_idx.get(), tc.g_start.get());
+    k_seg_counts_multi<<<g_q, 256, 0, st>>>(d_sd.get(), P.csc_slot.get(), tc.g_co.get(), tc.g_cnt.get(), tc.csc_rank.get(), P.csr_idx.get(), tc.g_start.get(), tc.samples.get());
     FY_KERNEL_CHECK();
     if (n_tail) {
-        k_seg_counts_multi<<<g_qt, 256, 0, st>>>(d_sd.get() + np, P.csc_slot.get(), tc.g_co_tail.get(), tc.g_cnt.get(), tc.csc_rank.get(), P.csr_idx.get(), tc.g_start.get());
+        k_seg_counts_multi<<<g_qt, 256, 0, st>>>(d_sd.get() + np, P.csc_slot.get(), tc.g_co_tail.get(), tc.g_cnt.get(), tc.csc_rank.get(), P.csr_idx.get(), tc.g_start.get(), tc.samples.get());
         FY_KERNEL_CHECK();
     }
     FY_HIP(hipMemsetAsync(tc.g_cnt.get() + cnt_total, 0, sizeof(int32_t), st));
@@ -1774,6 +1803,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             if (any_half) {
                 k_csc_rank<<<grid_for(P.nnz), 256, 0, st>>>(P.nnz, P.csc_pair.get(), P.pair_rank.get(), csc_rank.get());
                 FY_KERNEL_CHECK();
+                build_csr_samples(ctx, P.nnz, P.csr_idx.get(), tc.samples, st);
             }
         }
         // first / last CSR entry of every planned cluster (slots are cluster-major): one round trip for all of them
@@ -1801,7 +1831,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             const int64_t deg2_c = (size_t)p.c < P.cluster_deg2.size() ? P.cluster_deg2[p.c] : 0;
             const int64_t seg_bound = bounded_tables && deg2_c > 0 ? deg2_c / 64 + (int64_t)p.nq * p.nch + 64 : 0;
             build_segments(ctx, P.csc_slot.get(), use_pk ? csc_x_over_s.get() : csc_x.get(), co, p.sbase, p.q0, p.nq, p.nch, segs[pi], ts,
-                           p.half ? csc_rank.get() : nullptr, P.csr_idx.get(), p.CH, nullptr, 0, seg_bound);
+                           p.half ? csc_rank.get() : nullptr, P.csr_idx.get(), p.CH, nullptr, 0, seg_bound, p.half ? tc.samples.get() : nullptr);
             if (p.p_eff < p.Ic) {
                 k_tail_blocks<<<std::min<int>(p.Uc, ctx->num_cus * 16), 256, 0, ts>>>(p.sbase, p.Uc, p.p_eff, P.rowptr.get(), P.csr_idx.get(), P.csr_r.get(),
                                                                           y_pk.get(), co);
