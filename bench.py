@@ -297,7 +297,10 @@ def main():
                                "(its dense cache would need 77 TB); the reference's own regime is in reference_regime"},
         "cold_or_warm": "cold: every timed job sorts the resident COO ratings into CSR / CSC and builds its tables (FY_RM2_NO_CACHE); see `warm`",
         "lists_per_s": total_users / (elapsed / a.steps), "log_terms_per_step": total_terms,
-        "phase_ms_rank0": phases, "datagen_s": gen_s, "roofline": roofline, "roofline_other_kernel": other,
+        "phase_ms_rank0": phases, "datagen_s": gen_s,
+        "job_stats_rank0": {k: int(st[k]) for k in ("n_clusters_nonempty", "cooc_launches", "score_launches", "panel_clusters", "blocks_total",
+                                                     "blocks_survived", "stray_blocks", "bound_repairs", "prune_fallbacks", "topn_select_users")},
+        "roofline": roofline, "roofline_other_kernel": other,
         "kernel_source_rev": rev,
     }
 

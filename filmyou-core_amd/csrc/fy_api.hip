@@ -43,6 +43,8 @@ void fy::load_tuning_from_env(Tuning& t) {
     if (const char* e = getenv("FY_SCORE_HEAVY")) { int v = atoi(e); if (v >= 0) t.score_heavy = v; }
     if (const char* e = getenv("FY_PANEL_REPAIR")) t.panel_repair = atoi(e) != 0;
     if (const char* e = getenv("FY_PANEL_MULTI_LAUNCH")) t.panel_multi_launch = atoi(e) != 0;
+    if (const char* e = getenv("FY_FLAT")) t.flat_batch = atoi(e) != 0;
+    if (const char* e = getenv("FY_FLAT_BUDGET_MB")) t.flat_budget = (int64_t)atoll(e) << 20;
     if (const char* e = getenv("FY_PANEL_TWO_PHASE")) t.panel_two_phase = atoi(e) != 0;
     if (const char* e = getenv("FY_PANEL_LANES")) { int v = atoi(e); if (v >= 1 && v <= 8) t.panel_lanes = v; }
     if (const char* e = getenv("FY_PRUNE_MIN_ITEMS")) { t.prune_min_items = atoi(e); t.prune_min_users = 0; }   // (a forced item threshold -- tests -- lifts the user threshold too)

@@ -339,7 +339,7 @@ inline int64_t cooc_item_count(int32_t nrows, int32_t CH, int32_t nch, bool half
     if (!half) return (int64_t)nrows * nch;
     return nrows > 0 ? cooc_half_item_index(nrows - 1, nch - 1, CH, nch) + 1 : 0;
 }
-__attribute__((unused)) static __global__ void k_item_list(CoocArgs A, int2* __restrict__ seg_out, int32_t* __restrict__ id_out) {
+__device__ __forceinline__ void item_list_body(const CoocArgs& A, int2* __restrict__ seg_out, int32_t* __restrict__ id_out) {
     const int n = A.nrows * A.nch;
     const int stride = A.row_stride ? A.row_stride : 1;
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
@@ -360,6 +360,9 @@ __attribute__((unused)) static __global__ void k_item_list(CoocArgs A, int2* __r
         seg_out[at] = make_int2(sp[e0], sp[e1]);
         id_out[at] = (lrow << 8) | ch;
     }
+}
+__attribute__((unused)) static __global__ void k_item_list(CoocArgs A, int2* __restrict__ seg_out, int32_t* __restrict__ id_out) {
+    item_list_body(A, seg_out, id_out);
 }
 
 // segment table of one cluster from its chunk_off table; returns the number of segments (synchronises once)

@@ -812,6 +812,11 @@ __global__ void k_cooc_rm2_multi(const CoocLaunch* __restrict__ D, int* __restri
     const MEpilogue E = d.E;
     cooc_rm2_body<PK, ACC>(A, E, d.n_items, counters + blockIdx.y);
 }
+// the item lists of all those launches (CoocArgs::item_seg / item_id name the lists to fill)
+__global__ void k_item_list_multi(const CoocLaunch* __restrict__ D) {
+    const CoocArgs A = D[blockIdx.y].A;
+    item_list_body(A, const_cast<int2*>(A.item_seg), const_cast<int32_t*>(A.item_id));
+}
 
 // ================================================================ mirror pass of the symmetric (half) walk
 // After k_cooc_rm2 with CoocArgs::half, row i of the packed matrix holds the columns j >= 256 * (i / 256) (exact for j > i,
@@ -1177,13 +1182,14 @@ bool fy::gram_half_build(Context* ctx, const Prepared& P, const float* csc_w, co
 // one launch for the row kernels of several clusters (two-phase panel mode; fixed-point packed walk only): `L` = one CoocLaunch per
 // cluster on the host, uploaded here; the launch shape (workgroup size, LDS) is that of the widest chunk among them
 static void launch_cooc_rm2_multi(Context* ctx, const ScoreTune& tune, std::vector<CoocLaunch>& L, bool tail_role, DevBuf<CoocLaunch>& d_launch,
-                                  DevBuf<int32_t>& d_counters, hipStream_t st) {
+                                  DevBuf<int32_t>& d_counters, hipStream_t st, bool item_lists = false /* fill the item lists first */) {
     if (L.empty()) return;
-    int max_chp = 0, max_items = 0;
+    int max_chp = 0, max_items = 0, max_list = 0;
     for (auto& x : L) {
         x.A.acc_quarter = tune.cooc_planes ? cooc_lds_columns(x.A.CH) / 4 : 0;
         max_chp = std::max(max_chp, cooc_lds_columns(x.A.CH));
         max_items = std::max(max_items, x.n_items);
+        max_list = std::max(max_list, x.A.nrows * x.A.nch);
     }
     const size_t lds = (size_t)max_chp * 8;
     const int by_lds = (int)std::max<size_t>(1, (160 * 1024 - 512) / (lds + 64));
@@ -1196,6 +1202,10 @@ static void launch_cooc_rm2_multi(Context* ctx, const ScoreTune& tune, std::vect
     FY_HIP(hipMemcpyAsync(d_launch.get(), L.data(), L.size() * sizeof(CoocLaunch), hipMemcpyHostToDevice, st));
     FY_HIP(hipMemsetAsync(d_counters.get(), 0, L.size() * sizeof(int32_t), st));
     const dim3 grid((unsigned)gx, (unsigned)L.size());
+    if (item_lists) {
+        k_item_list_multi<<<dim3((unsigned)std::max(1, std::min(grid_for(max_list), 4096)), (unsigned)L.size()), 256, 0, st>>>(d_launch.get());
+        FY_KERNEL_CHECK();
+    }
     if (tail_role) k_cooc_rm2_multi<true, unsigned long long, 1><<<grid, block, lds, st>>>(d_launch.get(), d_counters.get());
     else k_cooc_rm2_multi<true, unsigned long long, 0><<<grid, block, lds, st>>>(d_launch.get(), d_counters.get());
     FY_KERNEL_CHECK();
@@ -1217,6 +1227,7 @@ struct Plan {
     int32_t Uc, sbase, pbase, Ic, a, b, CH, nch, q0, nq;
     int64_t ldm, B;
     bool pack24, prune, coop, half, panel;
+    bool flat;       // one of many small unpruned clusters whose kernels run in ONE launch each (fy_rm2_kernels.hpp: FlatDesc)
     int32_t panel_cols, nsub;
     int64_t ldb64;
     // panel mode: the rows from p_eff on ("tail rows") are walked only over their first tail_chunks chunks (= the columns in
@@ -1670,6 +1681,29 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                         p.tail_width = (int32_t)(p.ldb64 - p.p_eff / 64);
                     }
         }
+        const int64_t flat_budget = tune.flat_budget > 0 ? tune.flat_budget : (int64_t)std::min<uint64_t>(ctx->total_mem / 4, (uint64_t)std::max<int64_t>(ws, (int64_t)8 << 30));
+        auto flat_need = [](const Plan& p) {
+            return (int64_t)p.Ic * p.ldm * (p.pack24 ? 3 : 4) + (int64_t)(p.b - p.a) * p.ldm * 4 + (int64_t)p.Ic * p.nch * 12 + 4096;
+        };
+        {   // flat batch: the small unpruned clusters of a multi-cluster job, every kernel of their chain ONE launch for all of them
+            // (FlatDesc, fy_rm2_kernels.hpp).  The matrices and score rows of the clusters of one batch are resident together; a job
+            // whose clusters do not fit the budget takes several batches.
+            int n_flat = 0;
+            const bool can = tune.flat_batch && plans.size() > 1 && use_pk && tune.cooc_fx && !tune.cooc_f32 && !J->fx_bounds.empty() &&
+                             prm.number_of_recommendations <= TOPN_LONG;
+            for (auto& p : plans) {
+                p.flat = false;
+                if (!can || p.prune || p.coop || p.panel) continue;
+                if (fx_exponent(&J->fx_bounds[3 * (size_t)p.c]) < 0) continue;
+                if (flat_need(p) > flat_budget) continue;
+                p.flat = true;
+                n_flat++;
+            }
+            if (n_flat < 2)
+                for (auto& p : plans) p.flat = false;
+            for (auto& p : plans)
+                if (p.flat) p.half = false;      // (a mirror pass per cluster would be two more launches each)
+        }
         bool any_panel = false;
         for (auto& p : plans) any_panel = any_panel || p.panel;
         // Two phases for panel-mode jobs (round 3): the matrix panels of ALL clusters are built first, back to back on the main stream
@@ -1707,15 +1741,16 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
         std::vector<Lane> lanes((size_t)NS);
         {
             size_t is_el = 1;
-            for (auto& p : plans) is_el = std::max(is_el, (size_t)p.Ic * p.nch);
+            for (auto& p : plans)
+                if (!p.flat) is_el = std::max(is_el, (size_t)p.Ic * p.nch);
             size_t m_el = 1, s_el = 1, ov_el = 1, bm_el = 1, ub_el = 1, am_el = 1, gp_el = 1, b64_el = 1, a64_el = 1;
             for (auto& p : plans) {
                 p.B = std::min<int64_t>(std::max<int64_t>(1, (ws / NS) / (p.ldm * 4)), p.b - p.a);
                 // pruned clusters keep only the seed columns of a score row (the survivors' scores are packed, see below):
                 // all users of the rank in one batch
                 const int64_t seed_cols = (int64_t)std::min<int64_t>(ceil_div(p.Ic, 256), tune.seed_chunks) * 256;
-                if (p.prune) p.B = p.b - p.a;
-                if (p.coop) continue;   // allocates for itself
+                if (p.prune || p.flat) p.B = p.b - p.a;
+                if (p.coop || p.flat) continue;   // allocate for themselves
                 if (p.panel) {
                     gp_el = std::max(gp_el, (size_t)p.Ic * p.panel_cols * 3 / 4 + 4);
                     b64_el = std::max(b64_el, (size_t)p.Ic * p.ldb64 * 3 / 4 + 4);
@@ -1785,7 +1820,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
         sig.push_back(use_pk ? 1 : 0);
         sig.push_back(plans.size() > 1 && !any_coop ? 1 : 0);
         for (auto& p : plans) {
-            const int32_t v[8] = {p.c, p.CH, p.nch, p.half ? 1 : 0, p.panel ? 1 : 0, p.p_eff, p.tail_chunks, p.coop ? 1 : 0};
+            const int32_t v[8] = {p.c, p.CH, p.nch, p.half ? 1 : 0, p.panel ? 1 : 0, p.p_eff, p.tail_chunks, (p.coop ? 1 : 0) | (p.flat ? 2 : 0)};
             sig.insert(sig.end(), v, v + 8);
         }
         const bool tables_cached = tc.valid && tc.sig == sig;
@@ -1860,6 +1895,116 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
         // tables and the per-job arrays back into the caching allocator while kernels of OTHER lanes may still be reading
         // them.  The guard drains every lane and the main stream first (members are destroyed in reverse order of
         // declaration: `lanes`, `segs` and the DevBufs above were declared before it, so it runs before they are released).
+        // ---- flat batch (Plan::flat): matrix build, scores and lists of all those clusters, one launch per kernel, on the main stream
+        DevBuf<char> flatM;
+        DevBuf<float> flatS;
+        DevBuf<int2> flat_seg;
+        DevBuf<int32_t> flat_id, flat_ov, flat_flags, flat_cnt;
+        DevBuf<CoocLaunch> d_flat_launch;
+        DevBuf<FlatDesc> d_flat[2];
+        for (size_t first = 0; first < plans.size();) {
+            std::vector<CoocLaunch> fb;
+            std::vector<FlatDesc> fd[2];       // [0] fp32 rows, [1] 24-bit rows
+            size_t m_bytes = 0, s_el = 0, i_el = 0, u_el = 0, n_flat = 0, last = first;
+            int64_t batch_bytes = 0;
+            for (; last < plans.size(); last++) {
+                const Plan& p = plans[last];
+                if (!p.flat) continue;
+                if (n_flat && batch_bytes + flat_need(p) > flat_budget) break;
+                batch_bytes += flat_need(p);
+                m_bytes += round_up((int64_t)p.Ic * p.ldm * (p.pack24 ? 3 : 4), 256);
+                s_el += (size_t)(p.b - p.a) * p.ldm;
+                i_el += (size_t)p.Ic * p.nch;
+                u_el += (size_t)(p.b - p.a);
+                n_flat++;
+            }
+            if (n_flat) {
+                flatM.alloc(ctx, m_bytes);
+                flatS.alloc(ctx, s_el);
+                flat_seg.alloc(ctx, i_el);
+                flat_id.alloc(ctx, i_el);
+                flat_ov.alloc(ctx, u_el);
+                flat_flags.alloc(ctx, 2 * n_flat);       // per cluster: n_heavy, any_overflow
+                size_t m_at = 0, s_at = 0, i_at = 0, u_at = 0, k = 0;
+                int max_grid[2] = {0, 0}, max_users[2] = {0, 0};
+                for (size_t pi = first; pi < last; pi++) {
+                    const Plan& p = plans[pi];
+                    if (!p.flat) continue;
+                    const int c = p.c;
+                    const int32_t nb = p.b - p.a;
+                    float* const Mc = reinterpret_cast<float*>(flatM.get() + m_at);
+                    float* const Sc = flatS.get() + s_at;
+                    CoocArgs CA{P.rank_pair.get(), P.pair_start.get(), segs[pi].ptr_(), segs[pi].seg_(), segs[pi].w_(), P.csr_idx.get(),
+                                csr_x.get(), p.pbase, p.sbase, p.Ic, p.CH, p.nch, 0, p.Ic, p.q0, p.nq, nullptr, 0, csr_pk.get(), nullptr,
+                                (uint32_t)std::min<int64_t>((int64_t)P.nnz * 4, 0xFFFFFFFFll)};
+                    const int fxk = fx_exponent(&J->fx_bounds[3 * (size_t)c]);
+                    CA.fx_scale = std::ldexp(1.0, fxk);
+                    const double w2s = (1.0 - lambda) * (1.0 - lambda) * (double)h_gscale[(size_t)c];
+                    MEpilogue ME{Mc, p.ldm, (float)w2s, std::ldexp(w2s, -fxk), p.pack24 ? 1 : 0, nullptr, p.ldb, 0, 0, nullptr, p.ldb64, nullptr};
+                    const int n_items = (int)cooc_item_count(p.Ic, p.CH, p.nch, false);
+                    CA.item_seg = flat_seg.get() + i_at;
+                    CA.item_id = flat_id.get() + i_at;
+                    CA.item_grab = cooc_item_grab((size_t)c < P.cluster_deg2.size() ? P.cluster_deg2[c] : P.sum_deg2, n_items);
+                    fb.push_back(CoocLaunch{CA, ME, n_items, 0});
+
+                    const int n_chunks = (int)ceil_div(p.Ic, 64 * VEC);
+                    // (the chip is filled by all clusters of the batch together: ~8 work-groups per CU over the whole launch)
+                    const int64_t fill = ceil_div(8 * (int64_t)ctx->num_cus, (int64_t)std::max(1, n_chunks) * (int64_t)n_flat);
+                    const int n_slices = (int)std::max<int64_t>(1, std::min<int64_t>(tune.max_slices, std::min<int64_t>(ceil_div(nb, 4), std::max<int64_t>(ceil_div(nb, 4 * (int64_t)tune.users_per_wave), fill))));
+                    FlatDesc d{};
+                    ScoreArgs& SA = d.SA;
+                    SA.M = Mc; SA.ldm = p.ldm; SA.Ic = p.Ic; SA.a_rank = a_rank.get() + p.pbase; SA.b_rank = b_rank32.get() + p.pbase;
+                    SA.rb_off = P.rowptr.get() + p.sbase;
+                    SA.csr_idx = P.csr_idx.get(); SA.csr_e = csr_e.get(); SA.csr_q = csr_q.get();
+                    SA.pvpi = pvpi.get(); SA.n_out = n_out.get(); SA.slot_lo = lo; SA.slot_base = p.sbase; SA.slot0 = p.a; SA.n_users = nb;
+                    SA.S = Sc; SA.ldS = p.ldm; SA.n_slices = n_slices; SA.n_chunks = n_chunks;
+                    d.n_heavy = flat_flags.get() + 2 * k;
+                    d.any_overflow = flat_flags.get() + 2 * k + 1;
+                    SA.n_heavy = tune.score_heavy > 0 ? d.n_heavy : nullptr;
+                    d.heavy_thresh = tune.score_heavy > 0 ? std::min(tune.score_heavy, 32) : 0x7FFFFFFF;
+                    d.TA = TopNArgs{Sc, p.ldm, p.Ic, n_out.get(), out_off.get(), P.rank_item_raw.get() + p.pbase, P.slot2du.get(), P.uid.get(), lo, p.a, c,
+                                    R->d_key0.get(), R->d_key1.get(), R->d_value.get(), R->d_aux.get(), 0, 0, nullptr, nullptr, 0, nullptr, nullptr, nullptr};
+                    d.overflow = flat_ov.get() + u_at;
+                    d.score_grid = n_chunks * n_slices;
+                    d.n_users = nb;
+                    const int f = p.pack24 ? 1 : 0;
+                    max_grid[f] = std::max(max_grid[f], d.score_grid);
+                    max_users[f] = std::max(max_users[f], nb);
+                    fd[f].push_back(d);
+                    m_at += (size_t)round_up((int64_t)p.Ic * p.ldm * (p.pack24 ? 3 : 4), 256);
+                    s_at += (size_t)nb * p.ldm;
+                    i_at += (size_t)p.Ic * p.nch;
+                    u_at += (size_t)nb;
+                    k++;
+                }
+                const size_t sp = t_cooc.begin(st);
+                launch_cooc_rm2_multi(ctx, tune, fb, false, d_flat_launch, flat_cnt, st, true);
+                t_cooc.end(sp, st);
+                R->st.cooc_launches++;
+                for (int f = 0; f < 2; f++) {
+                    if (fd[f].empty()) continue;
+                    const unsigned ny = (unsigned)fd[f].size();
+                    d_flat[f].alloc(ctx, fd[f].size());
+                    FY_HIP(hipMemcpyAsync(d_flat[f].get(), fd[f].data(), fd[f].size() * sizeof(FlatDesc), hipMemcpyHostToDevice, st));
+                    const size_t ss = t_score.begin(st);
+                    k_count_heavy_multi<<<(ny + 63) / 64, 64, 0, st>>>(d_flat[f].get(), (int32_t)ny);
+                    FY_KERNEL_CHECK();
+                    if (f) k_score_multi<4, true, 8><<<dim3((unsigned)max_grid[f], ny), 256, 0, st>>>(d_flat[f].get(), P.csr_idx.get(), csr_e.get(), csr_q.get(), pvpi.get(), n_out.get());
+                    else k_score_multi<4, false, 8><<<dim3((unsigned)max_grid[f], ny), 256, 0, st>>>(d_flat[f].get(), P.csr_idx.get(), csr_e.get(), csr_q.get(), pvpi.get(), n_out.get());
+                    FY_KERNEL_CHECK();
+                    t_score.end(ss, st);
+                    R->st.score_launches++;
+                    const size_t tt = t_topn.begin(st);
+                    k_topn_fast_multi<<<dim3((unsigned)max_users[f], ny), 256, 0, st>>>(d_flat[f].get(), tune.force_select);
+                    FY_KERNEL_CHECK();
+                    k_topn_select_multi<<<dim3((unsigned)max_users[f], ny), 256, 0, st>>>(d_flat[f].get(), prune_counters.get() + 2);
+                    FY_KERNEL_CHECK();
+                    t_topn.end(tt, st);
+                }
+                FY_HIP(hipStreamSynchronize(st));     // the host vectors behind the descriptor uploads leave scope here
+            }
+            first = last;
+        }
         struct PanelBuf {
             DevBuf<float> Gp, Bmax64, amax64, bmax64;
             DevBuf<uint32_t> Brep;
@@ -1938,6 +2083,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
 
         for (size_t pi = 0; pi < plans.size(); pi++) {
             const Plan& p = plans[pi];
+            if (p.flat) continue;                  // done above
             if ((phase == 1 || phase == 3) && !p.panel) continue;
             Lane& L = phase == 1 ? lanes[0] : (two_phase && p.panel ? plane[pi] : lanes[pi % NS]);
             hipStream_t ls = phase == 1 ? st : L.st;
@@ -1995,8 +2141,10 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                              nullptr, 0, 0, 0, nullptr, 0, nullptr, p.ldb64, 1};
                 int2* const tseg = batched ? plane[pi].item_seg_t.get() : L.item_seg.get();
                 int32_t* const tid = batched ? plane[pi].item_id_t.get() : L.item_id.get();
-                k_item_list<<<grid_for((int64_t)(Ic - p.p_eff)), 256, 0, ls>>>(CB, tseg, tid);
-                FY_KERNEL_CHECK();
+                if (!batched) {      // (batched: k_item_list_multi, in front of the launch)
+                    k_item_list<<<grid_for((int64_t)(Ic - p.p_eff)), 256, 0, ls>>>(CB, tseg, tid);
+                    FY_KERNEL_CHECK();
+                }
                 CB.item_seg = tseg;
                 CB.item_id = tid;
                 CB.item_grab = 8;      // a tail row's bound item is a handful of segments
@@ -2015,8 +2163,10 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                                                        : (int)cooc_item_count(Ic, CH, nch, p.half);
                 int2* const mseg = batched ? plane[pi].item_seg.get() : L.item_seg.get();
                 int32_t* const mid = batched ? plane[pi].item_id.get() : L.item_id.get();
-                k_item_list<<<grid_for((int64_t)Ic * nch), 256, 0, ls>>>(CA, mseg, mid);
-                FY_KERNEL_CHECK();
+                if (!batched) {
+                    k_item_list<<<grid_for((int64_t)Ic * nch), 256, 0, ls>>>(CA, mseg, mid);
+                    FY_KERNEL_CHECK();
+                }
                 CA.item_seg = mseg;
                 CA.item_id = mid;
                 CA.item_grab = cooc_item_grab(((size_t)c < P.cluster_deg2.size() ? P.cluster_deg2[c] : P.sum_deg2) / (p.half ? 2 : 1), n_items);
@@ -2227,8 +2377,8 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
         }
         if (phase == 1 && (!batch_main.empty() || !batch_tail.empty())) {     // the row kernels of all panel clusters: two launches
             const size_t sp = t_cooc.begin(st);
-            launch_cooc_rm2_multi(ctx, tune, batch_tail, true, d_batch_tail, d_cnt_tail, st);
-            launch_cooc_rm2_multi(ctx, tune, batch_main, false, d_batch_main, d_cnt_main, st);
+            launch_cooc_rm2_multi(ctx, tune, batch_tail, true, d_batch_tail, d_cnt_tail, st, true);
+            launch_cooc_rm2_multi(ctx, tune, batch_main, false, d_batch_main, d_cnt_main, st, true);
             t_cooc.end(sp, st);
             R->st.cooc_launches += (batch_tail.empty() ? 0 : 1) + 1;
         }

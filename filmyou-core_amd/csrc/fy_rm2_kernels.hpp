@@ -98,19 +98,19 @@ __device__ __forceinline__ bool fy_bound_keeps(float ub, float tau, float pvpi) 
 }
 
 template <int VEC, bool P24, int SB>
-__global__ __launch_bounds__(256) void k_score(const float* __restrict__ M_, const float* __restrict__ a_rank_,
-                                               const int32_t* __restrict__ rb_off_, const int32_t* __restrict__ csr_idx_,
-                                               const float* __restrict__ csr_e_, const float* __restrict__ csr_q_,
-                                               const double* __restrict__ pvpi_,
-                                               const int32_t* __restrict__ n_out_, float* __restrict__ S_, ScoreArgs A) {
+__device__ __forceinline__ void score_body(const float* __restrict__ M_, const float* __restrict__ a_rank_,
+                                           const int32_t* __restrict__ rb_off_, const int32_t* __restrict__ csr_idx_,
+                                           const float* __restrict__ csr_e_, const float* __restrict__ csr_q_,
+                                           const double* __restrict__ pvpi_,
+                                           const int32_t* __restrict__ n_out_, float* __restrict__ S_, const ScoreArgs& A, const int bx /* work-group index */) {
     using V = typename VecT<VEC>::type;
     using G = typename std::conditional<P24, U3, V>::type;   // what one lane loads per row
     static_assert(!P24 || VEC == 4, "24-bit rows are packed four columns to three dwords");
     constexpr int CW = 64 * VEC;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int chunk = blockIdx.x / A.n_slices;
-    const int slice = blockIdx.x - chunk * A.n_slices;
+    int chunk = bx / A.n_slices;
+    const int slice = bx - chunk * A.n_slices;
     // fused seed + bound launch (one grid, one tail): the chunks behind the first `chunks1` belong to a second matrix
     const bool second = A.chunks1 > 0 && chunk >= A.chunks1;
     if (second) chunk -= A.chunks1;
@@ -254,6 +254,14 @@ __global__ __launch_bounds__(256) void k_score(const float* __restrict__ M_, con
         store(u, slot, t, mask);
     }
 }
+template <int VEC, bool P24, int SB>
+__global__ __launch_bounds__(256) void k_score(const float* __restrict__ M_, const float* __restrict__ a_rank_,
+                                               const int32_t* __restrict__ rb_off_, const int32_t* __restrict__ csr_idx_,
+                                               const float* __restrict__ csr_e_, const float* __restrict__ csr_q_,
+                                               const double* __restrict__ pvpi_,
+                                               const int32_t* __restrict__ n_out_, float* __restrict__ S_, ScoreArgs A) {
+    score_body<VEC, P24, SB>(M_, a_rank_, rb_off_, csr_idx_, csr_e_, csr_q_, pvpi_, n_out_, S_, A, (int)blockIdx.x);
+}
 
 // ================================================================ top-N (PriorityQueue + poll loop, AbstractRM2Reducer.java:325, 358-369)
 // One workgroup per user.  NaN marks "not a candidate" (rated by the user / padding).  Order: larger score first
@@ -329,11 +337,10 @@ __device__ __forceinline__ void fy_bitonic_desc(uint64_t* v, int P2) {
 // top K of any subset that contains it), so an exact sort of the kept set gives the exact list, ties broken by
 // ascending raw item id.  If more than TOPN_MAX entries survive (massive ties, e.g. a row of -inf) the user is
 // flagged and k_topn_select below redoes it with a radix select.
-__global__ __launch_bounds__(256) void k_topn_fast(TopNArgs A, int32_t* __restrict__ overflow, int32_t* __restrict__ any_overflow,
-                                                   int force_select) {
+__device__ __forceinline__ void topn_fast_body(const TopNArgs& A, int32_t* __restrict__ overflow, int32_t* __restrict__ any_overflow,
+                                               int force_select, const int u /* user of the batch = work-group index */) {
     __shared__ uint64_t cand[TOPN_MAX];
     __shared__ uint32_t sh_count, sh_nvalid;
-    const int u = blockIdx.x;
     const int slot = A.slot0 + u;
     const int K = A.n_out[slot - A.slot_lo];
     if (threadIdx.x == 0) overflow[u] = 0;
@@ -447,8 +454,10 @@ __global__ __launch_bounds__(256) void k_topn_fast(TopNArgs A, int32_t* __restri
         A.out_cluster[off + i] = A.cluster;
     }
 }
-
-
+__global__ __launch_bounds__(256) void k_topn_fast(TopNArgs A, int32_t* __restrict__ overflow, int32_t* __restrict__ any_overflow,
+                                                   int force_select) {
+    topn_fast_body(A, overflow, any_overflow, force_select, (int)blockIdx.x);
+}
 
 // Seed phase of the pruned flow (what k_topn_fast does in mode 1), one WAVE per user: the seed scores (256 columns for N = 50) are
 // sorted in the wave's own slice of LDS with compiler fences instead of workgroup barriers -- a wave's LDS instructions complete in
@@ -641,13 +650,12 @@ __global__ __launch_bounds__(256) void k_topn_long(TopNArgs A, int32_t* __restri
 }
 
 // Fallback: exact radix select (three histogram passes + collect).  Runs only for users k_topn_fast flagged.
-__global__ __launch_bounds__(256) void k_topn_select(TopNArgs A, const int32_t* __restrict__ overflow,
-                                                     const int32_t* __restrict__ any_overflow, unsigned long long* __restrict__ n_selected = nullptr) {
+__device__ __forceinline__ void topn_select_body(const TopNArgs& A, const int32_t* __restrict__ overflow,
+                                                 const int32_t* __restrict__ any_overflow, unsigned long long* __restrict__ n_selected, const int u) {
     __shared__ uint32_t hist[TOPN_BINS];
     __shared__ uint64_t cand[TOPN_MAX];
     __shared__ uint32_t sh_prefix, sh_need, sh_count, sh_eq_taken;
     if (*any_overflow == 0) return;
-    const int u = blockIdx.x;
     if (overflow[u] == 0) return;
     const int slot = A.slot0 + u;
     const int K = A.n_out[slot - A.slot_lo];
@@ -793,6 +801,56 @@ __global__ __launch_bounds__(256) void k_topn_select(TopNArgs A, const int32_t* 
         A.out_score[off + i] = fy_order_unkey((uint32_t)(c >> 32));   // already the (float) cast of RM2HDFSReducer.java:48
         A.out_cluster[off + i] = A.cluster;
     }
+}
+__global__ __launch_bounds__(256) void k_topn_select(TopNArgs A, const int32_t* __restrict__ overflow,
+                                                     const int32_t* __restrict__ any_overflow, unsigned long long* __restrict__ n_selected = nullptr) {
+    topn_select_body(A, overflow, any_overflow, n_selected, (int)blockIdx.x);
+}
+
+// ================================================================ many small clusters in ONE launch per kernel ("flat batch")
+// A job over many clusters that are too small for the branch and bound (ML-1M shape in 50 clusters: 120 users and ~2 000 items
+// each) was a chain of ~9 stream operations per cluster -- 450 launches whose kernels last 60-120 us and cannot fill the chip;
+// 10 ms per job, most of it launch latency.  Here every kernel of the chain runs ONCE for all those clusters: blockIdx.y = the
+// cluster, its arguments come from a descriptor array in device memory (wave-uniform: scalar loads), work-groups beyond the
+// cluster's own grid leave at once.  The bodies are the single-cluster kernels' (score_body, topn_fast_body, topn_select_body).
+struct FlatDesc {
+    ScoreArgs SA;
+    TopNArgs TA;
+    int32_t* overflow;            // [n_users]
+    int32_t* any_overflow;        // this cluster's flag
+    int32_t* n_heavy;             // this cluster's count (= SA.n_heavy)
+    int32_t score_grid, n_users, heavy_thresh, pad;
+};
+__global__ void k_count_heavy_multi(const FlatDesc* __restrict__ D, int32_t n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const FlatDesc& d = D[i];
+    const int32_t* __restrict__ rowptr = d.SA.rb_off + (d.SA.slot0 - d.SA.slot_base);
+    int lo = 0, hi = d.n_users;       // first u with degree <= thresh (slots are in descending order of degree)
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (rowptr[mid + 1] - rowptr[mid] > d.heavy_thresh) lo = mid + 1; else hi = mid; }
+    *d.n_heavy = lo;
+    *d.any_overflow = 0;
+}
+template <int VEC, bool P24, int SB>
+__global__ __launch_bounds__(256) void k_score_multi(const FlatDesc* __restrict__ D, const int32_t* __restrict__ csr_idx_,
+                                                     const float* __restrict__ csr_e_, const float* __restrict__ csr_q_,
+                                                     const double* __restrict__ pvpi_, const int32_t* __restrict__ n_out_) {
+    const FlatDesc& d = D[blockIdx.y];
+    if ((int)blockIdx.x >= d.score_grid) return;
+    const ScoreArgs A = d.SA;
+    score_body<VEC, P24, SB>(A.M, A.a_rank, A.rb_off, csr_idx_, csr_e_, csr_q_, pvpi_, n_out_, A.S, A, (int)blockIdx.x);
+}
+__global__ __launch_bounds__(256) void k_topn_fast_multi(const FlatDesc* __restrict__ D, int force_select) {
+    const FlatDesc& d = D[blockIdx.y];
+    if ((int)blockIdx.x >= d.n_users) return;
+    const TopNArgs A = d.TA;
+    topn_fast_body(A, d.overflow, d.any_overflow, force_select, (int)blockIdx.x);
+}
+__global__ __launch_bounds__(256) void k_topn_select_multi(const FlatDesc* __restrict__ D, unsigned long long* __restrict__ n_selected) {
+    const FlatDesc& d = D[blockIdx.y];
+    if ((int)blockIdx.x >= d.n_users) return;
+    const TopNArgs A = d.TA;
+    topn_select_body(A, d.overflow, d.any_overflow, n_selected, (int)blockIdx.x);
 }
 
 // ================================================================ exact pruning of candidate blocks (branch and bound)

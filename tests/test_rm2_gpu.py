@@ -109,6 +109,36 @@ def test_synthetic_vs_oracle(ctx, shape, K, lam, top_n):
     print("worst relative error", shape, K, worst)
 
 
+@pytest.mark.parametrize("env,flat", [({"FY_FLAT": "0"}, False), ({}, True), ({"FY_FLAT_BUDGET_MB": "16"}, True),
+                                      ({"FY_M24_MIN_ITEMS": "64"}, True), ({"FY_M24_MIN_ITEMS": "64", "FY_FLAT_BUDGET_MB": "16"}, True),
+                                      ({"FY_M24_MIN_ITEMS": "64", "FY_FLAT": "0"}, False)])
+def test_many_small_clusters_in_one_launch_per_kernel(ctx, monkeypatch, env, flat):
+    """Flat batch (fy_rm2_kernels.hpp: FlatDesc): the unpruned clusters of a multi-cluster job run every kernel of their chain once for
+    all of them.  Against the oracle, with fp32 and with 24-bit matrix rows, in one batch and in several (a budget of 16 MB holds three or
+    four clusters), and the round-2 path (one cluster after the other on the lanes) beside it."""
+    S = synth()
+    u, i, s, facts = S.generate("ml100k", seed_offset=3)
+    u, i, s = u.numpy(), i.numpy(), s.numpy()
+    uu = np.unique(u)
+    K = 20
+    mc = S.hash_clustering(uu, K)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    conf = build_conf(lam=0.2, n_items=facts["n_items"], n_clusters=K, top_n=30)
+    rec = pkg().RM2Job(conf, ctx).run((u, i, s), clustering=(uu, mc))
+    ref = oracle_full(u, i, s, 0.2, facts["n_items"], K, uu, mc)
+    assert_topn_matches(rec.rows(), ref, 30)
+    launches = rec.stats["score_launches"]
+    if flat:
+        assert launches < K, launches                      # one scoring launch per batch
+        if "FY_FLAT_BUDGET_MB" in env:
+            assert launches > 1, launches                  # several batches
+        else:
+            assert launches == 1, launches
+    else:
+        assert launches == K, launches
+
+
 def test_edge_cases_match_oracle(ctx):
     P = pkg()
     # a 1-user cluster whose items are all rated (no list), a 1-user cluster next to a 2-user one, an unmapped user
