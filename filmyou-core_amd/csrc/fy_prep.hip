@@ -343,6 +343,31 @@ __global__ void k_gather_i32(int32_t n, const int32_t* __restrict__ src, const i
     for (int32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) dst[t] = src[index[t]];
 }
 
+__global__ void k_gather_i64(int32_t n, const int64_t* __restrict__ src, const int32_t* __restrict__ index, int64_t* __restrict__ dst) {
+    for (int32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) dst[t] = src[index[t]];
+}
+// out[t] = src[index[t]] for a host list of positions: ONE gather launch and one copy back (a d2h per element is ~15 us each -- 100
+// of them per job at 50 clusters).  Synchronises the context.
+void gather_to_host_i32(Context* ctx, const int32_t* src, const std::vector<int32_t>& index, int32_t* out) {
+    if (index.empty()) return;
+    DevBuf<int32_t> di(ctx, index.size()), dv(ctx, index.size());
+    h2d(ctx, di.get(), index.data(), index.size());
+    k_gather_i32<<<grid_for((int64_t)index.size()), 256, 0, ctx->stream>>>((int32_t)index.size(), src, di.get(), dv.get());
+    FY_KERNEL_CHECK();
+    d2h(ctx, out, dv.get(), index.size());
+    sync(ctx);
+}
+void gather_to_host_i64(Context* ctx, const int64_t* src, const std::vector<int32_t>& index, int64_t* out) {
+    if (index.empty()) return;
+    DevBuf<int32_t> di(ctx, index.size());
+    DevBuf<int64_t> dv(ctx, index.size());
+    h2d(ctx, di.get(), index.data(), index.size());
+    k_gather_i64<<<grid_for((int64_t)index.size()), 256, 0, ctx->stream>>>((int32_t)index.size(), src, di.get(), dv.get());
+    FY_KERNEL_CHECK();
+    d2h(ctx, out, dv.get(), index.size());
+    sync(ctx);
+}
+
 // ---------------------------------------------------------------- build
 void ratings_id_bounds(Context* ctx, fy_ratings* R) {
     R->max_user = R->max_item = -1;
@@ -595,8 +620,14 @@ void build_structure(Context* ctx, const fy_ratings* R, int32_t K, int64_t n_map
         d2h(ctx, P.work_prefix.data(), wpre.get(), (size_t)nU);
         d2h(ctx, &P.sum_deg2, d2pre.get() + (nU - 1), 1);
         std::vector<int64_t> at_end((size_t)K + 1, 0);     // inclusive prefix of n_u^2 at the last slot of every cluster
-        for (int c = 0; c < K; c++)
-            if (P.ucstart[c + 1] > P.ucstart[c]) d2h(ctx, &at_end[(size_t)c + 1], d2pre.get() + (P.ucstart[c + 1] - 1), 1);
+        {
+            std::vector<int32_t> where, which;
+            for (int c = 0; c < K; c++)
+                if (P.ucstart[c + 1] > P.ucstart[c]) { where.push_back(P.ucstart[c + 1] - 1); which.push_back(c + 1); }
+            std::vector<int64_t> got(where.size());
+            gather_to_host_i64(ctx, d2pre.get(), where, got.data());      // (synchronises: the copies above have landed too)
+            for (size_t t = 0; t < where.size(); t++) at_end[(size_t)which[t]] = got[t];
+        }
         sync(ctx);
         P.cluster_deg2.assign((size_t)K, 0);
         int64_t before = 0;

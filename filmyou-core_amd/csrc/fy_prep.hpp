@@ -67,5 +67,8 @@ void sort_pairs_u64_u64(Context*, uint64_t* kin, uint64_t* kout, uint64_t* vin, 
 void inclusive_scan_u32(Context*, const uint32_t* in, uint32_t* out, size_t n);
 void exclusive_scan_i32(Context*, const int32_t* in, int32_t* out, size_t n, hipStream_t st = nullptr);
 void inclusive_scan_i64(Context*, const int64_t* in, int64_t* out, size_t n);
+// out[t] = src[index[t]] for a host list of positions (one gather launch, one copy back; synchronises the context)
+void gather_to_host_i32(Context*, const int32_t* src, const std::vector<int32_t>& index, int32_t* out);
+void gather_to_host_i64(Context*, const int64_t* src, const std::vector<int32_t>& index, int64_t* out);
 
 }  // namespace fy

@@ -1843,11 +1843,14 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
         }
         // first / last CSR entry of every planned cluster (slots are cluster-major): one round trip for all of them
         std::vector<int32_t> csr_range(2 * plans.size() + 2, 0);
-        for (size_t pi = 0; pi < plans.size(); pi++) {
-            d2h(ctx, &csr_range[2 * pi], P.rowptr.get() + plans[pi].sbase, 1);
-            d2h(ctx, &csr_range[2 * pi + 1], P.rowptr.get() + plans[pi].sbase + plans[pi].Uc, 1);
+        {
+            std::vector<int32_t> where(2 * plans.size());
+            for (size_t pi = 0; pi < plans.size(); pi++) {
+                where[2 * pi] = plans[pi].sbase;
+                where[2 * pi + 1] = plans[pi].sbase + plans[pi].Uc;
+            }
+            gather_to_host_i32(ctx, P.rowptr.get(), where, csr_range.data());
         }
-        sync(ctx);
         // One cluster's tables: packed CSR with chunk-relative indices for its CH, chunk offsets, segment table (+ the tail rows'
         // one-chunk table over the block-compressed CSR in panel mode).  `co` = scratch for p.Uc * (p.nch + 1) offsets.
         const bool bounded_tables = false;     // (round 2: tables sized by upper bounds inside the lanes; the lanes build no tables any more)
