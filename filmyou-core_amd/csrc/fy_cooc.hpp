@@ -74,7 +74,13 @@ struct CoocArgs {
     // 57 % of the LDS cycles of a 50-cluster job).  0 = linear (item-item similarity: its top-K epilogue walks single columns).
     int32_t acc_quarter;
     int32_t acc32;       // 1: 32-bit fixed-point accumulators (the launch picks the instantiation)
+    // symmetric column-panel mode (fy_rm2.hip, Plan::psym): with `half`, only the rows in front of half_rows (the head rows = the
+    // panel's columns) are cut symmetrically, and they have items only for their first head_chunks chunks -- the head rows' co-ratings
+    // with the tail columns are the tail rows' with the head columns, which the tail rows store.  0 / 0 = plain half walk.
+    int32_t half_rows, head_chunks;
 };
+// is row `row` of the launch walked symmetrically (only the columns behind it)?
+__device__ __forceinline__ bool cooc_row_is_cut(const CoocArgs& A, int row) { return A.half && (A.half_rows == 0 || row < A.half_rows); }
 __device__ __forceinline__ int cooc_acc_index(int c, int quarter) { return quarter ? (c & 3) * quarter + (c >> 2) : c; }
 
 #ifndef FY_COOC_NB
@@ -346,7 +352,15 @@ __device__ __forceinline__ void item_list_body(const CoocArgs& A, int2* __restri
         const int lrow = t / A.nch, ch = t % A.nch;
         const int row = A.row0 + lrow * stride;
         int64_t at = t;
-        if (A.half) {
+        if (A.half && A.half_rows > 0) {            // symmetric panel mode (row0 = 0, stride 1): head rows cut, tail rows whole, both over the head chunks
+            if (row < A.half_rows) {
+                if (ch < row / A.CH || ch >= A.head_chunks) continue;
+                at = cooc_half_item_index(row, ch, A.CH, A.head_chunks);
+            } else {
+                if (ch >= A.tail_chunks) continue;
+                at = cooc_half_item_index(A.half_rows - 1, A.head_chunks - 1, A.CH, A.head_chunks) + 1 + (int64_t)(row - A.half_rows) * A.tail_chunks + ch;
+            }
+        } else if (A.half) {
             if (ch < row / A.CH) continue;
             at = cooc_half_item_index(row, ch, A.CH, A.nch);
         } else if (A.tail_chunks > 0 && lrow >= A.tail_row0) {

@@ -388,6 +388,10 @@ struct Half {
     // tail-row launches (column-panel mode): entries of the rows in front of only_from get no segments
     const int32_t* __restrict__ only_rows;      // [q0 + q]: row of the entry; nullptr = all rows
     int32_t only_from;
+    // column-panel mode: only the rows in front of sym_rows are cut (0 = all rows, plain half walk; < 0 = none: row_of_entry is set
+    // for the chunk limit alone), and the rows from lim_from on have segments only in their first lim_chunks chunks (0 = off) --
+    // rows and chunks the item list never names (tail rows behind the panel's chunks; symmetric panel mode: every row)
+    int32_t sym_rows, lim_from, lim_chunks;
 };
 __device__ __forceinline__ void seg_counts_body(const int32_t* __restrict__ csc_slot, const int32_t* __restrict__ chunk_off, int32_t slot_base,
                                                 int32_t q0, int32_t nq, int32_t nch, int32_t* __restrict__ cnt, const Half& H) {
@@ -396,8 +400,9 @@ __device__ __forceinline__ void seg_counts_body(const int32_t* __restrict__ csc_
         const bool live = q < nq && !(H.only_rows && H.only_rows[q0 + q] < H.only_from);
         const int32_t* co = live ? chunk_off + (int64_t)(csc_slot[q0 + q] - slot_base) * (nch + 1) : nullptr;
         int32_t prev = live ? co[0] : 0;
-        int32_t own = -1, behind = 0;
-        if (live && H.row_of_entry) {
+        int32_t own = -1, behind = 0, climit = nch;
+        if (live && H.row_of_entry && H.lim_chunks > 0 && H.row_of_entry[q0 + q] >= H.lim_from) climit = H.lim_chunks;
+        if (live && H.row_of_entry && (H.sym_rows == 0 || H.row_of_entry[q0 + q] < H.sym_rows)) {
             const int32_t r = H.row_of_entry[q0 + q];
             own = r / H.CH;
             // Where does the slice behind (v, i) start?  Exactly: behind the position of i in the rater's row -- a binary search over the
@@ -419,7 +424,7 @@ __device__ __forceinline__ void seg_counts_body(const int32_t* __restrict__ csc_
             if (live) {
                 const int32_t next = co[ch + 1];
                 const int32_t first = ch == own ? behind : prev;
-                n = ch < own ? 0 : (next - first + 63) >> 6;
+                n = (ch < own || ch >= climit) ? 0 : (next - first + 63) >> 6;
                 prev = next;
             }
             cnt[(int64_t)ch * (nq + 1) + q] = n;
@@ -437,13 +442,15 @@ __global__ void k_seg_counts(const int32_t* __restrict__ csc_slot, const int32_t
 struct SegDesc {
     int32_t slot_base, q0, nq, nch, CH, half, only_from, co_stride;
     int64_t co_off, cnt_off;      // first entry of the table's chunk offsets / of its counts and prefixes
-    int32_t use_only_rows, pad;
+    int32_t use_only_rows, sym_rows;      // sym_rows, lim_from, lim_chunks: Half
+    int32_t lim_from, lim_chunks;
 };
 __global__ void k_seg_counts_multi(const SegDesc* __restrict__ D, const int32_t* __restrict__ csc_slot, const int32_t* __restrict__ co_all,
                                    int32_t* __restrict__ cnt_all, const int32_t* __restrict__ row_of_entry, const int32_t* __restrict__ csr_idx,
                                    int32_t* __restrict__ start_all, const int32_t* __restrict__ samples) {
     const SegDesc d = D[blockIdx.y];
-    const Half H{d.half ? row_of_entry : nullptr, csr_idx, d.CH, start_all + d.q0, samples, d.use_only_rows ? row_of_entry : nullptr, d.only_from};
+    const Half H{(d.half || d.lim_chunks > 0) ? row_of_entry : nullptr, csr_idx, d.CH, start_all + d.q0, samples, d.use_only_rows ? row_of_entry : nullptr, d.only_from,
+                 d.half ? d.sym_rows : -1, d.lim_from, d.lim_chunks};
     seg_counts_body(csc_slot, co_all + d.co_off, d.slot_base, d.q0, d.nq, d.nch, cnt_all + d.cnt_off, H);
 }
 
@@ -469,9 +476,13 @@ __device__ __forceinline__ void seg_fill_body(const int32_t* __restrict__ csc_sl
             f0 = co[0];
             len = co[1] - f0;
             if (H.row_of_entry) {
-                const int32_t own = H.row_of_entry[q0 + q] / H.CH;
-                if (ch < own) len = 0;
-                else if (ch == own) { f0 = H.start[q]; len = co[1] - f0; }
+                const int32_t r = H.row_of_entry[q0 + q];
+                if (H.sym_rows == 0 || r < H.sym_rows) {
+                    const int32_t own = r / H.CH;
+                    if (ch < own) len = 0;
+                    else if (ch == own) { f0 = H.start[q]; len = co[1] - f0; }
+                }
+                if (H.lim_chunks > 0 && r >= H.lim_from && ch >= H.lim_chunks) len = 0;
             }
             if (H.only_rows && H.only_rows[q0 + q] < H.only_from) len = 0;
             w = csc_w[q0 + q];
@@ -512,7 +523,8 @@ __global__ void k_seg_fill_multi(const SegDesc* __restrict__ D, const int32_t* _
                                  const int32_t* __restrict__ co_all, const int32_t* __restrict__ ptr_all, int2* __restrict__ seg, float* __restrict__ seg_w,
                                  const int32_t* __restrict__ row_of_entry, const int32_t* __restrict__ csr_idx, int32_t* __restrict__ start_all) {
     const SegDesc d = D[blockIdx.y];
-    const Half H{d.half ? row_of_entry : nullptr, csr_idx, d.CH, start_all + d.q0, nullptr, d.use_only_rows ? row_of_entry : nullptr, d.only_from};
+    const Half H{(d.half || d.lim_chunks > 0) ? row_of_entry : nullptr, csr_idx, d.CH, start_all + d.q0, nullptr, d.use_only_rows ? row_of_entry : nullptr, d.only_from,
+                 d.half ? d.sym_rows : -1, d.lim_from, d.lim_chunks};
     seg_fill_body(csc_slot, csc_w, co_all + d.co_off, d.slot_base, d.q0, d.nq, d.nch, ptr_all + d.cnt_off, seg, seg_w, H);
 }
 // chunk offsets / packed CSR / block-compressed tail CSR of all planned clusters: blockIdx.y = cluster of the plan
@@ -624,7 +636,7 @@ __device__ __forceinline__ void cooc_rm2_epilogue(const CoocArgs& A, const MEpil
     const int c1 = (ch == A.nch - 1) ? (int)E.ldm : min(c0 + A.CH, (int)E.ldm);
     // symmetric walk: in the row's own chunk nothing in front of its 256-column diagonal block was accumulated (and the
     // mirror pass writes that part of the row); the block maxima of the diagonal block are the mirror pass's too
-    const int cb = (A.half && c0 <= row) ? (row & ~255) : c0;
+    const int cb = (cooc_row_is_cut(A, row) && c0 <= row) ? (row & ~255) : c0;
     const int first_bmax_block = A.half ? (row >> 8) + 1 : 0;
     if (E.pack24) {
         // four columns -> three dwords (c0 and c1 are multiples of 64)
@@ -775,7 +787,7 @@ __device__ __forceinline__ void cooc_rm2_body(const CoocArgs& A, const MEpilogue
         // symmetric walk: in the row's OWN chunk the slices start at a 64-aligned position in front of the row's column (segment
         // table: Half::start); the entries at or before it are masked here -- row i accumulates only the columns j > i
         const int row_of_item = A.row0 + (id >> 8) * (A.row_stride ? A.row_stride : 1);
-        const int rmask = (A.half && row_of_item >= c0 && row_of_item < c0 + A.CH) ? row_of_item - c0 : -1;
+        const int rmask = (cooc_row_is_cut(A, row_of_item) && row_of_item >= c0 && row_of_item < c0 + A.CH) ? row_of_item - c0 : -1;
         if constexpr (PK) cooc_accumulate_pk<ACC>(A, acc, s0, s1, batch, rmask);
         else cooc_accumulate_segments<false, ACC>(A, acc, s0, s1, c0, batch, rmask);
         // (every thread read sh_* of THIS item before the barrier that ended the previous epilogue)
@@ -838,8 +850,8 @@ __device__ __forceinline__ uint32_t fy_load24(const uint32_t* __restrict__ row3,
 }
 constexpr int MIRROR_PITCH = 772;    // bytes per LDS row: 768 + 4 (an odd number of dwords spreads the rows over the banks)
 
-__global__ __launch_bounds__(1024) void k_mirror_tiles(float* __restrict__ M_, int64_t ldm, int32_t Ic, float* __restrict__ Bmax_, int64_t ldb) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char fy_mirror_lds[];   // [128][MIRROR_PITCH]: the destination rows, packed
+extern __shared__ __attribute__((aligned(16))) unsigned char fy_mirror_lds[];   // [128][MIRROR_PITCH]: the destination rows, packed
+__device__ __forceinline__ void mirror_tiles_body(float* __restrict__ M_, int64_t ldm, int32_t Ic, float* __restrict__ Bmax_, int64_t ldb) {
     __shared__ uint32_t rowmax[128];
     const int tj = blockIdx.x, B = blockIdx.y;
     if (tj < 2 * (B + 1)) return;                         // only tiles strictly behind the diagonal block are sources
@@ -892,9 +904,12 @@ __global__ __launch_bounds__(1024) void k_mirror_tiles(float* __restrict__ M_, i
     }
 }
 
+__global__ __launch_bounds__(1024) void k_mirror_tiles(float* __restrict__ M_, int64_t ldm, int32_t Ic, float* __restrict__ Bmax_, int64_t ldb) {
+    mirror_tiles_body(M_, ldm, Ic, Bmax_, ldb);
+}
 // diagonal blocks: thread c owns row 256 B + c; element (c, r) for r < c is element (r, c) of a row above (a 3-byte gather),
 // the rest of the row's segment is its own; the maximum over the completed segment is Bmax[row][B]
-__global__ __launch_bounds__(256) void k_mirror_diag(float* __restrict__ M_, int64_t ldm, int32_t Ic, float* __restrict__ Bmax_, int64_t ldb) {
+__device__ __forceinline__ void mirror_diag_body(float* __restrict__ M_, int64_t ldm, int32_t Ic, float* __restrict__ Bmax_, int64_t ldb) {
     const int B = blockIdx.x, c = threadIdx.x;
     const int row = 256 * B + c;
     if (row >= Ic) return;
@@ -924,6 +939,102 @@ __global__ __launch_bounds__(256) void k_mirror_diag(float* __restrict__ M_, int
         bp[0] = (uint8_t)best;
         bp[1] = (uint8_t)(best >> 8);
         bp[2] = (uint8_t)(best >> 16);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_mirror_diag(float* __restrict__ M_, int64_t ldm, int32_t Ic, float* __restrict__ Bmax_, int64_t ldb) {
+    mirror_diag_body(M_, ldm, Ic, Bmax_, ldb);
+}
+// the panels of all clusters of a symmetric panel-mode job: blockIdx.z (tiles, column maxima) / blockIdx.y (diagonal blocks) = cluster
+struct PanelDesc {
+    float* Gp;
+    float* Bmax64;
+    uint32_t* Brep;
+    int64_t panel_cols, ldb64;
+    int32_t Ic, p_eff, nsub, pad;
+};
+__global__ __launch_bounds__(1024) void k_mirror_tiles_multi(const PanelDesc* __restrict__ D) {
+    const PanelDesc d = D[blockIdx.z];
+    if ((int)blockIdx.x >= (int)(d.panel_cols / 128) || (int)blockIdx.y >= (int)(d.panel_cols / 256) - 1) return;
+    mirror_tiles_body(d.Gp, d.panel_cols, d.p_eff, nullptr, 0);
+}
+__global__ __launch_bounds__(256) void k_mirror_diag_multi(const PanelDesc* __restrict__ D) {
+    const PanelDesc d = D[blockIdx.y];
+    if ((int)blockIdx.x >= (int)(d.panel_cols / 256)) return;
+    mirror_diag_body(d.Gp, d.panel_cols, d.p_eff, nullptr, 0);
+}
+// Symmetric panel mode: the sub-block maxima of the HEAD rows (i < p_eff) from the stored panel, by symmetry:
+//     Bmax64[i][sb] = max_{j in sub-block sb} G[i][j] = max_j Gp[j][i],      Brep[i][sb] = (second largest << 8) | (j of the largest - 64 sb)
+// for every sub-block sb of the row -- the panel Gp holds column i of EVERY row j (head rows after the mirror pass, tail rows from
+// their walk over the head chunks).  Work-group = 256 columns x 16 sub-blocks (1024 rows of the panel): wave w takes sub-blocks
+// 4 w .. 4 w + 3, a lane four columns (12-byte loads, a wave reads 768 contiguous bytes of a row); the results go through LDS so
+// that a thread writes the 16 entries of ONE row of Bmax64 / Brep (48 / 64 contiguous bytes).  Every entry of the head rows is
+// written, zeros too: what the row kernel's epilogue left there (sub-blocks of the partly walked own chunk) is overwritten.
+__global__ __launch_bounds__(256) void k_panel_colmax(const PanelDesc* __restrict__ D) {
+    const PanelDesc dsc = D[blockIdx.z];
+    const float* __restrict__ Gp_ = dsc.Gp;
+    float* __restrict__ Bmax64_ = dsc.Bmax64;
+    uint32_t* __restrict__ Brep = dsc.Brep;
+    const int64_t panel_cols = dsc.panel_cols, ldb64 = dsc.ldb64;
+    const int32_t Ic = dsc.Ic, p_eff = dsc.p_eff, nsub = dsc.nsub;
+    if ((int)blockIdx.x * 256 >= p_eff || (int)blockIdx.y * 16 >= nsub) return;
+    __shared__ uint32_t sh_m[16][257], sh_r[16][257];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col0 = blockIdx.x * 256, sbg = blockIdx.y * 16;
+    const int c = col0 + 4 * lane;
+    const unsigned char* __restrict__ base = reinterpret_cast<const unsigned char*>(Gp_) + (int64_t)c * 3;
+    const int64_t pitch = panel_cols * 3;
+    for (int s = 0; s < 4; s++) {
+        const int sb = sbg + 4 * wave + s;
+        uint32_t t1[4] = {0, 0, 0, 0}, t2[4] = {0, 0, 0, 0};
+        if (sb < nsub) {
+            const int j0 = 64 * sb, nr = min(64, Ic - j0);
+            for (int r = 0; r < nr; r += 8) {
+                uint32_t d[8][3];
+#pragma unroll
+                for (int x = 0; x < 8; x++) {
+                    const uint32_t* __restrict__ p = reinterpret_cast<const uint32_t*>(base + (int64_t)(j0 + min(r + x, nr - 1)) * pitch);
+                    d[x][0] = p[0]; d[x][1] = p[1]; d[x][2] = p[2];
+                }
+#pragma unroll
+                for (int x = 0; x < 8; x++) {
+                    if (r + x < nr) {
+                        uint32_t v[4];
+                        fy_unpack24_raw(d[x][0], d[x][1], d[x][2], v);
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const uint32_t key = (v[q] << 6) | (uint32_t)(r + x);
+                            t2[q] = max(min(t1[q], key), t2[q]);
+                            t1[q] = max(t1[q], key);
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            sh_m[4 * wave + s][4 * lane + q] = t1[q] >> 6;
+            sh_r[4 * wave + s][4 * lane + q] = (t1[q] >> 6) ? (((t2[q] >> 6) << 8) | (t1[q] & 63u)) : 0u;
+        }
+    }
+    __syncthreads();
+    const int i = col0 + threadIdx.x;
+    if (i < p_eff) {
+        uint32_t m[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) m[k] = sh_m[k][threadIdx.x];
+        // 16 entries of 3 bytes = 12 dwords at a 16-byte aligned address (ldb64 and sbg are multiples of 16)
+        uint32_t* __restrict__ bp = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(Bmax64_) + ((int64_t)i * ldb64 + sbg) * 3);
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const uint32_t* v = m + 4 * g;
+            bp[3 * g + 0] = v[0] | (v[1] << 24);
+            bp[3 * g + 1] = (v[1] >> 8) | (v[2] << 16);
+            bp[3 * g + 2] = (v[2] >> 16) | (v[3] << 8);
+        }
+        uint32_t* __restrict__ rp = Brep + (int64_t)i * ldb64 + sbg;
+#pragma unroll
+        for (int k = 0; k < 16; k++) rp[k] = sh_r[k][threadIdx.x];
     }
 }
 
@@ -1227,6 +1338,7 @@ struct Plan {
     int32_t Uc, sbase, pbase, Ic, a, b, CH, nch, q0, nq;
     int64_t ldm, B;
     bool pack24, prune, coop, half, panel;
+    bool psym;       // symmetric panel mode: head rows x head columns by a half walk + mirror, head rows x tail columns not at all (k_panel_colmax)
     bool flat;       // one of many small unpruned clusters whose kernels run in ONE launch each (fy_rm2_kernels.hpp: FlatDesc)
     int32_t panel_cols, nsub;
     int64_t ldb64;
@@ -1263,7 +1375,10 @@ static void build_tables_all(Context* ctx, const Prepared& P, const std::vector<
         const Plan& p = plans[pi];
         const bool tail = p.p_eff < p.Ic;
         hco[pi] = CoDesc{p.sbase, p.Uc, p.CH, p.nch, csr_range[2 * pi], csr_range[2 * pi + 1], p.p_eff, tail ? 1 : 0, co_total, co_tail_total};
-        SegDesc m{p.sbase, p.q0, p.nq, p.nch, p.CH, p.half ? 1 : 0, 0, p.nch + 1, co_total, cnt_total, 0, 0};
+        // panel mode: the tail rows are walked over their first tail_chunks chunks only; symmetric panel mode: so are the head rows,
+        // and those are cut (Half::sym_rows / lim_from / lim_chunks) -- rows and chunks the item list never names get no segments
+        SegDesc m{p.sbase, p.q0, p.nq, p.nch, p.CH, (p.half || p.psym) ? 1 : 0, 0, p.nch + 1, co_total, cnt_total, 0, p.psym ? p.p_eff : 0,
+                  p.psym ? 0 : p.p_eff, (p.panel && p.tail_chunks > 0 && p.p_eff < p.Ic) ? p.tail_chunks : 0};
         main_of[pi] = (int64_t)hsd.size();
         hsd.push_back(m);
         cnt_total += (int64_t)p.nch * ((int64_t)p.nq + 1);
@@ -1275,7 +1390,7 @@ static void build_tables_all(Context* ctx, const Prepared& P, const std::vector<
     for (size_t pi = 0; pi < np; pi++) {      // the tail tables behind the main ones (their chunk offsets are the k_tail_blocks ranges)
         const Plan& p = plans[pi];
         if (p.p_eff >= p.Ic) continue;
-        SegDesc t{p.sbase, p.q0, p.nq, 1, 0, 0, p.p_eff, 2, hco[pi].co_tail_off, cnt_total, 1, 0};
+        SegDesc t{p.sbase, p.q0, p.nq, 1, 0, 0, p.p_eff, 2, hco[pi].co_tail_off, cnt_total, 1, 0, 0, 0};
         tail_of[pi] = (int64_t)hsd.size();
         hsd.push_back(t);
         cnt_total += (int64_t)p.nq + 1;
@@ -1675,6 +1790,14 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                         // 1625 users 295 / 227, 200 clusters of 812 users 919 / 509 -- the difference is blocks behind the panel)
                         const int64_t want_cols = (int64_t)tune.panel_cols * (p.Uc < tune.panel_wide_below_users ? 2 : 1);
                         p.panel_cols = (int32_t)std::min<int64_t>(p.ldm, std::max<int64_t>(round_up(want_cols, 256), (int64_t)tune.seed_chunks * 256));
+                        // (symmetric panel mode needs the head rows = the panel's columns: whole chunks of a width that divides the panel)
+                        if (tune.panel_sym && p.panel_cols % p.CH != 0) {
+                            const int32_t lim = std::min<int>(max_ch_lds, std::max<int>(tune.panel_max_ch, (int)round_up(ceil_div(p.Ic, 255), 256)));
+                            for (int32_t parts = 1; parts <= 8; parts++) {
+                                const int32_t w = p.panel_cols / parts;
+                                if (p.panel_cols % parts == 0 && w % 256 == 0 && w <= lim && ceil_div(p.Ic, w) < 256) { p.CH = w; p.nch = (int32_t)ceil_div(p.Ic, w); break; }
+                            }
+                        }
                         p.tail_chunks = (int32_t)ceil_div(p.panel_cols, p.CH);
                         p.p_eff = (int32_t)std::min<int64_t>((int64_t)p.tail_chunks * p.CH, p.Ic);
                         if (p.p_eff % 256 != 0 || p.tail_chunks >= p.nch) { p.p_eff = p.Ic; p.tail_chunks = 0; }   // one chunk, or a ragged one: no tail rows
@@ -1701,6 +1824,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             }
             if (n_flat < 2)
                 for (auto& p : plans) p.flat = false;
+            for (auto& p : plans) p.psym = false;
             for (auto& p : plans)
                 if (p.flat) p.half = false;      // (a mirror pass per cluster would be two more launches each)
         }
@@ -1716,6 +1840,15 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
         for (auto& p : plans)
             if (p.panel) { n_panel++; panel_bytes += (int64_t)p.Ic * p.panel_cols * 3 + (int64_t)p.Ic * p.ldb64 * 7 + 64; }
         const bool two_phase = tune.panel_two_phase && n_panel >= 2 && (uint64_t)panel_bytes < ctx->total_mem / 3;
+        // Symmetric panel mode (two-phase jobs, batched fixed-point row kernels): G is symmetric, so (1) inside the panel's square
+        // [0, p_eff)^2 the head rows are walked like the one-cluster job's -- only the columns behind the row, k_mirror_* fills the
+        // rest -- and (2) the head rows are not walked over the tail columns at all: those co-ratings are the tail rows' with the head
+        // columns, which the tail rows walk and STORE (Gp[j][i], j >= p_eff > i), and the only thing the head rows needed them for,
+        // the maxima of their 64-column sub-blocks, are column maxima of the stored panel (k_panel_colmax).  Half the pair visits.
+        if (two_phase && tune.panel_sym && tune.panel_multi_launch && use_pk && tune.cooc_fx && !tune.cooc_f32 && !J->fx_bounds.empty())
+            for (auto& p : plans)
+                p.psym = p.panel && p.tail_chunks > 0 && p.p_eff < p.Ic && p.p_eff == p.panel_cols && p.p_eff % 1024 == 0 && p.a == p.sbase && p.b == p.sbase + p.Uc &&
+                         fx_exponent(&J->fx_bounds[3 * (size_t)p.c]) >= 0;
         // (lanes: one-phase panel mode 2 -- more lanes only queue behind each other's row kernels; two-phase 8 -- only light kernels are left
         // on the lanes: measured at 50 clusters, ms per job: 2 lanes 98.0, 4: 95.9, 8: 93.1)
         const int want_lanes = tune.lanes_forced ? tune.lanes : (two_phase ? std::max(tune.lanes, 8) : (any_panel ? std::min(tune.lanes, tune.panel_lanes) : tune.lanes));
@@ -1820,7 +1953,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
         sig.push_back(use_pk ? 1 : 0);
         sig.push_back(plans.size() > 1 && !any_coop ? 1 : 0);
         for (auto& p : plans) {
-            const int32_t v[8] = {p.c, p.CH, p.nch, p.half ? 1 : 0, p.panel ? 1 : 0, p.p_eff, p.tail_chunks, (p.coop ? 1 : 0) | (p.flat ? 2 : 0)};
+            const int32_t v[8] = {p.c, p.CH, p.nch, p.half ? 1 : 0, p.panel ? 1 : 0, p.p_eff, p.tail_chunks, (p.coop ? 1 : 0) | (p.flat ? 2 : 0) | (p.psym ? 4 : 0)};
             sig.insert(sig.end(), v, v + 8);
         }
         const bool tables_cached = tc.valid && tc.sig == sig;
@@ -2073,6 +2206,8 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
         std::vector<CoocLaunch> batch_main, batch_tail;      // phase 1: the row kernels of all panel clusters, launched together
         DevBuf<CoocLaunch> d_batch_main, d_batch_tail;
         DevBuf<int32_t> d_cnt_main, d_cnt_tail;
+        DevBuf<PanelDesc> d_panel_desc;
+        std::vector<PanelDesc> hpd;                          // (lives as long as its upload may be in flight)
         for (int phase = two_phase ? 1 : 0; phase <= (two_phase ? 3 : 0); phase++) {
         if (phase == 3) {             // every cluster's survivor count has been queued: one wait for all of them
             for (int l = 0; l < NS; l++) FY_HIP(hipStreamSynchronize(lanes[l].st));
@@ -2161,9 +2296,11 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 CA.tail_chunks = p.tail_chunks;
             }
             {
-                CA.half = p.half ? 1 : 0;
-                const int n_items = CA.tail_chunks > 0 ? (int)((int64_t)p.p_eff * nch + (int64_t)(Ic - p.p_eff) * p.tail_chunks)
-                                                       : (int)cooc_item_count(Ic, CH, nch, p.half);
+                CA.half = (p.half || p.psym) ? 1 : 0;
+                if (p.psym) { CA.half_rows = p.p_eff; CA.head_chunks = p.tail_chunks; }
+                const int n_items = p.psym ? (int)(cooc_half_item_index(p.p_eff - 1, p.tail_chunks - 1, CH, p.tail_chunks) + 1 + (int64_t)(Ic - p.p_eff) * p.tail_chunks)
+                                    : CA.tail_chunks > 0 ? (int)((int64_t)p.p_eff * nch + (int64_t)(Ic - p.p_eff) * p.tail_chunks)
+                                                         : (int)cooc_item_count(Ic, CH, nch, p.half);
                 int2* const mseg = batched ? plane[pi].item_seg.get() : L.item_seg.get();
                 int32_t* const mid = batched ? plane[pi].item_id.get() : L.item_id.get();
                 if (!batched) {
@@ -2383,6 +2520,31 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             launch_cooc_rm2_multi(ctx, tune, batch_tail, true, d_batch_tail, d_cnt_tail, st, true);
             launch_cooc_rm2_multi(ctx, tune, batch_main, false, d_batch_main, d_cnt_main, st, true);
             t_cooc.end(sp, st);
+            // symmetric panel mode: the lower triangle of every panel's square, then the head rows' bounds (three launches for all clusters)
+            int max_cols = 0, max_nsub = 0;
+            for (size_t pi = 0; pi < plans.size(); pi++) {
+                const Plan& p = plans[pi];
+                if (!p.psym) continue;
+                hpd.push_back(PanelDesc{pbuf[pi].Gp.get(), pbuf[pi].Bmax64.get(), pbuf[pi].Brep.get(), p.panel_cols, p.ldb64, p.Ic, p.p_eff, p.nsub, 0});
+                max_cols = std::max(max_cols, p.panel_cols);
+                max_nsub = std::max(max_nsub, p.nsub);
+            }
+            if (!hpd.empty()) {
+                const size_t sm = t_mirror.begin(st);
+                d_panel_desc.alloc(ctx, hpd.size());
+                FY_HIP(hipMemcpyAsync(d_panel_desc.get(), hpd.data(), hpd.size() * sizeof(PanelDesc), hipMemcpyHostToDevice, st));
+                const unsigned nz = (unsigned)hpd.size();
+                if (max_cols / 256 > 1) {
+                    FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mirror_tiles_multi), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * MIRROR_PITCH));
+                    k_mirror_tiles_multi<<<dim3((unsigned)(max_cols / 128), (unsigned)(max_cols / 256 - 1), nz), 1024, 128 * MIRROR_PITCH, st>>>(d_panel_desc.get());
+                    FY_KERNEL_CHECK();
+                }
+                k_mirror_diag_multi<<<dim3((unsigned)(max_cols / 256), nz), 256, 0, st>>>(d_panel_desc.get());
+                FY_KERNEL_CHECK();
+                k_panel_colmax<<<dim3((unsigned)(max_cols / 256), (unsigned)ceil_div(max_nsub, 16), nz), 256, 0, st>>>(d_panel_desc.get());
+                FY_KERNEL_CHECK();
+                t_mirror.end(sm, st);
+            }
             R->st.cooc_launches += (batch_tail.empty() ? 0 : 1) + 1;
         }
         }      // phase
