@@ -1296,6 +1296,10 @@ static void launch_cooc_rm2_multi(Context* ctx, const ScoreTune& tune, std::vect
                                   DevBuf<int32_t>& d_counters, hipStream_t st, bool item_lists = false /* fill the item lists first */) {
     if (L.empty()) return;
     int max_chp = 0, max_items = 0, max_list = 0;
+    for (size_t k = 0; k < L.size(); k++)      // (a null operand here is a fault on the GPU a moment later)
+        if (!L[k].A.item_seg || !L[k].A.item_id || !L[k].E.M || !L[k].A.seg || !L[k].A.seg_ptr || (L[k].E.panel_cols && !L[k].E.Bmax64))
+            FY_FAIL(FY_ERR_STATE, "internal: launch %zu of %zu of a batched row kernel has a null operand (item_seg %p item_id %p M %p seg %p ptr %p Bmax64 %p)", k, L.size(),
+                    (const void*)L[k].A.item_seg, (const void*)L[k].A.item_id, (const void*)L[k].E.M, (const void*)L[k].A.seg, (const void*)L[k].A.seg_ptr, (const void*)L[k].E.Bmax64);
     for (auto& x : L) {
         x.A.acc_quarter = tune.cooc_planes ? cooc_lds_columns(x.A.CH) / 4 : 0;
         max_chp = std::max(max_chp, cooc_lds_columns(x.A.CH));
@@ -1839,7 +1843,26 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
         int n_panel = 0;
         for (auto& p : plans)
             if (p.panel) { n_panel++; panel_bytes += (int64_t)p.Ic * p.panel_cols * 3 + (int64_t)p.Ic * p.ldb64 * 7 + 64; }
-        const bool two_phase = tune.panel_two_phase && n_panel >= 2 && (uint64_t)panel_bytes < ctx->total_mem / 3;
+        // (more panels than fit a third of the HBM: the clusters are taken in GROUPS, each through all phases -- 100 clusters of ML-25M
+        // shape keep 127 GB of panels)
+        const bool two_phase = tune.panel_two_phase && n_panel >= 2;
+        std::vector<int> group_of(plans.size(), 0);
+        int n_groups = 1;
+        if (two_phase) {
+            const int64_t limit = tune.panel_group_bytes > 0 ? tune.panel_group_bytes : (int64_t)(ctx->total_mem / 3);
+            int64_t in_group = 0;
+            int g = 0;
+            for (size_t pi = 0; pi < plans.size(); pi++) {
+                const Plan& p = plans[pi];
+                if (!p.panel) continue;
+                const int64_t need = (int64_t)p.Ic * p.panel_cols * 3 + (int64_t)p.Ic * p.ldb64 * 7 + (int64_t)(p.b - p.a) * p.ldb64 * 7 + (int64_t)p.Ic * p.nch * 12;
+                if (in_group > 0 && in_group + need > limit) { g++; in_group = 0; }
+                in_group += need;
+                group_of[pi] = g;
+            }
+            n_groups = g + 1;
+        }
+        (void)panel_bytes;
         // Symmetric panel mode (two-phase jobs, batched fixed-point row kernels): G is symmetric, so (1) inside the panel's square
         // [0, p_eff)^2 the head rows are walked like the one-cluster job's -- only the columns behind the row, k_mirror_* fills the
         // rest -- and (2) the head rows are not walked over the tail columns at all: those co-ratings are the tail rows' with the head
@@ -2151,10 +2174,11 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             float *amax64, *bmax64;
         };
         std::vector<PanelBuf> pbuf(two_phase ? plans.size() : 0);
-        if (two_phase)
+        std::vector<Lane> plane(two_phase ? plans.size() : 0);
+        auto group_buffers = [&](int grp) {
             for (size_t pi = 0; pi < plans.size(); pi++) {
                 const Plan& p = plans[pi];
-                if (!p.panel) continue;
+                if (!p.panel || group_of[pi] != grp) continue;
                 pbuf[pi].Gp.alloc(ctx, (size_t)p.Ic * p.panel_cols * 3 / 4 + 4);
                 pbuf[pi].Bmax64.alloc(ctx, (size_t)p.Ic * p.ldb64 * 3 / 4 + 4);
                 pbuf[pi].Brep.alloc(ctx, (size_t)p.Ic * p.ldb64 + 4);
@@ -2165,11 +2189,9 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
         // bound and the survivor count of every cluster, ONE wait reads all counts (pinned host memory), phase 3 queues the survivor
         // passes and top-N.  (With one scratch set per lane the host waited for every cluster's count before it could queue the next
         // cluster of that lane: 50 round trips during which the other lanes ran dry.)
-        std::vector<Lane> plane(two_phase ? plans.size() : 0);
-        if (two_phase)
             for (size_t pi = 0; pi < plans.size(); pi++) {
                 const Plan& p = plans[pi];
-                if (!p.panel) continue;
+                if (!p.panel || group_of[pi] != grp) continue;
                 Lane& W = plane[pi];
                 const size_t nbp = (size_t)(p.b - p.a);
                 const size_t seed_cols = (size_t)std::min<int64_t>(ceil_div(p.Ic, 256), tune.seed_chunks) * 256;
@@ -2189,6 +2211,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 W.n_quads.alloc(ctx, nbp + 1);
                 W.quad_prefix.alloc(ctx, nbp + 1);
             }
+        };
         struct LaneGuard {
             Context* ctx;
             hipEvent_t fork = nullptr;
@@ -2208,12 +2231,24 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
         DevBuf<int32_t> d_cnt_main, d_cnt_tail;
         DevBuf<PanelDesc> d_panel_desc;
         std::vector<PanelDesc> hpd;                          // (lives as long as its upload may be in flight)
+        for (int grp = 0; grp < n_groups; grp++) {
+        if (two_phase) {
+            if (grp > 0) {       // the previous group's kernels have drained (below): its panels and scratch go back to the allocator
+                for (size_t pi = 0; pi < plans.size(); pi++)
+                    if (plans[pi].panel && group_of[pi] == grp - 1) { pbuf[pi] = PanelBuf(); plane[pi] = Lane(); }
+            }
+            group_buffers(grp);
+            batch_main.clear();
+            batch_tail.clear();
+            hpd.clear();
+        }
         for (int phase = two_phase ? 1 : 0; phase <= (two_phase ? 3 : 0); phase++) {
         if (phase == 3) {             // every cluster's survivor count has been queued: one wait for all of them
             for (int l = 0; l < NS; l++) FY_HIP(hipStreamSynchronize(lanes[l].st));
             FY_HIP(hipStreamSynchronize(st));
         }
         if ((phase == 0 || phase == 2) && NS > 1) {   // the lanes start after everything queued on the main stream so far
+            if (guard.fork) { FY_HIP(hipEventDestroy(guard.fork)); guard.fork = nullptr; }
             FY_HIP(hipEventCreateWithFlags(&guard.fork, hipEventDisableTiming));
             FY_HIP(hipEventRecord(guard.fork, st));
             for (int l = 0; l < NS; l++) FY_HIP(hipStreamWaitEvent(lanes[l].st, guard.fork, 0));
@@ -2222,12 +2257,22 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
         for (size_t pi = 0; pi < plans.size(); pi++) {
             const Plan& p = plans[pi];
             if (p.flat) continue;                  // done above
+            if (group_of[pi] != grp) continue;     // (clusters outside panel mode are in group 0)
             if ((phase == 1 || phase == 3) && !p.panel) continue;
             Lane& L = phase == 1 ? lanes[0] : (two_phase && p.panel ? plane[pi] : lanes[pi % NS]);
             hipStream_t ls = phase == 1 ? st : L.st;
             const bool do_build = !(phase >= 2 && p.panel), do_score = phase != 1;
             const PanelPtrs PP = two_phase && p.panel ? PanelPtrs{pbuf[pi].Gp.get(), pbuf[pi].Bmax64.get(), pbuf[pi].Brep.get(), pbuf[pi].amax64.get(), pbuf[pi].bmax64.get()}
                                                       : PanelPtrs{L.Gp.get(), L.Bmax64.get(), L.Brep.get(), L.amax64.get(), L.bmax64.get()};
+            auto checkpoint = [&](const char* what) {
+                if (!tune.debug_sync) return;
+                const hipError_t e = hipDeviceSynchronize();
+                fprintf(stderr, "[fy] group %d/%d phase %d plan %zu (cluster %d): %s -> %s\n", grp, n_groups, phase, pi, p.c, what, hipGetErrorString(e));
+                fflush(stderr);
+            };
+            checkpoint("start");
+            if (p.panel && (!PP.Gp || !PP.Bmax64 || !PP.Brep || !PP.amax64 || !PP.bmax64 || (two_phase && (!L.S.get() || !L.UB.get() || !L.n_quads.get()) && phase != 1)))
+                FY_FAIL(FY_ERR_STATE, "internal: cluster %d (plan %zu, group %d of %d, phase %d) has no panel buffers", p.c, pi, grp, n_groups, phase);
             const int c = p.c;
             const int32_t sbase = p.sbase, pbase = p.pbase, Ic = p.Ic, a = p.a, b = p.b, CH = p.CH, nch = p.nch;
             const int64_t ldm = p.ldm;
@@ -2317,6 +2362,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 }
             }
             t_cooc.end(sp, ls);
+            checkpoint("row kernel queued / run");
             if (!batched) R->st.cooc_launches++;
             if (p.half) {    // lower triangle + the block maxima in front of / on the diagonal
                 const size_t sm = t_mirror.begin(ls);
@@ -2439,6 +2485,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 if (split) {      // the count goes to pinned memory; the host does not wait here
                     FY_HIP(hipMemcpyAsync(&guard.pinned[pi], L.quad_prefix.get() + nb, sizeof(int32_t), hipMemcpyDeviceToHost, ls));
                     t_score.end(ss, ls);
+                    checkpoint("front (seed + bound, select, second bound)");
                     continue;
                 }
                 }      // phase != 3
@@ -2513,6 +2560,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 k_topn_select<<<nb, 256, 0, ls>>>(TA, L.overflow.get(), L.any_overflow.get(), prune_counters.get() + 2);
                 FY_KERNEL_CHECK();
                 t_topn.end(tt, ls);
+                checkpoint("back (survivors, strays, lists)");
             }
         }
         if (phase == 1 && (!batch_main.empty() || !batch_tail.empty())) {     // the row kernels of all panel clusters: two launches
@@ -2524,7 +2572,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             int max_cols = 0, max_nsub = 0;
             for (size_t pi = 0; pi < plans.size(); pi++) {
                 const Plan& p = plans[pi];
-                if (!p.psym) continue;
+                if (!p.psym || group_of[pi] != grp) continue;
                 hpd.push_back(PanelDesc{pbuf[pi].Gp.get(), pbuf[pi].Bmax64.get(), pbuf[pi].Brep.get(), p.panel_cols, p.ldb64, p.Ic, p.p_eff, p.nsub, 0});
                 max_cols = std::max(max_cols, p.panel_cols);
                 max_nsub = std::max(max_nsub, p.nsub);
@@ -2545,9 +2593,19 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 FY_KERNEL_CHECK();
                 t_mirror.end(sm, st);
             }
+            if (tune.debug_sync) {
+                const hipError_t e = hipDeviceSynchronize();
+                fprintf(stderr, "[fy] group %d/%d: batched row kernels, mirror, column maxima -> %s\n", grp, n_groups, hipGetErrorString(e));
+                fflush(stderr);
+            }
             R->st.cooc_launches += (batch_tail.empty() ? 0 : 1) + 1;
         }
         }      // phase
+        if (grp + 1 < n_groups) {     // the next group re-uses this group's memory: everything queued so far must have finished
+            for (int l = 0; l < NS; l++) FY_HIP(hipStreamSynchronize(lanes[l].st));
+            FY_HIP(hipStreamSynchronize(st));
+        }
+        }      // group
         if (NS > 1) {   // join: the main stream continues after every lane has drained
             for (int l = 0; l < NS; l++) {
                 hipEvent_t done;

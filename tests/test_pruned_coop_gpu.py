@@ -273,10 +273,16 @@ def test_panel_mode_vs_oracle(forced, monkeypatch, shape, K, lam, top_n, panel_c
     ctx.close()
 
 
-def test_panel_mode_many_clusters_equals_full_pass(monkeypatch):
+@pytest.mark.parametrize("extra", [{}, {"FY_PANEL_SYM": "0"}, {"FY_PANEL_GROUP_MB": "24"}, {"FY_PANEL_TWO_PHASE": "0"}])
+def test_panel_mode_many_clusters_equals_full_pass(monkeypatch, extra):
     """The production switch: ML-1M-shaped data in 12 clusters with the production thresholds scaled down (clusters of >= 1024
-    items are pruned), panel mode chosen by the cluster count alone; all rows against the plain full pass (FY_PRUNE=0)."""
+    items are pruned), panel mode chosen by the cluster count alone; all rows against the plain full pass (FY_PRUNE=0).
+    Default = the symmetric panel mode (head rows walked behind the diagonal over the panel's chunks only, their bounds over the tail
+    columns from the stored panel's column maxima); FY_PANEL_SYM=0 = head rows over all their chunks; a group budget of 24 MB takes the
+    clusters in several groups (each through all phases); FY_PANEL_TWO_PHASE=0 = every cluster start to end on its lane (round 2)."""
     import os
+    for k, v in extra.items():
+        monkeypatch.setenv(k, v)
     monkeypatch.setenv("FY_PRUNE_MIN_ITEMS", "1024")
     monkeypatch.setenv("FY_M24_MIN_ITEMS", "0")
     monkeypatch.setenv("FY_PANEL_COLS", "1024")
