@@ -46,12 +46,17 @@ void inclusive_scan_u32(Context* c, const uint32_t* in, uint32_t* out, size_t n)
     DevBuf<char> t(c, tmp);
     FY_HIP(rocprim::inclusive_scan(t.get(), tmp, in, out, n, rocprim::plus<uint32_t>(), c->stream));
 }
-void exclusive_scan_i32(Context* c, const int32_t* in, int32_t* out, size_t n, hipStream_t st) {
+void exclusive_scan_i32(Context* c, const int32_t* in, int32_t* out, size_t n, hipStream_t st, DevBuf<char>* scratch) {
     if (n == 0) return;
     if (!st) st = c->stream;
     size_t tmp = 0;
     FY_HIP(rocprim::exclusive_scan(nullptr, tmp, in, out, int32_t(0), n, rocprim::plus<int32_t>(), st));
-    if (st == c->stream) {
+    if (scratch) {
+        // the caller's buffer outlives everything it queues on the lane (hipMallocAsync / hipFreeAsync around every scan of a lane cost
+        // the HOST ~1 ms per call: 48 of the 82 ms of a 50-cluster job were spent queueing the clusters' fronts)
+        if (scratch->size() < tmp || !scratch->get()) scratch->alloc(c, std::max<size_t>(tmp, 4096));
+        FY_HIP(rocprim::exclusive_scan(scratch->get(), tmp, in, out, int32_t(0), n, rocprim::plus<int32_t>(), st));
+    } else if (st == c->stream) {
         DevBuf<char> t(c, tmp);
         FY_HIP(rocprim::exclusive_scan(t.get(), tmp, in, out, int32_t(0), n, rocprim::plus<int32_t>(), st));
     } else {

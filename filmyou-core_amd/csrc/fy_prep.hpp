@@ -65,7 +65,8 @@ void sort_pairs_u64_u32(Context*, uint64_t* kin, uint64_t* kout, uint32_t* vin, 
 void sort_pairs_u64_f32(Context*, uint64_t* kin, uint64_t* kout, float* vin, float* vout, size_t n, int end_bit = 64);
 void sort_pairs_u64_u64(Context*, uint64_t* kin, uint64_t* kout, uint64_t* vin, uint64_t* vout, size_t n, int end_bit = 64);
 void inclusive_scan_u32(Context*, const uint32_t* in, uint32_t* out, size_t n);
-void exclusive_scan_i32(Context*, const int32_t* in, int32_t* out, size_t n, hipStream_t st = nullptr);
+// scratch: a buffer of the caller for the scan's temporary storage (grown when too small); it must outlive the work queued on st
+void exclusive_scan_i32(Context*, const int32_t* in, int32_t* out, size_t n, hipStream_t st = nullptr, DevBuf<char>* scratch = nullptr);
 void inclusive_scan_i64(Context*, const int64_t* in, int64_t* out, size_t n);
 // out[t] = src[index[t]] for a host list of positions (one gather launch, one copy back; synchronises the context)
 void gather_to_host_i32(Context*, const int32_t* src, const std::vector<int32_t>& index, int32_t* out);

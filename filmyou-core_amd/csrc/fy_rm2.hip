@@ -19,6 +19,7 @@
 
 #include "fy_cooc.hpp"
 #include "fy_prep.hpp"
+#include <chrono>
 #include "fy_rm2.hpp"
 
 namespace fy {
@@ -1890,6 +1891,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             DevBuf<int2> stray_items;
             DevBuf<int32_t> n_heavy;       // k_count_heavy
             DevBuf<int32_t> n_quads, quad_prefix;
+            DevBuf<char> scan_tmp;         // temporary storage of the lane's scans
             DevBuf<int2> item_seg, item_seg_t;      // (_t: the tail-row bound launch of a cluster whose row kernels are batched)
             DevBuf<int32_t> item_id, item_id_t;
             DevBuf<float> Ssurv;   // packed scores of the surviving blocks (pruned clusters)
@@ -2243,6 +2245,15 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             hpd.clear();
         }
         for (int phase = two_phase ? 1 : 0; phase <= (two_phase ? 3 : 0); phase++) {
+        const auto host_t0 = std::chrono::steady_clock::now();
+        struct PhaseClock {
+            const std::chrono::steady_clock::time_point t0;
+            int grp, phase;
+            bool on;
+            ~PhaseClock() {
+                if (on) fprintf(stderr, "[fy] group %d phase %d: host queued for %.3f ms\n", grp, phase, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+            }
+        } phase_clock{host_t0, grp, phase, tune.debug_sync};
         if (phase == 3) {             // every cluster's survivor count has been queued: one wait for all of them
             for (int l = 0; l < NS; l++) FY_HIP(hipStreamSynchronize(lanes[l].st));
             FY_HIP(hipStreamSynchronize(st));
@@ -2481,7 +2492,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                     k_bound_repair<<<std::min<int>(nb, ctx->num_cus * 16), 256, 0, ls>>>(RA);
                     FY_KERNEL_CHECK();
                 }
-                exclusive_scan_i32(ctx, L.n_quads.get(), L.quad_prefix.get(), (size_t)nb + 1, ls);
+                exclusive_scan_i32(ctx, L.n_quads.get(), L.quad_prefix.get(), (size_t)nb + 1, ls, &L.scan_tmp);
                 if (split) {      // the count goes to pinned memory; the host does not wait here
                     FY_HIP(hipMemcpyAsync(&guard.pinned[pi], L.quad_prefix.get() + nb, sizeof(int32_t), hipMemcpyDeviceToHost, ls));
                     t_score.end(ss, ls);
