@@ -1195,7 +1195,9 @@ struct StrayArgs {
 };
 // Work items of k_score_stray: a user's stray blocks in groups of STRAY_GROUP (a user has 4 on average and up to ~20: one
 // workgroup per USER left the launch waiting for the users with the most blocks; the co-rater table is rebuilt per group).
-constexpr int STRAY_GROUP = 4;
+// One block per item since round 3: a cluster's launch has a few hundred items for 1 500 work-group slots and lasts as long as its
+// slowest item -- groups of four: 200 clusters of ML-25M shape 345 ms per job, single blocks 285 ms.
+constexpr int STRAY_GROUP = 1;
 __global__ void k_stray_items(const int32_t* __restrict__ surv_prefix, const uint16_t* __restrict__ surv, int64_t ldsurv, int32_t n_users,
                               int32_t panel_blocks, int2* __restrict__ items, int32_t* __restrict__ n_items) {
     for (int u = blockIdx.x * blockDim.x + threadIdx.x; u < n_users; u += gridDim.x * blockDim.x) {
