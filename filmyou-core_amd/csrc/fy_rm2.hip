@@ -1796,6 +1796,14 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                         const int64_t want_cols = (int64_t)tune.panel_cols * (p.Uc < tune.panel_wide_below_users ? 2 : 1);
                         p.panel_cols = (int32_t)std::min<int64_t>(p.ldm, std::max<int64_t>(round_up(want_cols, 256), (int64_t)tune.seed_chunks * 256));
                         // (symmetric panel mode needs the head rows = the panel's columns: whole chunks of a width that divides the panel)
+                        // Either the chunk width is re-picked so that it divides the panel, or -- where that would take too many rows out of
+                        // the head (the rows with EXACT sub-block maxima; a tail row's bounds behind the panel are sums, and looser: Netflix
+                        // shape in 50 clusters, chunks of 3584 columns: 7168 head rows; with 4096 head rows 3867 instead of 58 blocks survive
+                        // behind the panel and the job takes 713 instead of 175 ms) -- the panel is widened to the chunks that cover it.
+                        // (Widening from 1.25 x instead of 1.5 x the panel: 200 clusters of ML-25M shape 285 -> 299 ms, 25 clusters 59.8 -> 62.6 ms.)
+                        const int64_t p_eff_chunks = std::min<int64_t>(ceil_div(p.panel_cols, p.CH) * (int64_t)p.CH, p.Ic);
+                        if (tune.panel_sym && p.panel_cols % p.CH != 0 && 2 * p_eff_chunks > 3 * (int64_t)p.panel_cols && p_eff_chunks % 256 == 0 && p_eff_chunks < p.Ic)
+                            p.panel_cols = (int32_t)p_eff_chunks;
                         if (tune.panel_sym && p.panel_cols % p.CH != 0) {
                             const int32_t lim = std::min<int>(max_ch_lds, std::max<int>(tune.panel_max_ch, (int)round_up(ceil_div(p.Ic, 255), 256)));
                             for (int32_t parts = 1; parts <= 8; parts++) {
@@ -1871,7 +1879,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
         // the maxima of their 64-column sub-blocks, are column maxima of the stored panel (k_panel_colmax).  Half the pair visits.
         if (two_phase && tune.panel_sym && tune.panel_multi_launch && use_pk && tune.cooc_fx && !tune.cooc_f32 && !J->fx_bounds.empty())
             for (auto& p : plans)
-                p.psym = p.panel && p.tail_chunks > 0 && p.p_eff < p.Ic && p.p_eff == p.panel_cols && p.p_eff % 1024 == 0 && p.a == p.sbase && p.b == p.sbase + p.Uc &&
+                p.psym = p.panel && p.tail_chunks > 0 && p.p_eff < p.Ic && p.p_eff == p.panel_cols && p.p_eff % 256 == 0 && p.a == p.sbase && p.b == p.sbase + p.Uc &&
                          fx_exponent(&J->fx_bounds[3 * (size_t)p.c]) >= 0;
         // (lanes: one-phase panel mode 2 -- more lanes only queue behind each other's row kernels; two-phase 8 -- only light kernels are left
         // on the lanes: measured at 50 clusters, ms per job: 2 lanes 98.0, 4: 95.9, 8: 93.1)
