@@ -348,6 +348,18 @@ __global__ void k_gather_i32(int32_t n, const int32_t* __restrict__ src, const i
     for (int32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) dst[t] = src[index[t]];
 }
 
+__global__ void k_set_i32(int32_t* __restrict__ at, int32_t value) { *at = value; }
+// pcstart = exclusive prefix of the per-cluster pair counts (K + 1 entries), cluster_q[c] = pair_start[pcstart[c]]: one thread, K is small
+__global__ void k_cluster_starts(int32_t K, const int32_t* __restrict__ pcount, const int32_t* __restrict__ pair_start, int32_t* __restrict__ pcstart,
+                                 int32_t* __restrict__ cluster_q) {
+    if (blockIdx.x || threadIdx.x) return;
+    int32_t at = 0;
+    for (int32_t c = 0; c <= K; c++) {
+        pcstart[c] = at;
+        cluster_q[c] = pair_start[at];
+        if (c < K) at += pcount[c];
+    }
+}
 __global__ void k_gather_i64(int32_t n, const int64_t* __restrict__ src, const int32_t* __restrict__ index, int64_t* __restrict__ dst) {
     for (int32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) dst[t] = src[index[t]];
 }
@@ -417,10 +429,16 @@ void build_structure(Context* ctx, const fy_ratings* R, int32_t K, int64_t n_map
         FY_KERNEL_CHECK();
         sort_pairs_u64_f32(ctx, k1a.get(), k1b.get(), const_cast<float*>(R->score.get()), sc_um.get(), n_in, std::min(64, ib + ub));
     }
-    const int64_t nnz = (int64_t)fetch(ctx, kept.get());
+    // (host round trips cost ~30 us each plus the bubble behind them: what can be read together is read together)
+    unsigned long long h_kept = 0;
+    int h_flags = 0;
+    d2h(ctx, &h_kept, kept.get(), 1);
+    d2h(ctx, &h_flags, err.get(), 1);
+    sync(ctx);
+    const int64_t nnz = (int64_t)h_kept;
     P.nnz = nnz;
     {
-        const int flags = fetch(ctx, err.get());
+        const int flags = h_flags;
         if (flags & ERR_NEG_ID) FY_FAIL(FY_ERR_NEGATIVE_ID, "negative user or item id in the ratings");
         P.ratings_fp16_exact = !(flags & NOTE_NOT_FP16);
         P.ratings_positive = !(flags & NOTE_NONPOSITIVE);
@@ -443,19 +461,20 @@ void build_structure(Context* ctx, const fy_ratings* R, int32_t K, int64_t n_map
     k_heads_hi32<<<grid_for(nnz), 256, 0, st>>>(nnz, ukeys, head.get(), 1, err.get(), ib);
     FY_KERNEL_CHECK();
     inclusive_scan_u32(ctx, head.get(), du1.get(), nnz);
-    const int32_t nU = (int32_t)fetch(ctx, du1.get() + (nnz - 1));
-    if (fetch(ctx, err.get()) & ERR_DUP) FY_FAIL(FY_ERR_DUPLICATE_RATING, "two ratings share one (user, item) key");
+    uint32_t h_nU = 0;
+    d2h(ctx, &h_nU, du1.get() + (nnz - 1), 1);
+    d2h(ctx, &h_flags, err.get(), 1);
+    sync(ctx);
+    const int32_t nU = (int32_t)h_nU;
+    if (h_flags & ERR_DUP) FY_FAIL(FY_ERR_DUPLICATE_RATING, "two ratings share one (user, item) key");
     P.nU = nU;
 
     P.uid.alloc(ctx, nU);
     DevBuf<int32_t> ustart(ctx, (size_t)nU + 1);
     k_scatter_users<<<grid_for(nnz), 256, 0, st>>>(nnz, ukeys, head.get(), du1.get(), P.uid.get(), ustart.get(), ib);
     FY_KERNEL_CHECK();
-    {
-        const int32_t last = (int32_t)nnz;
-        h2d(ctx, ustart.get() + nU, &last, 1);
-        sync(ctx);
-    }
+    k_set_i32<<<1, 1, 0, st>>>(ustart.get() + nU, (int32_t)nnz);
+    FY_KERNEL_CHECK();
     P.usum.alloc(ctx, nU);
     P.udeg.alloc(ctx, nU);
     k_user_sums<<<grid_for((int64_t)nU * 64, 256), 256, 0, st>>>(nU, ustart.get(), sc_um.get(), P.usum.get(), P.udeg.get());
@@ -463,10 +482,10 @@ void build_structure(Context* ctx, const fy_ratings* R, int32_t K, int64_t n_map
 
     // ---- cluster routing
     P.ucluster.alloc(ctx, nU);
+    std::vector<uint64_t> hm((size_t)std::max<int64_t>(0, n_map));      // (host sources of two uploads: they live until the next synchronisation, below)
+    std::vector<uint32_t> hv((size_t)std::max<int64_t>(0, n_map));
     {
         if (n_map >= ((int64_t)1 << 32)) FY_FAIL(FY_ERR_UNSUPPORTED, "clustering map with more than 2^32 entries");
-        std::vector<uint64_t> hm((size_t)n_map);
-        std::vector<uint32_t> hv((size_t)n_map);
         for (int64_t m = 0; m < n_map; m++) {
             // key = (user : position in the file): sorted by it, the pairs of one user keep their order -- a later pair of the same
             // user wins, like successive TIntIntHashMap.put calls.  (A negative id can never match a kept rating.)
@@ -481,10 +500,8 @@ void build_structure(Context* ctx, const fy_ratings* R, int32_t K, int64_t n_map
         sort_pairs_u64_u32(ctx, dm_in.get(), dm.get(), dv_in.get(), dv.get(), (size_t)n_map);
         k_lookup_cluster<<<grid_for(nU), 256, 0, st>>>(nU, P.uid.get(), n_map, dm.get(), dv.get(), K, P.ucluster.get(), err.get());
         FY_KERNEL_CHECK();
-        sync(ctx);   // hm / hv must outlive the copies
     }
-    if (fetch(ctx, err.get()) & ERR_CLUSTER_RANGE)
-        FY_FAIL(FY_ERR_CLUSTER_RANGE, "a rated user is routed to a cluster outside [0, %d)", K);
+    // (a user routed outside [0, K) is counted in cluster 0 by the kernels below and reported at the next synchronisation)
 
     // ---- slots: cluster-major, heavy rows first
     P.d_csize.alloc(ctx, (size_t)K);
@@ -502,7 +519,9 @@ void build_structure(Context* ctx, const fy_ratings* R, int32_t K, int64_t n_map
     }
     P.csize.resize(K);
     d2h(ctx, P.csize.data(), P.d_csize.get(), (size_t)K);
+    d2h(ctx, &h_flags, err.get(), 1);
     sync(ctx);
+    if (h_flags & ERR_CLUSTER_RANGE) FY_FAIL(FY_ERR_CLUSTER_RANGE, "a rated user is routed to a cluster outside [0, %d)", K);
     P.ucstart.assign(K + 1, 0);
     for (int c = 0; c < K; c++) P.ucstart[c + 1] = P.ucstart[c] + P.csize[c];
     if (cluster_count)
@@ -537,20 +556,17 @@ void build_structure(Context* ctx, const fy_ratings* R, int32_t K, int64_t n_map
     FY_KERNEL_CHECK();
     k_cluster_pair_counts<<<grid_for(K), 256, 0, st>>>(K, nP, P.pair_cluster.get(), pcount.get());
     FY_KERNEL_CHECK();
-    const int32_t last_pair = (int32_t)nnz;   // must outlive the copy (synchronised just below)
-    h2d(ctx, P.pair_start.get() + nP, &last_pair, 1);
-    std::vector<int32_t> hpc(K);
-    d2h(ctx, hpc.data(), pcount.get(), (size_t)K);
-    sync(ctx);
-    P.pcstart.assign(K + 1, 0);
-    for (int c = 0; c < K; c++) P.pcstart[c + 1] = P.pcstart[c] + hpc[c];
-    P.d_pcstart.alloc(ctx, (size_t)K + 1);
-    h2d(ctx, P.d_pcstart.get(), P.pcstart.data(), (size_t)K + 1);
-    {   // first CSC entry of every cluster = pair_start at the cluster's first pair (pairs are cluster-major)
+    k_set_i32<<<1, 1, 0, st>>>(P.pair_start.get() + nP, (int32_t)nnz);
+    FY_KERNEL_CHECK();
+    {   // first pair of every cluster (prefix of the counts) and its first CSC entry = pair_start there (pairs are cluster-major): on the
+        // device, one copy back for both
+        P.d_pcstart.alloc(ctx, (size_t)K + 1);
         DevBuf<int32_t> dq(ctx, (size_t)K + 1);
-        k_gather_i32<<<grid_for(K + 1), 256, 0, st>>>(K + 1, P.pair_start.get(), P.d_pcstart.get(), dq.get());
+        k_cluster_starts<<<1, 64, 0, st>>>(K, pcount.get(), P.pair_start.get(), P.d_pcstart.get(), dq.get());
         FY_KERNEL_CHECK();
+        P.pcstart.assign((size_t)K + 1, 0);
         P.cluster_q.resize((size_t)K + 1);
+        d2h(ctx, P.pcstart.data(), P.d_pcstart.get(), (size_t)K + 1);
         d2h(ctx, P.cluster_q.data(), dq.get(), (size_t)K + 1);
         sync(ctx);
     }
@@ -632,8 +648,8 @@ void build_structure(Context* ctx, const fy_ratings* R, int32_t K, int64_t n_map
             std::vector<int64_t> got(where.size());
             gather_to_host_i64(ctx, d2pre.get(), where, got.data());      // (synchronises: the copies above have landed too)
             for (size_t t = 0; t < where.size(); t++) at_end[(size_t)which[t]] = got[t];
+            if (where.empty()) sync(ctx);
         }
-        sync(ctx);
         P.cluster_deg2.assign((size_t)K, 0);
         int64_t before = 0;
         for (int c = 0; c < K; c++) {
