@@ -45,7 +45,7 @@ void fy::load_tuning_from_env(Tuning& t) {
     if (const char* e = getenv("FY_PANEL_MULTI_LAUNCH")) t.panel_multi_launch = atoi(e) != 0;
     if (const char* e = getenv("FY_FLAT")) t.flat_batch = atoi(e) != 0;
     if (const char* e = getenv("FY_PANEL_SYM")) t.panel_sym = atoi(e) != 0;
-    if (const char* e = getenv("FY_DEBUG_SYNC")) t.debug_sync = atoi(e) != 0;
+    if (const char* e = getenv("FY_DEBUG_SYNC")) t.debug_sync = atoi(e);
     if (const char* e = getenv("FY_PANEL_GROUP_MB")) t.panel_group_bytes = (int64_t)atoll(e) << 20;
     if (const char* e = getenv("FY_FLAT_BUDGET_MB")) t.flat_budget = (int64_t)atoll(e) << 20;
     if (const char* e = getenv("FY_PANEL_TWO_PHASE")) t.panel_two_phase = atoi(e) != 0;

@@ -83,7 +83,7 @@ struct Tuning {
     int panel_lanes = 2;               // job lanes when clusters run in panel mode (measured, 50 clusters: 1 lane 300 ms, 2: 213, 3: 230, 4: 240)
     int64_t flat_budget = 0;           // FY_FLAT_BUDGET_MB: bytes of matrices + score rows one flat batch may hold (0 = a quarter of the HBM, at most the workspace)
     int64_t panel_group_bytes = 0;     // FY_PANEL_GROUP_MB: bytes of panels + scoring scratch one group of panel-mode clusters may hold (0 = a third of the HBM)
-    bool debug_sync = false;           // FY_DEBUG_SYNC=1: multi-cluster jobs drain the device after every step of a cluster and say on stderr where they are
+    int debug_sync = 0;                // FY_DEBUG_SYNC=1: multi-cluster jobs drain the device after every step of a cluster and say on stderr where they are; 2: only the wall clock of the phases (drains the device at the phase ends)
     bool panel_sym = true;             // FY_PANEL_SYM=0: panel mode walks the head rows over all their chunks (round 2) instead of symmetrically over the panel's
     bool flat_batch = true;            // FY_FLAT=0: small unpruned clusters one after the other on the lanes (round 2) instead of one launch per kernel
     bool panel_multi_launch = true;    // FY_PANEL_MULTI_LAUNCH=0: one row-kernel launch per cluster also in two-phase panel mode

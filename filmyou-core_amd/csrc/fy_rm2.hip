@@ -2261,7 +2261,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             ~PhaseClock() {
                 if (on) fprintf(stderr, "[fy] group %d phase %d: host queued for %.3f ms\n", grp, phase, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
             }
-        } phase_clock{host_t0, grp, phase, tune.debug_sync};
+        } phase_clock{host_t0, grp, phase, tune.debug_sync != 0};
         if (phase == 3) {             // every cluster's survivor count has been queued: one wait for all of them
             for (int l = 0; l < NS; l++) FY_HIP(hipStreamSynchronize(lanes[l].st));
             FY_HIP(hipStreamSynchronize(st));
@@ -2284,7 +2284,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             const PanelPtrs PP = two_phase && p.panel ? PanelPtrs{pbuf[pi].Gp.get(), pbuf[pi].Bmax64.get(), pbuf[pi].Brep.get(), pbuf[pi].amax64.get(), pbuf[pi].bmax64.get()}
                                                       : PanelPtrs{L.Gp.get(), L.Bmax64.get(), L.Brep.get(), L.amax64.get(), L.bmax64.get()};
             auto checkpoint = [&](const char* what) {
-                if (!tune.debug_sync) return;
+                if (tune.debug_sync != 1) return;
                 const hipError_t e = hipDeviceSynchronize();
                 fprintf(stderr, "[fy] group %d/%d phase %d plan %zu (cluster %d): %s -> %s\n", grp, n_groups, phase, pi, p.c, what, hipGetErrorString(e));
                 fflush(stderr);
@@ -2612,12 +2612,17 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 FY_KERNEL_CHECK();
                 t_mirror.end(sm, st);
             }
-            if (tune.debug_sync) {
+            if (tune.debug_sync == 1) {
                 const hipError_t e = hipDeviceSynchronize();
                 fprintf(stderr, "[fy] group %d/%d: batched row kernels, mirror, column maxima -> %s\n", grp, n_groups, hipGetErrorString(e));
                 fflush(stderr);
             }
             R->st.cooc_launches += (batch_tail.empty() ? 0 : 1) + 1;
+        }
+        if (tune.debug_sync == 2) {
+            (void)hipDeviceSynchronize();
+            fprintf(stderr, "[fy] group %d phase %d: %.3f ms from its first queued operation to the drained device\n", grp, phase,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count());
         }
         }      // phase
         if (grp + 1 < n_groups) {     // the next group re-uses this group's memory: everything queued so far must have finished
