@@ -332,6 +332,28 @@ __global__ void k_csr_keys(int64_t n, const int32_t* __restrict__ csc_slot, cons
         keys[q] = ((uint64_t)(uint32_t)csc_slot[q] << rb) | (uint32_t)pair_rank[csc_pair[q]];
 }
 
+// CSC entries of one (cluster, item) column in RANK order: number of entries of the column at every rank position
+__global__ void k_rank_counts(int32_t nP, const int32_t* __restrict__ rank_pair, const int32_t* __restrict__ pair_start, int32_t* __restrict__ cnt) {
+    for (int32_t r = blockIdx.x * blockDim.x + threadIdx.x; r <= nP; r += gridDim.x * blockDim.x) {
+        const int32_t p = r < nP ? rank_pair[r] : 0;
+        cnt[r] = r < nP ? pair_start[p + 1] - pair_start[p] : 0;
+    }
+}
+// the CSC entries moved column by column into rank order (cluster-major, inside a cluster by compact item index), each with its
+// key (slot << rb) | index: a STABLE sort by the slot bits alone then leaves every row's indices ascending
+__global__ void k_csr_keys_ranked(int64_t n, const int32_t* __restrict__ csc_slot, const int32_t* __restrict__ csc_pair, const float* __restrict__ csc_r,
+                                  const int32_t* __restrict__ pair_rank, const int32_t* __restrict__ pair_cluster, const int32_t* __restrict__ pcstart,
+                                  const int32_t* __restrict__ pair_start, const int32_t* __restrict__ rank_start, uint64_t* __restrict__ keys,
+                                  float* __restrict__ vals, int rb) {
+    for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t p = csc_pair[q];
+        const int32_t idx = pair_rank[p];
+        const int64_t dst = (int64_t)rank_start[pcstart[pair_cluster[p]] + idx] + (q - pair_start[p]);
+        keys[dst] = ((uint64_t)(uint32_t)csc_slot[q] << rb) | (uint32_t)idx;
+        vals[dst] = csc_r[q];
+    }
+}
+
 __global__ void k_low_bits(int64_t n, const uint64_t* __restrict__ keys, int32_t* __restrict__ out, int rb) {
     const uint64_t mask = ((uint64_t)1 << rb) - 1;
     for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x)
@@ -627,10 +649,18 @@ void build_structure(Context* ctx, const fy_ratings* R, int32_t K, int64_t n_map
         int32_t max_Ic = 1;
         for (int c = 0; c < K; c++) max_Ic = std::max(max_Ic, P.pcstart[c + 1] - P.pcstart[c]);
         const int rb = std::max(1, bits_for((uint64_t)(max_Ic - 1)));   // key = (slot << rb) | compact item index
-        k_csr_keys<<<grid_for(nnz), 256, 0, st>>>(nnz, P.csc_slot.get(), P.csc_pair.get(), P.pair_rank.get(), ka.get(), rb);
+        // The columns are first moved into rank order (a permutation of whole columns: coalesced), then ONE stable sort by the slot
+        // bits alone puts the rows together with their indices ascending: 3 radix passes instead of 5 over (slot, index) at ML-25M shape.
+        DevBuf<int32_t> rank_cnt(ctx, (size_t)nP + 1), rank_start(ctx, (size_t)nP + 1);
+        DevBuf<float> r_ranked(ctx, nnz);
+        k_rank_counts<<<grid_for((int64_t)nP + 1), 256, 0, st>>>(nP, P.rank_pair.get(), P.pair_start.get(), rank_cnt.get());
+        FY_KERNEL_CHECK();
+        exclusive_scan_i32(ctx, rank_cnt.get(), rank_start.get(), (size_t)nP + 1);
+        k_csr_keys_ranked<<<grid_for(nnz), 256, 0, st>>>(nnz, P.csc_slot.get(), P.csc_pair.get(), P.csc_r.get(), P.pair_rank.get(), P.pair_cluster.get(),
+                                                          P.d_pcstart.get(), P.pair_start.get(), rank_start.get(), ka.get(), r_ranked.get(), rb);
         FY_KERNEL_CHECK();
         P.csr_r.alloc(ctx, nnz);
-        sort_pairs_u64_f32(ctx, ka.get(), kb.get(), P.csc_r.get(), P.csr_r.get(), nnz, std::min(64, rb + std::max(1, bits_for((uint64_t)(nU - 1)))));
+        sort_pairs_u64_f32(ctx, ka.get(), kb.get(), r_ranked.get(), P.csr_r.get(), nnz, std::min(64, rb + std::max(1, bits_for((uint64_t)(nU - 1)))), rb);
         P.csr_idx.alloc(ctx, nnz);
         k_low_bits<<<grid_for(nnz), 256, 0, st>>>(nnz, kb.get(), P.csr_idx.get(), rb);
         FY_KERNEL_CHECK();
