@@ -69,8 +69,9 @@ __device__ __forceinline__ void fy_pair_entry(const PairPass& A, int32_t q, Pair
     a.wm = fmaxf(a.wm, (float)wt);
     a.rm = fmaxf(a.rm, (float)r);
 }
-__device__ __forceinline__ void fy_pair_reduce(PairAcc& a) {
-    for (int o = 32; o > 0; o >>= 1) {
+template <int G = 64>
+__device__ __forceinline__ void fy_pair_reduce(PairAcc& a) {      // over groups of G consecutive lanes
+    for (int o = G / 2; o > 0; o >>= 1) {
         a.ps += __shfl_down(a.ps, o, 64);
         a.b += __shfl_down(a.b, o, 64);
         a.ws += __shfl_down(a.ws, o, 64);
@@ -88,19 +89,25 @@ __device__ __forceinline__ void fy_pair_store(const PairPass& A, int32_t pos, in
     A.fx_rank[3 * (int64_t)pos + 1] = a.wm * 1.000001f;
     A.fx_rank[3 * (int64_t)pos + 2] = a.rm;
 }
+// G lanes per column: 64 for the long columns of a big cluster; 16 where the average column is short (50 clusters of ML-25M shape:
+// 2.5 M columns of 10 raters -- a wave per column spent 1.7 ms per job there, four columns per wave 0.5)
+template <int G>
 __global__ void k_pair_pass(int32_t nP, PairPass A, int32_t* __restrict__ heavy, int32_t* __restrict__ n_heavy) {
-    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
-    for (int32_t pos = blockIdx.x * wpb + (threadIdx.x >> 6); pos < nP; pos += gridDim.x * wpb) {
-        const int32_t pr = A.rank_pair[pos];
-        const int32_t q0 = A.pair_start[pr], q1 = A.pair_start[pr + 1];
-        if (q1 - q0 > PAIR_HEAVY) {
-            if (lane == 0) heavy[atomicAdd(n_heavy, 1)] = pos;
-            continue;
-        }
+    const int lane = threadIdx.x & (G - 1), gpb = blockDim.x / G;
+    const int32_t stride = gridDim.x * gpb;
+    // (every group of a wave runs the same number of rounds: the shuffles of the reduction need all lanes)
+    for (int32_t pos0 = blockIdx.x * gpb; pos0 < nP; pos0 += stride) {
+        const int32_t pos = pos0 + (int32_t)(threadIdx.x / G);
+        const bool live = pos < nP;
+        const int32_t pr = live ? A.rank_pair[pos] : 0;
+        const int32_t q0 = live ? A.pair_start[pr] : 0, q1 = live ? A.pair_start[pr + 1] : 0;
+        const bool is_heavy = q1 - q0 > PAIR_HEAVY;
+        if (is_heavy && lane == 0) heavy[atomicAdd(n_heavy, 1)] = pos;
         PairAcc a = fy_pair_zero();
-        for (int32_t q = q0 + lane; q < q1; q += 64) fy_pair_entry(A, q, a);
-        fy_pair_reduce(a);
-        if (lane == 0) fy_pair_store(A, pos, pr, q1 - q0, a);
+        if (!is_heavy)
+            for (int32_t q = q0 + lane; q < q1; q += G) fy_pair_entry(A, q, a);
+        fy_pair_reduce<G>(a);
+        if (live && !is_heavy && lane == 0) fy_pair_store(A, pos, pr, q1 - q0, a);
     }
 }
 __global__ __launch_bounds__(1024) void k_pair_pass_heavy(PairPass A, const int32_t* __restrict__ heavy, const int32_t* __restrict__ n_heavy) {
@@ -1527,7 +1534,8 @@ fy_rm2_job* fy::rm2_prepare(Context* ctx, const fy_rm2_params* prm, const fy_rat
         n_heavy.zero();
         const PairPass PA{P.rank_pair.get(), P.pair_start.get(), P.pair_di.get(), P.csc_slot.get(), P.csc_r.get(), J->usum_slot.get(),
                           J->deg_slot.get(), J->slot_lo, J->slot_hi, J->partial.get(), J->b_rank.get(), J->walk_rank.get(), J->cnt_rank.get(), J->fx_rank.get()};
-        k_pair_pass<<<grid_for((int64_t)P.nP * 64, 256), 256, 0, ctx->stream>>>(P.nP, PA, heavy.get(), n_heavy.get());
+        if (P.nnz < 24 * (int64_t)P.nP) k_pair_pass<16><<<grid_for((int64_t)P.nP * 16, 256), 256, 0, ctx->stream>>>(P.nP, PA, heavy.get(), n_heavy.get());
+        else k_pair_pass<64><<<grid_for((int64_t)P.nP * 64, 256), 256, 0, ctx->stream>>>(P.nP, PA, heavy.get(), n_heavy.get());
         FY_KERNEL_CHECK();
         k_pair_pass_heavy<<<ctx->num_cus * 2, 1024, 0, ctx->stream>>>(PA, heavy.get(), n_heavy.get());
         FY_KERNEL_CHECK();
