@@ -240,6 +240,9 @@ __device__ __forceinline__ void cooc_accumulate_pk(const CoocArgs& A, ACC* __res
     using Group = PkGroup;
     auto issue = [&](Group& G, const int2& d, float w, int g) __attribute__((always_inline)) { cooc_pk_issue(rsrc, lane4, G, d, w, g); };
     const double fx = A.fx_scale;
+    // accumulator of chunk-relative column c (cooc_acc_index) as ONE 24-bit multiply-add without a select:
+    // planar (c & 3) * quarter + (c >> 2), linear (c & 0) * 0 + (c >> 0)
+    const uint32_t ix_mask = A.acc_quarter ? 3u : 0u, ix_shift = A.acc_quarter ? 2u : 0u, ix_quarter = (uint32_t)A.acc_quarter;
     auto commit = [&](Group& G) __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < NB; q++) {
@@ -252,8 +255,14 @@ __device__ __forceinline__ void cooc_accumulate_pk(const CoocArgs& A, ACC* __res
             } else if constexpr (std::is_same<ACC, unsigned long long>::value) {
                 // round(p * 2^k) without a 64-bit conversion: p * 2^k + 2^52 has the integer in its mantissa (0 <= p * 2^k < 2^52)
                 const double d = fma((double)(G.W[q] * x), fx, 4503599627370496.0);
-                const unsigned long long v = (unsigned long long)__double_as_longlong(d) & 0xFFFFFFFFFFFFFull;
-                if (lane < G.L[q] && (int)(G.pk[q] & 0xFFFFu) > rmask) atomicAdd(&acc[cooc_acc_index((int)(G.pk[q] & 0xFFFFu), A.acc_quarter)], v);   // ds_add_u64
+                unsigned long long v = (unsigned long long)__double_as_longlong(d) & 0xFFFFFFFFFFFFFull;
+                // (round 3, from the ISA: the index was a 64-bit multiply-add plus a select between the planar and the linear layout,
+                // and value and index were computed INSIDE an exec-masked branch per segment -- s_and_saveexec, s_cbranch_execz.  Now a
+                // 24-bit multiply-add, and everything but the atomic in front of the mask: the masked block is one instruction, no branch.)
+                const uint32_t c = G.pk[q] & 0xFFFFu;
+                uint32_t at = __umul24(c & ix_mask, ix_quarter) + (c >> ix_shift);
+                asm volatile("" : "+v"(at), "+v"(v));
+                if (lane < G.L[q] && (int)c > rmask) atomicAdd(&acc[at], v);   // ds_add_u64
             } else {
                 const ACC v = (ACC)(G.W[q] * x);
                 if (lane < G.L[q] && (int)(G.pk[q] & 0xFFFFu) > rmask) atomicAdd(&acc[cooc_acc_index((int)(G.pk[q] & 0xFFFFu), A.acc_quarter)], v);   // ds_add_f64
