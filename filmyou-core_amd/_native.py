@@ -20,7 +20,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
 # every symbol include/filmyou.h declares (tests check the library exports exactly these)
 SYMBOLS = [
     "fy_abi_version", "fy_last_error", "fy_context_create", "fy_context_destroy", "fy_context_synchronize", "fy_context_reload_tuning", "fy_context_inject_alloc_failure",
-    "fy_context_stream", "fy_ratings_create", "fy_ratings_destroy", "fy_ratings_nnz", "fy_rm2_prepare",
+    "fy_context_stream", "fy_ratings_create", "fy_ratings_destroy", "fy_ratings_nnz", "fy_ratings_drop_cache", "fy_rm2_prepare",
     "fy_rm2_partial_stats", "fy_rm2_set_global_stats", "fy_rm2_set_collectives", "fy_rccl_unique_id", "fy_rccl_create", "fy_rccl_collectives", "fy_rccl_counters", "fy_rccl_destroy", "fy_rccl_detach_context", "fy_rm2_score", "fy_rm2_job_destroy", "fy_rm2_run",
     "fy_itemsim_build", "fy_itemsim_run", "fy_itemcf_recommend", "fy_cluster_assign", "fy_nmf_factorize", "fy_result_size", "fy_result_key0", "fy_result_key1", "fy_result_value",
     "fy_result_aux", "fy_result_n_users", "fy_result_user_id", "fy_result_user_sum", "fy_result_n_items",
@@ -52,6 +52,18 @@ def build(force=False, verbose=False):
         hipcc = "hipcc"
     cflags = [f for f in HIPCC_FLAGS if f not in ("-shared", "-ldl")]
     common = max(os.path.getmtime(d) for d in [os.path.join(CSRC, h) for h in HEADERS] + [INCLUDE])
+    # objects are only as good as the command that made them: another compiler or other flags (HIPCC, HIPCC_FLAGS edited) rebuild
+    # everything -- staleness by mtime alone would link objects of mixed flags
+    import hashlib
+    stamp_path = os.path.join(obj_dir, "flags.stamp")
+    stamp = hashlib.sha256(("\0".join([os.path.realpath(hipcc)] + cflags)).encode()).hexdigest()
+    try:
+        with open(stamp_path) as f:
+            same_flags = f.read().strip() == stamp
+    except OSError:
+        same_flags = False
+    if not same_flags:
+        force = True
 
     def compile_one(src):
         path, obj = os.path.join(CSRC, src), os.path.join(obj_dir, src + ".o")
@@ -65,6 +77,8 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
+    with open(stamp_path, "w") as f:
+        f.write(stamp + "\n")
     cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB_PATH] + objs + ["-ldl"]
     if verbose:
         print(" ".join(cmd))
@@ -172,6 +186,8 @@ def load():
     L.fy_ratings_destroy.restype = None
     L.fy_ratings_nnz.argtypes = [vp]
     L.fy_ratings_nnz.restype = i64
+    L.fy_ratings_drop_cache.argtypes = [vp]
+    L.fy_ratings_drop_cache.restype = None
     L.fy_rm2_prepare.argtypes = [vp, C.POINTER(RM2Params), vp, i64, vp, vp, vp, pvp]
     L.fy_rm2_partial_stats.argtypes = [vp, pvp, C.POINTER(i64)]
     L.fy_rm2_set_global_stats.argtypes = [vp, vp, i32]

@@ -24,7 +24,7 @@ using namespace fy;
 void fy::load_tuning_from_env(Tuning& t) {
     t = Tuning{};
     if (const char* e = getenv("FY_M24")) t.pack24 = atoi(e) != 0;
-    if (const char* e = getenv("FY_M24_MIN_ITEMS")) t.pack24_min_items = atoi(e);
+    if (const char* e = getenv("FY_M24_MIN_ITEMS")) t.pack24_min_items = std::max(0, atoi(e));
     if (const char* e = getenv("FY_SCORE_SLICES")) t.max_slices = atoi(e);
     if (const char* e = getenv("FY_SCORE_UPW")) { int v = atoi(e); if (v >= 1) t.users_per_wave = v; }
     if (const char* e = getenv("FY_PRUNE")) t.prune = atoi(e) != 0;
@@ -46,15 +46,15 @@ void fy::load_tuning_from_env(Tuning& t) {
     if (const char* e = getenv("FY_FLAT")) t.flat_batch = atoi(e) != 0;
     if (const char* e = getenv("FY_PANEL_SYM")) t.panel_sym = atoi(e) != 0;
     if (const char* e = getenv("FY_DEBUG_SYNC")) t.debug_sync = atoi(e);
-    if (const char* e = getenv("FY_PANEL_GROUP_MB")) t.panel_group_bytes = (int64_t)atoll(e) << 20;
-    if (const char* e = getenv("FY_FLAT_BUDGET_MB")) t.flat_budget = (int64_t)atoll(e) << 20;
+    if (const char* e = getenv("FY_PANEL_GROUP_MB")) t.panel_group_bytes = std::max<int64_t>(0, (int64_t)atoll(e)) << 20;      // (0 = default)
+    if (const char* e = getenv("FY_FLAT_BUDGET_MB")) t.flat_budget = std::max<int64_t>(0, (int64_t)atoll(e)) << 20;
     if (const char* e = getenv("FY_PANEL_TWO_PHASE")) t.panel_two_phase = atoi(e) != 0;
     if (const char* e = getenv("FY_PANEL_LANES")) { int v = atoi(e); if (v >= 1 && v <= 8) t.panel_lanes = v; }
     if (const char* e = getenv("FY_PRUNE_MIN_ITEMS")) { t.prune_min_items = atoi(e); t.prune_min_users = 0; }   // (a forced item threshold -- tests -- lifts the user threshold too)
     if (const char* e = getenv("FY_PRUNE_MIN_USERS")) { int v = atoi(e); if (v >= 0) t.prune_min_users = v; }
     if (const char* e = getenv("FY_SEED_CHUNKS")) { int v = atoi(e); if (v >= 0 && v <= 4) { t.seed_chunks = v; t.seed_forced = v > 0; } }
     if (const char* e = getenv("FY_WORKSPACE_GB")) { long v = atol(e); if (v >= 1) t.workspace_default = (int64_t)v << 30; }
-    if (const char* e = getenv("FY_LANES")) { int v = atoi(e); if (v >= 1 && v <= 8) t.lanes = v; t.lanes_forced = true; }
+    if (const char* e = getenv("FY_LANES")) { int v = atoi(e); if (v >= 1 && v <= 8) { t.lanes = v; t.lanes_forced = true; } }
     if (const char* e = getenv("FY_COOC_BLOCK")) { int v = atoi(e); if (v == 256 || v == 512 || v == 1024) t.cooc_block = v; }
     if (const char* e = getenv("FY_COOC_MAX_CH")) { int v = atoi(e); if (v >= 64 && v <= 20224) { t.cooc_max_ch = v; t.cooc_max_ch_forced = true; } }
     if (const char* e = getenv("FY_TOPN_FORCE_SELECT")) t.force_select = atoi(e) != 0;
@@ -184,6 +184,16 @@ void fy_ratings_destroy(fy_ratings* r) {
     if (ctx) (void)hipStreamSynchronize(ctx->stream);
 }
 int64_t fy_ratings_nnz(const fy_ratings* r) { return r ? r->nnz : 0; }
+void fy_ratings_drop_cache(fy_ratings* r) {
+    if (!r) return;
+    std::shared_ptr<void> old;
+    {
+        std::lock_guard<std::mutex> g(r->cache_mu);
+        old.swap(r->rm2_cache);
+    }
+    if (old && r->ctx) (void)hipStreamSynchronize(r->ctx->stream);     // nothing queued may still read what is released next
+    old.reset();
+}
 
 // ---------------------------------------------------------------- RM2
 int fy_rm2_prepare(fy_context* c, const fy_rm2_params* p, const fy_ratings* r, int64_t n_map, const int32_t* map_user,

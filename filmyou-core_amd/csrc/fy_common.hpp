@@ -7,7 +7,9 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <exception>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -248,6 +250,18 @@ struct EventTimer {
     size_t count() const { return spans.size(); }
 };
 
+// Declared right AFTER the host-side sources (std::vector, stack arrays) of queued hipMemcpyAsync uploads: when an exception unwinds the
+// scope, the stream is drained before those sources are destroyed (objects die in reverse order of declaration).  On the normal
+// path the scope's own synchronisation has already happened and this does nothing.
+struct SyncOnUnwind {
+    hipStream_t st;
+    int n0;
+    explicit SyncOnUnwind(hipStream_t s) : st(s), n0(std::uncaught_exceptions()) {}
+    ~SyncOnUnwind() {
+        if (std::uncaught_exceptions() > n0) (void)hipStreamSynchronize(st);
+    }
+};
+
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 inline int64_t round_up(int64_t a, int64_t b) { return ceil_div(a, b) * b; }
 
@@ -267,6 +281,9 @@ struct fy_ratings {
     // their sort keys into the bits these ids need
     int32_t max_user = -1, max_item = -1;
     // what the last RM2 job over these ratings built from them and its clustering alone (fy_rm2.hip: RM2Static): a later job
-    // with the same clustering starts from it.  Released with the ratings (before their context).
+    // with the same clustering starts from it.  Released with the ratings (before their context), by fy_ratings_drop_cache, and
+    // by a caching job whose clustering / share does not match it (BEFORE that job builds its own: never two static sets in HBM).
+    // The pointer is read and written under cache_mu; the jobs themselves are single-threaded per ratings object (include/filmyou.h).
     mutable std::shared_ptr<void> rm2_cache;
+    mutable std::mutex cache_mu;
 };

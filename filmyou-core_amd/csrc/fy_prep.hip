@@ -512,6 +512,7 @@ void build_structure(Context* ctx, const fy_ratings* R, int32_t K, int64_t n_map
     P.ucluster.alloc(ctx, nU);
     std::vector<uint64_t> hm((size_t)std::max<int64_t>(0, n_map));      // (host sources of two uploads: they live until the next synchronisation, below)
     std::vector<uint32_t> hv((size_t)std::max<int64_t>(0, n_map));
+    SyncOnUnwind hm_hv_guard(st);      // an allocation or a sort below may throw while the two uploads are still queued
     {
         if (n_map >= ((int64_t)1 << 32)) FY_FAIL(FY_ERR_UNSUPPORTED, "clustering map with more than 2^32 entries");
         for (int64_t m = 0; m < n_map; m++) {

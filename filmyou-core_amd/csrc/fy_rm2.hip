@@ -1490,9 +1490,16 @@ fy_rm2_job* fy::rm2_prepare(Context* ctx, const fy_rm2_params* prm, const fy_rat
     EventTimer tm(ctx);
     const size_t span = tm.begin();
     const bool use_cache = !(prm->flags & FY_RM2_NO_CACHE);
-    if (use_cache && R->rm2_cache) {
-        std::shared_ptr<RM2Static> have = std::static_pointer_cast<RM2Static>(R->rm2_cache);
-        if (have->matches(prm, n_map, map_user, map_cluster, cluster_count)) {      // warm: same ratings, same clustering, same share
+    if (use_cache) {
+        std::shared_ptr<RM2Static> have;
+        {
+            std::lock_guard<std::mutex> g(R->cache_mu);
+            have = std::static_pointer_cast<RM2Static>(R->rm2_cache);
+            // another clustering, rank or world: the old static set (CSR / CSC, statistics, every table of the row kernel) goes back to
+            // the allocator BEFORE the new one is built -- peak HBM is one set plus the job's scratch, not two
+            if (have && !have->matches(prm, n_map, map_user, map_cluster, cluster_count)) { R->rm2_cache.reset(); have.reset(); }
+        }
+        if (have) {      // warm: same ratings, same clustering, same share
             std::unique_ptr<fy_rm2_job> J(new fy_rm2_job(have));
             J->ctx = ctx;
             J->prm = *prm;
@@ -1554,13 +1561,13 @@ fy_rm2_job* fy::rm2_prepare(Context* ctx, const fy_rm2_params* prm, const fy_rat
         tm.end(span);
         sync(ctx);
         J->ms_prepare = tm.total_ms();
-        if (use_cache) R->rm2_cache = fresh;
+        if (use_cache) { std::lock_guard<std::mutex> g(R->cache_mu); R->rm2_cache = fresh; }
         return J.release();
     }
     tm.end(span);
     sync(ctx);
     J->ms_prepare = tm.total_ms();
-    if (use_cache) R->rm2_cache = fresh;
+    if (use_cache) { std::lock_guard<std::mutex> g(R->cache_mu); R->rm2_cache = fresh; }
     return J.release();
 }
 
@@ -2068,10 +2075,6 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
         } else if (!lazy_tables)
             for (size_t pi = 0; pi < plans.size(); pi++) build_tables(pi, st, co_lane[0].get());
         t_tables.end(span_tables);
-        // Error path: anything thrown below (an allocation, a launch, a collective) unwinds the lanes' buffers, the segment
-        // tables and the per-job arrays back into the caching allocator while kernels of OTHER lanes may still be reading
-        // them.  The guard drains every lane and the main stream first (members are destroyed in reverse order of
-        // declaration: `lanes`, `segs` and the DevBufs above were declared before it, so it runs before they are released).
         // ---- flat batch (Plan::flat): matrix build, scores and lists of all those clusters, one launch per kernel, on the main stream
         DevBuf<char> flatM;
         DevBuf<float> flatS;
@@ -2082,6 +2085,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
         for (size_t first = 0; first < plans.size();) {
             std::vector<CoocLaunch> fb;
             std::vector<FlatDesc> fd[2];       // [0] fp32 rows, [1] 24-bit rows
+            SyncOnUnwind fb_fd_guard(st);      // (their uploads are queued below; the batch's own synchronisation is at its end)
             size_t m_bytes = 0, s_el = 0, i_el = 0, u_el = 0, n_flat = 0, last = first;
             int64_t batch_bytes = 0;
             for (; last < plans.size(); last++) {
@@ -2230,6 +2234,18 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 W.quad_prefix.alloc(ctx, nbp + 1);
             }
         };
+        // Error path: anything thrown below (an allocation, a launch, a collective) unwinds the lanes' buffers, the segment
+        // tables and the per-job arrays back into the caching allocator while kernels of OTHER lanes may still be reading
+        // them.  The guard drains every lane and the main stream first (members are destroyed in reverse order of
+        // declaration: `lanes`, `segs` and the DevBufs above were declared before it, so it runs before they are released).
+        // (The flat batch above runs on the main stream alone, in front of the guard: its uploads' sources have their own SyncOnUnwind.)
+        // (host-side sources of uploads and the device buffers of the batched launches: declared in FRONT of the guard, so that the
+        // guard -- which drains every lane and the main stream -- is destroyed before them on every path)
+        std::vector<CoocLaunch> batch_main, batch_tail;      // phase 1: the row kernels of all panel clusters, launched together
+        DevBuf<CoocLaunch> d_batch_main, d_batch_tail;
+        DevBuf<int32_t> d_cnt_main, d_cnt_tail;
+        DevBuf<PanelDesc> d_panel_desc;
+        std::vector<PanelDesc> hpd;                          // (lives as long as its upload may be in flight)
         struct LaneGuard {
             Context* ctx;
             hipEvent_t fork = nullptr;
@@ -2244,11 +2260,6 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
         if (two_phase) FY_HIP(hipHostMalloc(reinterpret_cast<void**>(&guard.pinned), plans.size() * sizeof(int32_t), hipHostMallocDefault));
         // phase 0: every cluster start to end on its lane.  two_phase: phase 1 = the panels of all panel-mode clusters on the main stream,
         // phase 2 = everything else on the lanes.
-        std::vector<CoocLaunch> batch_main, batch_tail;      // phase 1: the row kernels of all panel clusters, launched together
-        DevBuf<CoocLaunch> d_batch_main, d_batch_tail;
-        DevBuf<int32_t> d_cnt_main, d_cnt_tail;
-        DevBuf<PanelDesc> d_panel_desc;
-        std::vector<PanelDesc> hpd;                          // (lives as long as its upload may be in flight)
         for (int grp = 0; grp < n_groups; grp++) {
         if (two_phase) {
             if (grp > 0) {       // the previous group's kernels have drained (below): its panels and scratch go back to the allocator
@@ -2605,6 +2616,15 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 max_nsub = std::max(max_nsub, p.nsub);
             }
             if (!hpd.empty()) {
+                // operand check on the host (round 3: these launches faulted at address 0x1000 when a half-built group handed them the
+                // descriptors of clusters whose panels were not allocated): every panel pointer set, every shape what the kernels' grids assume
+                for (size_t k = 0; k < hpd.size(); k++) {
+                    const PanelDesc& d = hpd[k];
+                    if (!d.Gp || !d.Bmax64 || !d.Brep || d.panel_cols <= 0 || d.panel_cols % 256 != 0 || d.p_eff != d.panel_cols || d.Ic < d.p_eff || d.nsub <= 0 ||
+                        d.ldb64 < d.nsub)
+                        FY_FAIL(FY_ERR_STATE, "internal: panel %zu of %zu of a batched mirror / column-maximum launch is unusable (Gp %p Bmax64 %p Brep %p panel_cols %d p_eff %d Ic %d nsub %d ldb64 %lld)",
+                                k, hpd.size(), (const void*)d.Gp, (const void*)d.Bmax64, (const void*)d.Brep, (int)d.panel_cols, (int)d.p_eff, (int)d.Ic, (int)d.nsub, (long long)d.ldb64);
+                }
                 const size_t sm = t_mirror.begin(st);
                 d_panel_desc.alloc(ctx, hpd.size());
                 FY_HIP(hipMemcpyAsync(d_panel_desc.get(), hpd.data(), hpd.size() * sizeof(PanelDesc), hipMemcpyHostToDevice, st));

@@ -629,7 +629,9 @@ __global__ __launch_bounds__(256) void k_topn_long(TopNArgs A, int32_t* __restri
     }
     __syncthreads();
     const int n = (int)sh_count;
-    if (n > cap) {   // block-uniform
+    // (n < K cannot happen while n_out counts only scored candidates and the histogram threshold keeps >= K of the sample -- but if it
+    // ever did, e.g. NaN scores, the entries behind n would be emitted as items: such a user goes to the exact select instead)
+    if (n > cap || n < K) {   // block-uniform
         if (tid == 0) { overflow[u] = 1; atomicAdd(any_overflow, 1); }
         return;
     }

@@ -156,6 +156,11 @@ class Ratings:
         self._keep = None
         self.nnz = n
 
+    def drop_cache(self):
+        """fy_ratings_drop_cache: releases what earlier jobs kept on this object (CSR / CSC, statistics, row-kernel tables)."""
+        if getattr(self, "_h", None) and self.ctx._h:
+            self._lib.fy_ratings_drop_cache(self._h)
+
     def close(self):
         if getattr(self, "_h", None):
             if self.ctx._h:
@@ -371,13 +376,25 @@ class RM2Job:
         rm2 = os.path.join(base, "rm2")
         suffix = "part-r-%05d" % rank
         # Rank 0 alone wipes <directory>/rm2 (RM2Job.java:84), BEFORE its first collective: every other rank writes only after the
-        # job, i.e. after a collective rank 0 has joined.  mapred.output.dir is never deleted (the reference does not: Hadoop's
-        # FileOutputFormat.checkOutputSpecs refuses an existing directory and the job fails): an existing directory fails the job on
-        # a single rank; with several ranks the directory is shared, and only this rank's own part file must not exist.
+        # job, i.e. after a collective rank 0 has joined.  (The wipe comes before the output check, as in the reference: RM2Job.run
+        # removes <directory>/rm2 at :84 and only the submission of job RM2-3 runs checkOutputSpecs -- a refused job has already lost
+        # the previous run's statistics there too.)
+        # mapred.output.dir is never deleted (the reference does not: Hadoop's FileOutputFormat.checkOutputSpecs refuses an existing
+        # directory and the job fails).  One rank: an existing directory fails the job.  Several ranks share the directory, so it may
+        # exist -- but it must not hold ANY part-r-* file, whoever wrote it (a rerun into the directory of a job with a larger world would
+        # leave that job's other part files beside the new ones, and a reader of the directory would get stale rows without any
+        # error).  No rank writes before it has passed a collective inside the job, which every rank joins only after this check: all
+        # ranks see the same directory and fail together instead of hanging in a collective.
         if rank == 0:
             shutil.rmtree(rm2, ignore_errors=True)
-        if (world == 1 and os.path.exists(outp)) or os.path.exists(os.path.join(outp, suffix)):
-            raise RuntimeError("%s failed!: output directory %s already exists" % (self.JOB_NAME, outp))
+        if world == 1:
+            stale = [outp] if os.path.exists(outp) else []
+        else:
+            stale = sorted(f for f in (os.listdir(outp) if os.path.isdir(outp) else []) if f.startswith("part-r-"))
+            if os.path.exists(outp) and not os.path.isdir(outp):
+                stale = [outp]
+        if stale:
+            raise RuntimeError("%s failed!: output directory %s already exists%s" % (self.JOB_NAME, outp, "" if world == 1 else " and holds " + ", ".join(stale[:4])))
         rec = self.run((user, item, score), clustering=(cu, cc), clustering_count=count, rank=rank, world=world, **kw)
         try:
             rows = rec.rows()

@@ -79,6 +79,11 @@ int fy_ratings_create(fy_context*, int64_t nnz, const int32_t* user, const int32
                       int location, fy_ratings** out);
 void fy_ratings_destroy(fy_ratings*);
 int64_t fy_ratings_nnz(const fy_ratings*);
+/* Releases what the jobs keep on the ratings object between calls (see fy_rm2_params::flags): the next job builds everything again.
+ * A caching job whose clustering, rank or world differs from the kept state's releases it itself before it builds its own; a
+ * FY_RM2_NO_CACHE job neither uses nor touches it (call this first when its memory is wanted back: the kept state of an ML-25M-shaped
+ * job is ~2.5 GB).  Jobs over ONE ratings object must not run concurrently; distinct ratings objects (and contexts) may. */
+void fy_ratings_drop_cache(fy_ratings*);
 
 /* ------------------------------------------------------------------ RM2 job
  * Field names follow the Hadoop Configuration keys of M/rmrecommender/RMRecommenderDriver.java:49-120. */

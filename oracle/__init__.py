@@ -52,6 +52,8 @@ def _load():
     L.rm2o_run_gram.argtypes = L.rm2o_run.argtypes
     L.rm2o_run_gram.restype = C.c_int
     L.rm2o_last_error.restype = C.c_char_p
+    L.rm2o_select_clusters.argtypes = [C.c_int32, vp]
+    L.rm2o_select_clusters.restype = None
     L.rm2o_free.argtypes = [vp]
     for name, rt in (("n_recs", i64), ("rec_user", vp), ("rec_item", vp), ("rec_cluster", vp), ("rec_score", vp),
                      ("n_users", i64), ("user_id", vp), ("user_sum", vp), ("n_items", i64), ("item_id", vp),
@@ -101,9 +103,12 @@ def rm2_gram(*args, **kw):
 
 
 def rm2(user, item, score, *, lam, number_of_items, number_of_recommendations, number_of_clusters,
-        map_user=None, map_cluster=None, cluster_count=None, filter_users=0, n_threads=1, _gram=False):
-    """Run the RM2 oracle.  Returns a dict of numpy arrays (see oracle.h for the ordering)."""
+        map_user=None, map_cluster=None, cluster_count=None, filter_users=0, n_threads=1, _gram=False, only_clusters=None):
+    """Run the RM2 oracle.  Returns a dict of numpy arrays (see oracle.h for the ordering).
+    only_clusters: run job RM2-3 for these reduce groups only (statistics stay global)."""
     L = _load()
+    sel = _i32(only_clusters if only_clusters is not None else [])
+    L.rm2o_select_clusters(len(sel), sel.ctypes.data)
     user, item = _i32(user), _i32(item)
     score = np.ascontiguousarray(score, dtype=np.float32)
     mu = _i32(map_user if map_user is not None else [])
@@ -117,6 +122,7 @@ def rm2(user, item, score, *, lam, number_of_items, number_of_recommendations, n
     out = C.c_void_p()
     rc = (L.rm2o_run_gram if _gram else L.rm2o_run)(C.byref(P), len(user), user.ctypes.data, item.ctypes.data, score.ctypes.data, len(mu),
                     mu.ctypes.data, mc.ctypes.data, cc.ctypes.data if cc is not None else None, C.byref(out))
+    L.rm2o_select_clusters(0, None)
     if rc != 0:
         raise RuntimeError("rm2 oracle failed (%d): %s" % (rc, L.rm2o_last_error().decode()))
     h = out.value

@@ -29,6 +29,8 @@ int rm2o_run(const rm2o_params* P, int64_t nnz, const int32_t* user, const int32
 int rm2o_run_gram(const rm2o_params* P, int64_t nnz, const int32_t* user, const int32_t* item, const float* score,
                   int64_t n_map, const int32_t* map_user, const int32_t* map_cluster, const int32_t* cluster_count,
                   rm2o_result** out);
+/* test-side: run only these clusters in job RM2-3 (n = 0: all); the statistics jobs always see every rating */
+void rm2o_select_clusters(int32_t n, const int32_t* list);
 const char* rm2o_last_error(void);
 void rm2o_free(rm2o_result*);
 /* recommendations: grouped by cluster asc, user id asc, then best first (ties: ascending item id) */

@@ -39,6 +39,22 @@
 static char g_err[256];
 const char* rm2o_last_error(void) { return g_err; }
 
+/* Test-side selection: when set, job RM2-3 runs only the listed reduce groups (clusters); jobs RM2-1/2 (user sums, totalSum,
+ * p(i|C)) still see ALL ratings, as in the reference, where each cluster is its own reduce group (RM2Job.java:251).  Used to run
+ * whole clusters of a full-size job through the fp64 scorers in bounded time. */
+static int g_n_sel = 0;
+static int32_t g_sel[64];
+void rm2o_select_clusters(int32_t n, const int32_t* list) {
+    g_n_sel = n < 0 ? 0 : (n > 64 ? 64 : n);
+    for (int k = 0; k < g_n_sel; k++) g_sel[k] = list[k];
+}
+static int cluster_selected(int c) {
+    if (g_n_sel == 0) return 1;
+    for (int k = 0; k < g_n_sel; k++)
+        if (g_sel[k] == c) return 1;
+    return 0;
+}
+
 #define FAIL(code, ...)                              \
     do {                                             \
         snprintf(g_err, sizeof g_err, __VA_ARGS__);  \
@@ -256,7 +272,7 @@ static int run_impl(const rm2o_params* P, int64_t nnz_in, const int32_t* user, c
     double t_score = 0.0;
     for (int c = 0; c < K; c++) {
         const int Uc = csize[c];
-        if (Uc == 0) continue;
+        if (Uc == 0 || !cluster_selected(c)) continue;
         const int32_t* cu = cusers + cstart[c];
         /* createUserAndItemMappings: items rated by somebody of this cluster, dense re-index */
         int32_t* loc = (int32_t*)malloc(sizeof(int32_t) * (size_t)(nI + 1));
@@ -279,7 +295,8 @@ static int run_impl(const rm2o_params* P, int64_t nnz_in, const int32_t* user, c
              *   G[j][i] = (1-l)^2 (X^T X)_ji + l (1-l) p_j b_i,  X_vi = r_vi / s_v,  b_i = sum_v X_vi,
              *   e_uj    = (1-l) (b_j - x_uj) + l (U_c - 1) p_j.
              * One dense Ic x Ic matrix per cluster replaces the U_c - 1 multiply-adds per log term. */
-            if ((double)Ic * (double)Ic * 8.0 > 12e9) { free(loc); free(items); FAIL(-6, "cluster %d: the %d x %d Gram does not fit the CPU baseline's budget", c, Ic, Ic); }
+            const char* bud = getenv("RM2O_GRAM_BUDGET_GB");   /* host memory the dense fp64 Gram may take (default 12 GB) */
+            if ((double)Ic * (double)Ic * 8.0 > (bud ? atof(bud) : 12.0) * 1e9) { free(loc); free(items); FAIL(-6, "cluster %d: the %d x %d Gram does not fit the CPU baseline's budget", c, Ic, Ic); }
             G = (double*)calloc((size_t)Ic * (size_t)Ic, sizeof(double));
             bvec = (double*)calloc((size_t)Ic + 1, sizeof(double));
             if (!G || !bvec) { free(G); free(bvec); free(loc); free(items); FAIL(-5, "cluster %d: cannot allocate the %d x %d Gram", c, Ic, Ic); }

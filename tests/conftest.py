@@ -46,3 +46,14 @@ def rm_golden2():
         d = json.load(f)
     d["coo"] = coo_from_items_by_users(d["A_items_by_users"])
     return d
+
+
+def pytest_terminal_summary(terminalreporter):
+    """How often the oracle comparisons of this run needed an absolute term on top of north_star's relative 1e-5 (tests/util.py)."""
+    try:
+        from util import SLACK_TALLY as T
+    except Exception:
+        return
+    if T["calls"]:
+        terminalreporter.write_line("oracle comparisons: %d calls, %d scores, %d needed an absolute slack, worst relative error %.2e"
+                                    % (T["calls"], T["comparisons"], T["needed_atol"], T["worst_rel"]))

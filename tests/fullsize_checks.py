@@ -43,10 +43,7 @@ def run_rm2(data, top_n, lam, env=None, clusters=1):
         conf.setInt("numberOfItems", data["facts"]["n_items"])
         conf.setInt("numberOfClusters", clusters)
         conf.setInt("numberOfRecommendations", top_n)
-        clustering = None
-        if clusters > 1:
-            uu = np.arange(1, data["facts"]["n_users"] + 1, dtype=np.int32)      # ids are 1..n in the synthetic shapes
-            clustering = (uu, synth().hash_clustering(uu, clusters))
+        clustering = clustering_of(data, clusters)
         rec = P.RM2Job(conf, ctx).run(P.Ratings(ctx, *data["dev"]), clustering=clustering)
         rows, sums, st = rec.rows(), rec.sums(), rec.stats
         rec.close()
@@ -128,6 +125,57 @@ def check_rm2(data, rows, sums, st, top_n, lam, n_picks=10):
             assert exact(ix) <= lst_scores[-1] + RTOL * abs(lst_scores[-1])
     assert worst <= RTOL, worst
     return worst
+
+
+def clustering_of(data, clusters):
+    if clusters <= 1:
+        return None
+    uu = np.arange(1, data["facts"]["n_users"] + 1, dtype=np.int32)      # ids are 1..n in the synthetic shapes
+    return uu, synth().hash_clustering(uu, clusters)
+
+
+def all_rows_against_fp64_definition(data, rows, lam, clusters, label):
+    """EVERY row of a full-size job against the fp64 definition (tests/fp64_definition.py: torch fp64 on the card, pinned to the
+    reference's golden triples and to the brute-force oracle by tests/test_fp64_definition_cpu.py).  Pure relative 1e-5 -- north_star's
+    criterion, no absolute term.  Prints the measured maximum and returns the report."""
+    from fp64_definition import compare_with_definition, fp64_scores
+    ref = fp64_scores(data["dev"], rows, lam, data["facts"]["n_items"], clustering=clustering_of(data, clusters))
+    rep = compare_with_definition(rows, ref, rtol=RTOL)
+    print("%s: ALL %d rows against the fp64 definition: worst relative error %.2e, %d rows over 1e-5, 99.99th percentile %.1e; worst rows (user, item, got, fp64, rel): %s"
+          % (label, rep["rows"], rep["worst"], rep["n_over"], rep["p9999"], rep["worst_rows"][:3]))
+    assert rep["n_over"] == 0 and rep["worst"] <= RTOL, rep
+    return rep
+
+
+def whole_clusters_against_the_gram_oracle(data, rows, lam, top_n, clusters, selected, label):
+    """Whole clusters of a many-cluster job through oracle.rm2_gram (the CPU's fp64 Gram scorer, itself checked against the
+    brute-force oracle in tests/test_oracle_golden.py): every row of those clusters, pure relative 1e-5, lists tie-tolerant."""
+    import oracle
+    u, i, s = (t.cpu().numpy() for t in data["dev"])
+    mu, mc = clustering_of(data, clusters)
+    old = os.environ.get("RM2O_GRAM_BUDGET_GB")
+    os.environ["RM2O_GRAM_BUDGET_GB"] = "40"
+    try:
+        ref = oracle.rm2_gram(u, i, s, lam=lam, number_of_items=data["facts"]["n_items"], number_of_recommendations=top_n,
+                              number_of_clusters=clusters, map_user=mu, map_cluster=mc, n_threads=min(16, os.cpu_count() or 1),
+                              only_clusters=selected)
+    finally:
+        if old is None:
+            del os.environ["RM2O_GRAM_BUDGET_GB"]
+        else:
+            os.environ["RM2O_GRAM_BUDGET_GB"] = old
+    assert sorted(set(ref["rec_cluster"].tolist())) == sorted(selected)
+    m = np.isin(rows["cluster"], np.asarray(selected))
+    got = {k: rows[k][m] for k in ("user", "item", "score")}
+    og = np.argsort(got["user"], kind="stable")                       # both by ascending user id, list order kept
+    orf = np.argsort(ref["rec_user"], kind="stable")
+    a = {k: got[k][og] for k in got}
+    b = {"user": ref["rec_user"][orf], "item": ref["rec_item"][orf], "score": ref["rec_score"][orf]}
+    n_diff, worst = assert_same_lists(a, b, score_rtol=RTOL, tie_rtol=RTOL)
+    print("%s: clusters %s through the fp64 Gram oracle: %d rows, %d at a cut-off differ (ties), worst relative error %.2e (pure relative, no absolute slack)"
+          % (label, selected, len(a["user"]), n_diff, worst))
+    assert n_diff <= 1e-4 * len(a["user"])
+    return len(a["user"]), n_diff, worst
 
 
 def assert_same_lists(a, b, score_rtol=2e-6, tie_rtol=1e-5, score_atol=0.0):

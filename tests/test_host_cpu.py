@@ -66,3 +66,35 @@ def test_bench_refuses_a_mislabelled_gpu_count():
                              env=env, capture_output=True, text=True, timeout=300)
         assert out.returncode != 0 and "{" not in out.stdout
         assert out.stderr.count("needs an MI355X") >= 1          # the child ranks were started and refused to fall back
+
+
+def test_ranks_refuse_an_output_directory_that_holds_any_part_file(tmp_path):
+    """a rerun with world = 2 into the output directory of a job with a larger world (a foreign part-r-00003) must fail on
+    EVERY rank before its first collective -- Hadoop's FileOutputFormat.checkOutputSpecs refuses any existing output directory; with
+    several ranks the directory is shared, so it may exist but must hold no part file.  (The check needs no device: it runs here.)"""
+    import os
+    P = importlib.import_module("filmyou-core_amd")
+    sf = importlib.import_module("filmyou-core_amd.seqfile")
+    base = str(tmp_path / "recommendation")
+    u = np.array([1, 1, 2, 2], np.int32)
+    i = np.array([1, 2, 1, 3], np.int32)
+    sf.write_intpair_float(str(tmp_path / "input" / "ratings" / "data"), u, i, np.array([1, 2, 3, 4], np.float32))
+    sf.write_int_int(os.path.join(base, "clustering", "data"), np.array([1, 2], np.int32), np.array([0, 0], np.int32))
+    sf.write_int_int(os.path.join(base, "clusteringCount", "data"), np.array([0], np.int32), np.array([2], np.int32))
+    out = tmp_path / "output"
+    sf.write_intpair_float(str(out / "part-r-00003"), u, i, np.array([1, 1, 1, 1], np.float32))
+    os.makedirs(os.path.join(base, "rm2", "userSum"))
+    conf = P.Configuration()
+    conf.setFloat("lambda", 0.5)
+    conf.setInt("numberOfItems", 3)
+    conf.setInt("numberOfClusters", 1)
+    conf.set("directory", base)
+    conf.set("mapred.input.dir", str(tmp_path / "input" / "ratings"))
+    conf.set("mapred.output.dir", str(out))
+    for rank in (1, 0):
+        with pytest.raises(RuntimeError, match="RM2 failed!: output directory .* already exists and holds part-r-00003"):
+            P.RM2Job(conf).run_from_files(rank=rank, world=2, collectives=object())
+    assert sorted(os.listdir(str(out))) == [".part-r-00003.crc", "part-r-00003"] or sorted(os.listdir(str(out))) == ["part-r-00003"]
+    # an EMPTY shared directory is fine for several ranks (rank 0 may have created it), an existing one is not for a single rank
+    with pytest.raises(RuntimeError, match="RM2 failed!: output directory .* already exists"):
+        P.RM2Job(conf).run_from_files()

@@ -4,7 +4,7 @@ the single-LDS-chunk row kernel.  Same checks as at ML-25M shape (tests/fullsize
 comparison of the pruned job with the plain full pass (48 M rows)."""
 import pytest
 
-from fullsize_checks import assert_same_lists, check_itemsim, compare_itemsim_builds, check_rm2, load_shape, run_rm2
+from fullsize_checks import all_rows_against_fp64_definition, assert_same_lists, check_itemsim, compare_itemsim_builds, check_rm2, load_shape, run_rm2
 
 pytestmark = pytest.mark.gpu
 LAM, TOPN = 0.1, 100
@@ -25,6 +25,11 @@ def test_rm2_netflix_shape(data, pruned):
     assert st["blocks_total"] > 0 and st["blocks_survived"] < 0.05 * st["blocks_total"]
     worst = check_rm2(data, rows, sums, st, TOPN, LAM, n_picks=6)
     print("netflix-shape worst relative error vs fp64 definition: %.2e" % worst)
+
+
+def test_rm2_netflix_all_rows_against_the_fp64_definition(data, pruned):
+    """all 48 M rows of the top-100 job against the definition in fp64 (tests/fp64_definition.py)"""
+    all_rows_against_fp64_definition(data, pruned[0], LAM, 1, "Netflix shape, one cluster")
 
 
 def test_rm2_netflix_pruned_equals_full_pass_all_rows(data, pruned):

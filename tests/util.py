@@ -7,7 +7,10 @@ RTOL = 1e-5   # north_star: top-N lists match the reference within 1e-5 relative
 # A score is pvpi (positive, ~8 per rated item) plus a sum of negative logs; for tiny neighbourhoods with lambda near 1
 # the two cancel and |score| can be a few units while its terms are tens: a purely relative bound is ill-posed there.
 # The absolute slack is half of the tolerance the reference's own test uses (1e-4, T/util/HadoopIntegrationTest.java:53).
+# Since round 4 NO comparison gets it by default: assert_topn_matches is purely relative (north_star's criterion) unless a test
+# passes atol=ATOL itself and says why; every call adds to SLACK_TALLY how many of its comparisons needed an absolute term.
 ATOL = 5e-5
+SLACK_TALLY = {"calls": 0, "comparisons": 0, "needed_atol": 0, "worst_rel": 0.0}
 
 
 def pkg():
@@ -30,7 +33,7 @@ def full_ranking(ref):
     return out
 
 
-def assert_topn_matches(rows, ref_full, top_n, rtol=RTOL, atol=ATOL):
+def assert_topn_matches(rows, ref_full, top_n, rtol=RTOL, atol=0.0):
     """Tie-tolerant comparison of GPU top-N rows with the oracle's full ranking.
 
     The reference's PriorityQueue leaves the order of equal scores unspecified, and two scores closer
@@ -62,6 +65,8 @@ def assert_topn_matches(rows, ref_full, top_n, rtol=RTOL, atol=ATOL):
         if fin.any():
             err = np.abs(gs[fin] - want[fin]) / np.abs(want[fin])
             worst = max(worst, float(err.max()))
+            SLACK_TALLY["comparisons"] += int(fin.sum())
+            SLACK_TALLY["needed_atol"] += int((np.abs(gs[fin] - want[fin]) > rtol * np.abs(want[fin])).sum())
             assert np.all(np.abs(gs[fin] - want[fin]) <= rtol * np.abs(want[fin]) + atol), (u, err.max())
         assert np.all(gs[:-1] >= gs[1:]), "scores must be non-increasing"
         best = scores[:k]
@@ -70,4 +75,6 @@ def assert_topn_matches(rows, ref_full, top_n, rtol=RTOL, atol=ATOL):
         if fb.any():
             assert np.all(np.abs(gs[fb] - best[fb]) <= rtol * np.abs(best[fb]) + atol), (u, "k-th best mismatch")
     assert seen == set(ranking.keys())
+    SLACK_TALLY["calls"] += 1
+    SLACK_TALLY["worst_rel"] = max(SLACK_TALLY["worst_rel"], worst)
     return worst
