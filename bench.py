@@ -24,7 +24,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 L2_PEAK_GBS = 34500.0   # MI355X_MICROARCH.md, "L2 (per XCD)": ~34.5 TB/s aggregate over the 8 XCDs
-ICACHE_GATHER_GBS = 8600.0   # MI355X_MICROARCH.md, "Indexed rows": uniformly random 1 152-byte rows of a 38 MB table (served from the Infinity Cache): 8.6 TB/s chip-wide
+NUM_CUS, CLOCK_HZ = 256, 2.4e9   # MI355X_MICROARCH.md
+DS_ADD_U64_CYCLES = 10.8         # profiles/r2/micro_lds_atomic_rate.txt (tools/micro/lds_atomic_rate.hip): cycles per ds_add_u64 wave instruction, random addresses, every CU
+V_LOG_F32_PEAK = NUM_CUS * 4 * 16 / 4 * CLOCK_HZ   # transcendental (quarter) rate: 4 SIMDs x 16 lanes / 4 per clock per CU = 9.8e12 v_log_f32 per second
 DTYPE = "f32 (scores and logs fp32 / v_log_f32, folded in fp64; co-rating sums 64-bit fixed point in LDS (fp64 fallback); G stored as 24-bit e7m17 floats scaled per cluster above 4096 items; ratings fp16 in the row kernel when exactly representable)"
 
 
@@ -258,9 +260,21 @@ def main():
                 "algorithmic_bytes_per_launch": 8.0 * unordered_pairs / max(1, st["cooc_launches"]),
                 "share_of_step": ms_cooc / ms_per_step if ms_per_step > 0 else None}
     roofline["frac"] = roofline["achieved"] / HBM_PEAK_GBS
+    roofline["unit_note"] = ("achieved / frac use SURVEY 8d's unit, 8 B per unordered co-rating pair; the packed symmetric walk reads 4 B per pair, "
+                             "so this is the survey's model, not the kernel's own bytes: see frac_own_bytes and lds_atomic_floor_ms")
     if roofline["frac"] > 1.0:
         roofline["note"] = ("SURVEY 8d's unit (8 B per unordered co-rating pair) overstates this launch: the packed symmetric walk reads 4 B per unordered "
                             "pair and the column chunks stay in L2 / Infinity Cache; the fraction is the model's, not measured HBM traffic")
+    # The kernel's OWN minimum traffic: one 4-byte packed entry per unordered pair, 12 B of descriptor per <= 64-entry segment, and the
+    # matrix / panel / bound rows it stores (fy_stats::cooc_segments, cooc_matrix_bytes) -- against the same 8 TB/s
+    own_bytes = 4.0 * unordered_pairs + 12.0 * st.get("cooc_segments", 0) + float(st.get("cooc_matrix_bytes", 0))
+    roofline["own_bytes_per_step"] = own_bytes
+    roofline["frac_own_bytes"] = own_bytes / (ms_cooc * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_cooc > 0 else None
+    # ... and what actually bounds it on chip: every segment is one ds_add_u64 wave instruction on random LDS columns
+    # (10.8 cycles each, measured with every CU busy): the LDS-atomic floor of the launch, whatever the memory system delivers
+    floor_ms = st.get("cooc_segments", 0) * DS_ADD_U64_CYCLES / (NUM_CUS * CLOCK_HZ) * 1e3
+    roofline["lds_atomic_floor_ms"] = floor_ms
+    roofline["frac_of_lds_atomic_floor"] = floor_ms / ms_cooc if ms_cooc > 0 else None
     # the symmetric walk leaves the lower triangle to the mirror pass (k_mirror_tiles / k_mirror_diag): the matrix build as a whole
     ms_mirror = mean("ms_mirror")
     roofline["with_mirror_pass"] = {"ms": ms_cooc + ms_mirror, "achieved": 8.0 * unordered_pairs / ((ms_cooc + ms_mirror) * 1e-3) / 1e9 if ms_cooc > 0 else 0.0,
@@ -281,18 +295,27 @@ def main():
              "note": "4 B per evaluated log term against the L2; SURVEY 8d's unit (4 B x the reference's terms) does not apply: "
                      "98.6 % of those terms are excluded by the exact bound, never read"}
     other["frac"] = other["achieved"] / L2_PEAK_GBS
-    # What the kernels actually do is GATHER 768-byte row segments, one per rated item, from two 45 MB panels (at ML-25M shape): an
-    # XCD's 4 MiB L2 holds a tenth of them, the rest comes from the Infinity Cache.  The guide's measured rate for that access shape
-    # is the practical bound; the popular rows -- rated most often -- are the ones an L2 keeps, which is why the fraction can pass 1.
-    other["against_gathered_rows_from_infinity_cache"] = {
-        "peak": ICACHE_GATHER_GBS, "unit": "GB/s", "frac": other["achieved"] / ICACHE_GATHER_GBS,
-        "note": "MI355X_MICROARCH.md 'Indexed rows': 8.6 TB/s for uniformly random rows of a 38 MB table; the scoring kernels' panels are 2 x 45 MB, "
-                "read in 768-byte segments in the (popularity-skewed) order of the users' lists"}
-
+    # CU-side bytes (L2 -> CU) of the family from the TCP_TCC_READ_REQ pass of tools/profile_round.sh, when the stamped traffic.json
+    # holds it: measured bytes / ms against the aggregate L2 bandwidth (requests priced at the bytes per request calibrated on the
+    # same run's k_isim_sweep, whose 14 GB streaming read is known)
+    l2 = traffic.get("k_score", {}).get("l2_read_bytes_per_step")
+    other["l2_to_cu_bytes_per_step"] = l2
+    other["frac_measured_l2_bytes"] = (l2 / (ms_score * 1e-3) / 1e9 / L2_PEAK_GBS) if (l2 and ms_score > 0) else None
     phases = {k: mean(k) for k in ("ms_prepare", "ms_tables", "ms_cooc", "ms_mirror", "ms_score", "ms_topn", "ms_total")}
     phases["ms_job"] = phases["ms_prepare"] + phases["ms_total"]            # ms_total = everything after prepare (HIP events)
     phases["ms_other_in_job"] = phases["ms_total"] - phases["ms_tables"] - phases["ms_cooc"] - phases["ms_mirror"] - phases["ms_score"] - phases["ms_topn"]
     phases["ms_host_gaps"] = ms_per_step - phases["ms_job"]                  # wall clock outside the two event spans
+    # The phases no kernel roofline covers, each against HBM with a stated byte model (what the phase must move at the least):
+    #   prepare  read the COO (12 B per rating), write the CSR (8 B) and the CSC (12 B per rating: slot, rating, pair)
+    #   tables   read CSR + CSC once (20 B per rating), write the packed CSR (4 B per rating) and the segment table (12 B per segment)
+    #   mirror   read and write the lower triangle of the stored matrix (half of what the row kernels stored, twice)
+    nnz = float(st["nnz"])
+    pm = {"prepare": 32.0 * nnz, "tables": 24.0 * nnz + 12.0 * st.get("cooc_segments", 0), "mirror": float(st.get("cooc_matrix_bytes", 0))}
+    roofline_phases = {}
+    for name, b in pm.items():
+        ms = phases["ms_" + name]
+        roofline_phases[name] = {"bound": "hbm", "model_bytes": b, "ms": ms, "achieved": b / (ms * 1e-3) / 1e9 if ms > 0 else None, "peak": HBM_PEAK_GBS,
+                                 "unit": "GB/s", "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else None}
     out = {
         "metric": "top-N recs/sec (RM2), %s shape" % a.shape, "value": total_recs / (elapsed / a.steps), "unit": "recs/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -308,7 +331,7 @@ def main():
         "phase_ms_rank0": phases, "datagen_s": gen_s,
         "job_stats_rank0": {k: int(st[k]) for k in ("n_clusters_nonempty", "cooc_launches", "score_launches", "panel_clusters", "blocks_total",
                                                      "blocks_survived", "stray_blocks", "bound_repairs", "prune_fallbacks", "topn_select_users")},
-        "roofline": roofline, "roofline_other_kernel": other,
+        "roofline": roofline, "roofline_other_kernel": other, "roofline_phases": roofline_phases,
         "kernel_source_rev": rev,
     }
 
@@ -345,6 +368,10 @@ def main():
                              "log_terms_per_s": t2 / (el2 / 2),
                              "phase_ms": {k: float(np.mean([x[k] for x in s2])) for k in ("ms_prepare", "ms_tables", "ms_cooc", "ms_mirror", "ms_score", "ms_topn", "ms_total")},
                              "pruned": bool(s2[-1]["blocks_total"] > 0), "panel_clusters": int(s2[-1]["panel_clusters"]),
+                             # a job that takes the plain full pass evaluates every log term: its ceiling is the v_log_f32 issue rate
+                             "full_pass_frac_of_v_log_f32_peak": (t2 / (float(np.mean([x["ms_score"] for x in s2])) * 1e-3) / V_LOG_F32_PEAK)
+                                                                 if (s2[-1]["blocks_total"] == 0 and np.mean([x["ms_score"] for x in s2]) > 0) else None,
+                             "log_terms_evaluated": int(s2[-1]["log_terms_evaluated"]) if s2[-1]["blocks_total"] else int(s2[-1]["log_terms"]),
                              "blocks_survived_frac": (s2[-1]["blocks_survived"] / s2[-1]["blocks_total"]) if s2[-1]["blocks_total"] else None,
                              "stray_blocks": int(s2[-1]["stray_blocks"]), "bound_repairs": int(s2[-1]["bound_repairs"])}
             except RuntimeError as e:
@@ -413,14 +440,16 @@ def main():
             _, _, counts = job_c.run(Hd, first_user=1)
             fence()
             dt_c = time.perf_counter() - t0
-            gpu_ms = drv.stats["ms_total"] - drv.stats["ms_prepare"]
+            gpu_ms = drv.stats["ms_cooc"]            # the iterations alone (HIP events around the loop: H / W resident in HBM)
             bytes_it = 2.0 * facts["nnz"] * (12 + 8 * kf) + 3.0 * 8 * kf * (facts["n_users"] + facts["n_items"])
             out["factorization"] = {"what": "PPC, k = %d, %d iterations (host H/W in and out) + cluster assignment" % (kf, iters),
                                     "seconds": dt_f, "ms_per_iteration_gpu": gpu_ms / iters, "ms_prepare": drv.stats["ms_prepare"],
+                                    "ms_call_with_host_transfers": drv.stats["ms_total"],
                                     "roofline": {"bound": "hbm", "achieved": bytes_it / (gpu_ms / iters * 1e-3) / 1e9,
                                                  "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                  "frac": bytes_it / (gpu_ms / iters * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                                 "note": "ms_per_iteration_gpu still contains the H/W transfers of the call"},
+                                                 "note": "iterations alone (H / W in HBM); algorithmic bytes: two SpMMs of 12 B + one k-row of the dense factor per rating, "
+                                                         "the updates stream H, W, X once"},
                                     "cluster_assign_ms": 1e3 * dt_c, "users_per_s_cluster_assign": facts["n_users"] / dt_c,
                                     "largest_cluster": int(counts.max())}
         except RuntimeError as e:

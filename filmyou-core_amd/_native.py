@@ -143,7 +143,8 @@ class Stats(C.Structure):
                 ("log_terms_evaluated", C.c_int64), ("prune_fallbacks", C.c_int64), ("ms_tables", C.c_double), ("ms_mirror", C.c_double), ("topn_select_users", C.c_int64),
                 ("panel_clusters", C.c_int64), ("stray_blocks", C.c_int64), ("bound_repairs", C.c_int64),
                 ("isim_candidates", C.c_int64), ("isim_redone_rows", C.c_int64),
-                ("prepared_from_cache", C.c_int64), ("tables_from_cache", C.c_int64)]
+                ("prepared_from_cache", C.c_int64), ("tables_from_cache", C.c_int64),
+                ("cooc_segments", C.c_int64), ("cooc_matrix_bytes", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

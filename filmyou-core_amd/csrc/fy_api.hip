@@ -28,6 +28,7 @@ void fy::load_tuning_from_env(Tuning& t) {
     if (const char* e = getenv("FY_SCORE_SLICES")) t.max_slices = atoi(e);
     if (const char* e = getenv("FY_SCORE_UPW")) { int v = atoi(e); if (v >= 1) t.users_per_wave = v; }
     if (const char* e = getenv("FY_PRUNE")) t.prune = atoi(e) != 0;
+    if (const char* e = getenv("FY_LAZY_MIRROR")) t.lazy_mirror = atoi(e) != 0;
     if (const char* e = getenv("FY_COOP")) t.coop = atoi(e) != 0;
     if (const char* e = getenv("FY_COOP_FORCE")) t.coop_force = atoi(e) != 0;
     if (const char* e = getenv("FY_COOC_PK")) t.cooc_pk = atoi(e) != 0;
@@ -52,7 +53,7 @@ void fy::load_tuning_from_env(Tuning& t) {
     if (const char* e = getenv("FY_PANEL_LANES")) { int v = atoi(e); if (v >= 1 && v <= 8) t.panel_lanes = v; }
     if (const char* e = getenv("FY_PRUNE_MIN_ITEMS")) { t.prune_min_items = atoi(e); t.prune_min_users = 0; }   // (a forced item threshold -- tests -- lifts the user threshold too)
     if (const char* e = getenv("FY_PRUNE_MIN_USERS")) { int v = atoi(e); if (v >= 0) t.prune_min_users = v; }
-    if (const char* e = getenv("FY_SEED_CHUNKS")) { int v = atoi(e); if (v >= 0 && v <= 4) { t.seed_chunks = v; t.seed_forced = v > 0; } }
+    if (const char* e = getenv("FY_SEED_CHUNKS")) { int v = atoi(e); if (v >= 0 && v <= 40) { t.seed_chunks = v; t.seed_forced = v > 0; } }     // (40 = SEED_CHUNKS_MAX, fy_rm2_kernels.hpp)
     if (const char* e = getenv("FY_WORKSPACE_GB")) { long v = atol(e); if (v >= 1) t.workspace_default = (int64_t)v << 30; }
     if (const char* e = getenv("FY_LANES")) { int v = atoi(e); if (v >= 1 && v <= 8) { t.lanes = v; t.lanes_forced = true; } }
     if (const char* e = getenv("FY_COOC_BLOCK")) { int v = atoi(e); if (v == 256 || v == 512 || v == 1024) t.cooc_block = v; }

@@ -284,6 +284,8 @@ void nmf_factorize(Context* ctx, const fy_nmf_params* prm, const fy_ratings* R, 
     double* h2 = H2.get();
     double* w2 = W2.get();
     const int f = prm->normalization_frequency;
+    EventTimer t_iter(ctx);      // the iterations alone: H / W are in HBM (the uploads are in front of it, the downloads behind)
+    const size_t sp_iter = t_iter.begin();
     for (int32_t it = 1; it <= prm->number_of_iterations; it++) {
         // H2 from (H, W)
         k_nmf_spmm_chunks<<<grid_for((int64_t)cu.n * 64, 256), 256, 0, s>>>(cu.n, k, cu.row.get(), cu.ptr.get(), uptr.get(), ku_s.get(), vu.get(), w, spart.get());
@@ -311,6 +313,7 @@ void nmf_factorize(Context* ctx, const fy_nmf_params* prm, const fy_ratings* R, 
         std::swap(h, h2);
         std::swap(w, w2);
     }
+    t_iter.end(sp_iter);
     d2h(ctx, H_host, h, (size_t)nU * k);
     d2h(ctx, W_host, w, (size_t)nI * k);
     t_total.end(sp_total);
@@ -322,6 +325,7 @@ void nmf_factorize(Context* ctx, const fy_nmf_params* prm, const fy_ratings* R, 
         st->n_items = nI;
         st->ms_prepare = t_prep.total_ms();
         st->ms_total = t_total.total_ms();
+        st->ms_cooc = t_iter.total_ms();      // (fy_stats has no field of its own for it: "the job's main kernels", like the RM2 matrix build)
     }
 }
 

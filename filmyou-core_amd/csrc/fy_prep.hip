@@ -704,6 +704,52 @@ void rank_slot_range(const Prepared& P, int rank, int world, int32_t& lo, int32_
     const int32_t n = P.nU;
     if (world <= 1 || n == 0) { lo = 0; hi = n; return; }
     const int64_t total = P.work_prefix[n - 1];
+    // At least as many non-empty clusters as ranks: WHOLE clusters per rank (the reference runs one reduce group per
+    // cluster, RM2Job.java:251) -- no cluster's co-rating matrix is then built on two ranks and nothing but the item statistics is
+    // exchanged.  Ownership stays a contiguous slot range (slots are cluster-major), so the clusters are cut into `world` contiguous
+    // runs of the cluster order with the smallest possible largest run (linear partition: binary search on the cap, greedy fill).
+    // Every rank computes the same cuts from the same prefix.
+    {
+        std::vector<int32_t> ends;          // last slot + 1 of every non-empty cluster, ascending
+        for (int c = 0; c < P.K; c++)
+            if (P.ucstart[c + 1] > P.ucstart[c]) ends.push_back(P.ucstart[c + 1]);
+        if ((int)ends.size() >= world) {
+            auto upto = [&](int32_t slot_end) -> int64_t { return slot_end > 0 ? P.work_prefix[slot_end - 1] : 0; };
+            auto runs_needed = [&](int64_t cap, std::vector<int32_t>* cuts) -> int {
+                int runs = 1;
+                int64_t start = 0;      // work in front of the current run
+                int32_t prev_end = 0;
+                if (cuts) cuts->clear();
+                for (size_t k = 0; k < ends.size(); k++) {
+                    const int64_t here = upto(ends[k]);
+                    if (here - start > cap && prev_end > 0 && upto(prev_end) > start) {     // close the run in front of this cluster
+                        if (cuts) cuts->push_back(prev_end);
+                        runs++;
+                        start = upto(prev_end);
+                    }
+                    if (here - start > cap) return world + 1;                                // a single cluster above the cap
+                    prev_end = ends[k];
+                }
+                return runs;
+            };
+            int64_t lo_cap = 0, hi_cap = total;
+            while (lo_cap < hi_cap) {
+                const int64_t mid = lo_cap + (hi_cap - lo_cap) / 2;
+                if (runs_needed(mid, nullptr) <= world) hi_cap = mid; else lo_cap = mid + 1;
+            }
+            std::vector<int32_t> cuts;
+            runs_needed(hi_cap, &cuts);
+            // fewer runs than ranks (one huge cluster among small ones): the last ranks stay empty rather than split a cluster
+            auto cut_at = [&](int r) -> int32_t {
+                if (r <= 0) return 0;
+                if (r >= world) return n;
+                return r - 1 < (int)cuts.size() ? cuts[(size_t)r - 1] : n;
+            };
+            lo = cut_at(rank);
+            hi = cut_at(rank + 1);
+            return;
+        }
+    }
     auto cut = [&](int r) -> int32_t {
         if (r <= 0) return 0;
         if (r >= world) return n;

@@ -859,12 +859,19 @@ __device__ __forceinline__ uint32_t fy_load24(const uint32_t* __restrict__ row3,
 constexpr int MIRROR_PITCH = 772;    // bytes per LDS row: 768 + 4 (an odd number of dwords spreads the rows over the banks)
 
 extern __shared__ __attribute__((aligned(16))) unsigned char fy_mirror_lds[];   // [128][MIRROR_PITCH]: the destination rows, packed
-__device__ __forceinline__ void mirror_tiles_body(float* __restrict__ M_, int64_t ldm, int32_t Ic, float* __restrict__ Bmax_, int64_t ldb) {
+// `need` / `write_below` (round 4, the LAZY mirror of the pruned one-cluster job): the transposed tile is stored only for the column blocks
+// somebody reads -- B < write_below (the seed columns) or need[B] != 0 (blocks with survivors, flagged on the device by
+// k_flag_surviving_blocks) -- while the block maxima (Bmax_ != nullptr) are taken from every tile.  The full mirror is write_below =
+// INT_MAX.  Measured: the survivors of the headline job (22 600 (user, block) pairs) lie in 8 of its 231 column blocks.
+__device__ __forceinline__ void mirror_tiles_body(float* __restrict__ M_, int64_t ldm, int32_t Ic, float* __restrict__ Bmax_, int64_t ldb,
+                                                  const int32_t* __restrict__ need = nullptr, int32_t write_below = 0x7FFFFFFF) {
     __shared__ uint32_t rowmax[128];
     const int tj = blockIdx.x, B = blockIdx.y;
     if (tj < 2 * (B + 1)) return;                         // only tiles strictly behind the diagonal block are sources
     const int dst_row0 = 128 * tj;
     if (dst_row0 >= Ic) return;                           // destination rows are real rows (the padding columns have none)
+    const bool write = B < write_below || (need && need[B] != 0);      // block-uniform
+    if (!write && !Bmax_) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const int64_t pitch = ldm * 3;
     unsigned char* __restrict__ Mb = reinterpret_cast<unsigned char*>(M_);
@@ -882,10 +889,12 @@ __device__ __forceinline__ void mirror_tiles_body(float* __restrict__ M_, int64_
         }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            unsigned char* d = fy_mirror_lds + (4 * m + q) * MIRROR_PITCH + 3 * r;    // destination row 4m + q, element r
-            d[0] = (unsigned char)v[q];
-            d[1] = (unsigned char)(v[q] >> 8);
-            d[2] = (unsigned char)(v[q] >> 16);
+            if (write) {
+                unsigned char* d = fy_mirror_lds + (4 * m + q) * MIRROR_PITCH + 3 * r;    // destination row 4m + q, element r
+                d[0] = (unsigned char)v[q];
+                d[1] = (unsigned char)(v[q] >> 8);
+                d[2] = (unsigned char)(v[q] >> 16);
+            }
             mx[q] = max(mx[q], v[q]);
         }
     }
@@ -894,7 +903,7 @@ __device__ __forceinline__ void mirror_tiles_body(float* __restrict__ M_, int64_
         if (mx[q]) atomicMax(&rowmax[4 * m + q], mx[q]);
     __syncthreads();
     // ---- store: one destination row (768 bytes = one 256-column block) per wave step
-    for (int c = wave; c < 128; c += nwaves) {
+    for (int c = wave; write && c < 128; c += nwaves) {
         const int dst_row = dst_row0 + c;
         if (dst_row >= Ic) break;
         const uint32_t* __restrict__ sp = reinterpret_cast<const uint32_t*>(fy_mirror_lds + c * MIRROR_PITCH) + 3 * lane;
@@ -912,8 +921,17 @@ __device__ __forceinline__ void mirror_tiles_body(float* __restrict__ M_, int64_
     }
 }
 
-__global__ __launch_bounds__(1024) void k_mirror_tiles(float* __restrict__ M_, int64_t ldm, int32_t Ic, float* __restrict__ Bmax_, int64_t ldb) {
-    mirror_tiles_body(M_, ldm, Ic, Bmax_, ldb);
+__global__ __launch_bounds__(1024) void k_mirror_tiles(float* __restrict__ M_, int64_t ldm, int32_t Ic, float* __restrict__ Bmax_, int64_t ldb,
+                                                       const int32_t* __restrict__ need, int32_t write_below) {
+    mirror_tiles_body(M_, ldm, Ic, Bmax_, ldb, need, write_below);
+}
+// need[b] = 1 for every block b some user of the batch keeps (the survivor lists of k_bound_select)
+__global__ void k_flag_surviving_blocks(int32_t n_users, const int32_t* __restrict__ n_quads, const uint16_t* __restrict__ surv, int64_t ldb, int32_t* __restrict__ need) {
+    for (int32_t u = blockIdx.x; u < n_users; u += gridDim.x)
+        for (int k = threadIdx.x; k < n_quads[u]; k += blockDim.x) {
+            const int b = surv[(int64_t)u * ldb + k];
+            if (need[b] == 0) need[b] = 1;      // (benign race: every writer stores 1)
+        }
 }
 // diagonal blocks: thread c owns row 256 B + c; element (c, r) for r < c is element (r, c) of a row above (a 3-byte gather),
 // the rest of the row's segment is its own; the maximum over the completed segment is Bmax[row][B]
@@ -1046,15 +1064,21 @@ __global__ __launch_bounds__(256) void k_panel_colmax(const PanelDesc* __restric
     }
 }
 
-static void launch_mirror(Context* ctx, float* M, int64_t ldm, int32_t Ic, float* Bmax, int64_t ldb, hipStream_t st) {
+// full mirror: write_below = INT_MAX.  Lazy mirror, first pass (block maxima from every tile, lower triangle only for the column blocks
+// in front of write_below + the diagonal blocks): need = nullptr, write_below = seed blocks.  Second pass (after the survivors are
+// known): Bmax = nullptr, need = the flags, write_below = 0, diag = false -- a tile of an unflagged block leaves at once.
+static void launch_mirror(Context* ctx, float* M, int64_t ldm, int32_t Ic, float* Bmax, int64_t ldb, hipStream_t st, const int32_t* need = nullptr,
+                          int32_t write_below = 0x7FFFFFFF, bool diag = true) {
     const int nblk = (int)(ldm / 256), ntile = (int)(ldm / 128);
     if (nblk > 1) {
         FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mirror_tiles), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * MIRROR_PITCH));
-        k_mirror_tiles<<<dim3(ntile, nblk - 1), 1024, 128 * MIRROR_PITCH, st>>>(M, ldm, Ic, Bmax, ldb);
+        k_mirror_tiles<<<dim3(ntile, nblk - 1), 1024, 128 * MIRROR_PITCH, st>>>(M, ldm, Ic, Bmax, ldb, need, write_below);
         FY_KERNEL_CHECK();
     }
-    k_mirror_diag<<<nblk, 256, 0, st>>>(M, ldm, Ic, Bmax, ldb);
-    FY_KERNEL_CHECK();
+    if (diag) {
+        k_mirror_diag<<<nblk, 256, 0, st>>>(M, ldm, Ic, Bmax, ldb);
+        FY_KERNEL_CHECK();
+    }
 }
 
 static void cooc_rm2_allow_lds() {
@@ -1107,6 +1131,7 @@ using namespace fy;
 // & FY_RM2_NO_CACHE builds it afresh and does not keep it: the "cold" job, which bench.py times as its headline value.
 struct TableCache {
     bool valid = false;
+    int64_t total_segments = 0;         // segments in all tables of the job (fy_stats::cooc_segments)
     std::vector<int32_t> sig;           // what the tables were built for: per planned cluster (c, CH, nch, half, panel, p_eff, tail_chunks), + flags
     bool have_x = false;
     DevBuf<float> csc_x, csc_x_over_s;  // x = r / s_v (and x / s_v for the packed walk) per CSC entry: ratings only
@@ -1458,6 +1483,7 @@ static void build_tables_all(Context* ctx, const Prepared& P, const std::vector<
     FY_HIP(hipStreamSynchronize(st));       // the ONE host round trip of the job's tables (d_co / d_sd's host copies are done too)
     tc.g_seg.alloc(ctx, (size_t)std::max(1, total));
     tc.g_w.alloc(ctx, (size_t)std::max(1, total));
+    tc.total_segments = total;
     const float* csc_w = use_pk ? tc.csc_x_over_s.get() : tc.csc_x.get();
     const dim3 g_f((unsigned)grid_for((((int64_t)max_nq + 63) >> 6) * 64 * 4, 256, 4096), n_main), g_ft((unsigned)grid_for((((int64_t)max_nq + 63) >> 6) * 64, 256, 4096), std::max(1u, n_tail));
     k_seg_fill_multi<<<g_f, 256, 0, st>>>(d_sd.get(), P.csc_slot.get(), csc_w, tc.g_co.get(), tc.g_ptr.get(), tc.g_seg.get(), tc.g_w.get(), tc.csc_rank.get(),
@@ -1617,7 +1643,14 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
     ScoreTune tune = score_tune(ctx);
     // tau_u is the N-th best of the seed scores: a seed of only a few N columns gives a weak threshold and many survivors
     // (Netflix shape, N = 100: 2.7 % of the blocks survive a 256-column seed, 0.1 % a 512-column one)
-    if (tune.seed_chunks == 0) tune.seed_chunks = (int)std::min<int64_t>(4, std::max<int64_t>(1, ceil_div(5 * (int64_t)prm.number_of_recommendations, 256)));
+    // (round 4: also for long lists -- the reference's default is N = 1000, RMRecommenderDriver.java:95 -- whose seed is 5 N columns too:
+    // 5120 of ML-25M's 59 047; up to round 3 the seed stopped at 1024 columns, whose 1000th best is no threshold at all, and such
+    // jobs took the plain full pass)
+    if (tune.seed_chunks == 0) tune.seed_chunks = (int)std::min<int64_t>(SEED_CHUNKS_MAX, std::max<int64_t>(1, ceil_div(5 * (int64_t)prm.number_of_recommendations, 256)));
+    // lists the one-wave seed sort cannot hold (k_topn_seed: at most TOPN_SAMPLE seed columns, lists of at most TOPN_LONG items) take
+    // k_topn_long in its seed / merge modes
+    const bool long_seed = tune.seed_chunks * 256 > TOPN_SAMPLE || prm.number_of_recommendations > TOPN_LONG;
+    const bool short_seed_ok = tune.seed_forced || 5 * (int64_t)prm.number_of_recommendations <= 4 * 256;     // (the cooperative path's limit)
     const bool pack24_allowed = tune.pack24 != 0;
     int64_t coop_pair_contribs = 0;   // cooperative clusters: ordered off-diagonal co-rating pairs of this rank's matrix rows
     bool any_coop = false;
@@ -1687,7 +1720,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
         if (nonempty == 1) {   // one neighbourhood: it is scored cooperatively when it is big enough for the branch and bound
             const int32_t Ic1 = P.pcstart[c1 + 1] - P.pcstart[c1];
             J->count_balanced = Ic1 >= tune.pack24_min_items && Ic1 >= tune.prune_min_items && ceil_div(Ic1, PRUNE_BLOCK) < 0xFFFF &&
-                                P.nU >= prm.world && (tune.seed_forced || 5 * (int64_t)prm.number_of_recommendations <= 4 * 256);
+                                P.nU >= prm.world && short_seed_ok && !long_seed;
         }
     }
     int32_t own_lo, own_hi;
@@ -1769,13 +1802,15 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             // N = 1000 at ML-25M shape: 77 % of the blocks survive and the three passes cost twice the plain one)
             // (and clusters of a few hundred users are not pruned at all: their seed thresholds are weak -- at 400 clusters of ML-25M
             // shape, 406 users each, 16-44 % of the blocks survive and the plain full pass is 1.6x faster than any pruned variant)
+            // (long lists: the seed is 5 N columns; where that is more than a third of the cluster's items the bound has nothing left to
+            // exclude and the plain full pass is taken)
             p.prune = tune.prune && p.pack24 && p.Ic >= tune.prune_min_items && p.nblk < 0xFFFF && p.Uc >= tune.prune_min_users &&
-                      (tune.seed_forced || 5 * (int64_t)prm.number_of_recommendations <= 4 * 256);
+                      (tune.seed_forced || 3 * (int64_t)tune.seed_chunks * 256 <= (int64_t)p.Ic);
             if (J->count_balanced && !p.prune) FY_FAIL(FY_ERR_STATE, "internal: count-balanced ownership without a cooperative cluster");
             // all ranks hold users of this cluster and can talk to each other: score it together, every rank with its
             // share of the matrix rows (score_cluster_coop)
             p.coop = false;
-            if (p.prune && tune.coop && ((prm.world > 1 && J->have_coll) || tune.coop_force)) {
+            if (p.prune && tune.coop && short_seed_ok && !long_seed && ((prm.world > 1 && J->have_coll) || tune.coop_force)) {
                 p.coop = true;
                 for (int k = 0; k < prm.world; k++) {
                     int32_t lo_k, hi_k;
@@ -1798,6 +1833,14 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
         {   // column-panel mode: many pruned clusters on this rank (the reference's regime: numberOfClusters ~ 50)
             int n_pruned = 0;
             for (auto& p : plans) n_pruned += (p.prune && !p.coop) ? 1 : 0;
+            // Long lists are pruned only where a few big clusters keep their dense matrices.  Measured at 50 clusters of ML-25M shape with
+            // N = 1000 (round 4): 41 % of the (user, block) pairs survive the bound of a 3 250-user cluster and 10 M of them lie behind
+            // the panel -- 14.9 s per job against 0.67 s for the plain full pass; one cluster: 14 % survive, 271 against 471 ms.
+            if (long_seed && n_pruned >= tune.panel_min_clusters && !tune.seed_forced) {
+                for (auto& p : plans)
+                    if (!p.coop) p.prune = false;
+                n_pruned = 0;
+            }
             if (n_pruned >= tune.panel_min_clusters)
                 for (auto& p : plans)
                     if (p.prune && !p.coop && use_pk && p.nch < 256 && p.nsub < 0xFFFF && p.Uc <= STRAY_UCAP) {
@@ -1913,6 +1956,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             DevBuf<int2> strayT;           // co-rater tables of k_score_stray
             DevBuf<int2> stray_items;
             DevBuf<int32_t> n_heavy;       // k_count_heavy
+            DevBuf<int32_t> need;          // lazy mirror: column blocks with survivors
             DevBuf<int32_t> n_quads, quad_prefix;
             DevBuf<char> scan_tmp;         // temporary storage of the lane's scans
             DevBuf<int2> item_seg, item_seg_t;      // (_t: the tail-row bound launch of a cluster whose row kernels are batched)
@@ -2404,7 +2448,11 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             if (!batched) R->st.cooc_launches++;
             if (p.half) {    // lower triangle + the block maxima in front of / on the diagonal
                 const size_t sm = t_mirror.begin(ls);
-                launch_mirror(ctx, L.M.get(), ldm, Ic, p.prune ? L.Bmax.get() : nullptr, p.ldb, ls);
+                // pruned flow: LAZY mirror -- the seed pass reads the seed columns of every row, the bound pass the block maxima, the
+                // survivor pass the surviving column blocks (mirrored below, once they are known); nothing else of the lower triangle
+                // is ever read, so it is not written (round 3 moved 10.7 GB here to fill a triangle of which a few per cent were read)
+                const bool lazy = p.prune && tune.lazy_mirror;
+                launch_mirror(ctx, L.M.get(), ldm, Ic, p.prune ? L.Bmax.get() : nullptr, p.ldb, ls, nullptr, lazy ? std::min(tune.seed_chunks, p.nblk) : 0x7FFFFFFF);
                 t_mirror.end(sm, ls);
             }
             }      // do_build
@@ -2496,7 +2544,10 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 TopNArgs T1{L.S.get(), SC, Ic, n_out.get(), out_off.get(), P.rank_item_raw.get() + pbase, P.slot2du.get(), P.uid.get(),
                             lo, s0, c, R->d_key0.get(), R->d_key1.get(), R->d_value.get(), R->d_aux.get(),
                             1, seed_chunks * 256, L.surv.get(), L.n_quads.get(), bld, L.tau.get()};
-                {
+                if (long_seed) {
+                    k_topn_long<<<nb, 256, (size_t)fy_topn_long_cap(prm.number_of_recommendations) * 8, ls>>>(T1, L.overflow.get(), L.any_overflow.get(), 0,
+                                                                                                         fy_topn_long_cap(prm.number_of_recommendations));
+                } else {
                     int lp2 = 64;                   // the sort's size: the seed columns, at most TOPN_SAMPLE
                     while (lp2 < std::min<int>(std::min<int>(Ic, seed_chunks * 256), TOPN_SAMPLE)) lp2 <<= 1;
                     k_topn_seed<<<(nb + 3) / 4, 256, (size_t)4 * lp2 * sizeof(uint64_t), ls>>>(T1, nb, L.overflow.get(), lp2);
@@ -2511,6 +2562,21 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                     k_bound_select<<<grid_for((int64_t)nb * 64, 256), 256, 0, ls>>>(L.UB.get(), p.ldb, p.nblk, seed_blocks, L.tau.get(), pvpi.get() + (s0 - lo), nb,
                                                                                    L.surv.get(), L.n_quads.get());
                 FY_KERNEL_CHECK();
+                if (tune.debug_sync == 3 && !p.panel) {      // which blocks survive, and for how many users
+                    DevBuf<int32_t> cnt(ctx, (size_t)p.nblk + 1);
+                    FY_HIP(hipMemsetAsync(cnt.get(), 0, ((size_t)p.nblk + 1) * sizeof(int32_t), ls));
+                    k_surv_block_counts<<<std::min<int>(nb, 4096), 64, 0, ls>>>(nb, L.n_quads.get(), L.surv.get(), p.ldb, cnt.get());
+                    std::vector<int32_t> hc((size_t)p.nblk + 1);
+                    FY_HIP(hipMemcpyAsync(hc.data(), cnt.get(), hc.size() * sizeof(int32_t), hipMemcpyDeviceToHost, ls));
+                    FY_HIP(hipStreamSynchronize(ls));
+                    int distinct = 0;
+                    long long total = 0;
+                    for (int b2 = 0; b2 < p.nblk; b2++) { distinct += hc[b2] > 0; total += hc[b2]; }
+                    fprintf(stderr, "[fy] cluster %d: %lld surviving (user, block) pairs in %d distinct blocks of %d:", c, total, distinct, p.nblk);
+                    for (int b2 = 0; b2 < p.nblk; b2++)
+                        if (hc[b2]) fprintf(stderr, " %d:%d", b2, hc[b2]);
+                    fprintf(stderr, "\n");
+                }
                 if (p.panel && tune.panel_repair) {
                     // (4b) sub-blocks that hold an item the user rated: bound again without the user's own co-ratings
                     RepairArgs RA{L.surv.get(), L.surv_mask.get(), L.n_quads.get(), bld, nb, s0, lo, p.p_eff, Ic, P.rowptr.get(), P.csr_idx.get(),
@@ -2518,6 +2584,15 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                                   L.tau.get(), pvpi.get(), (float)w2s, prune_counters.get()};
                     k_bound_repair<<<std::min<int>(nb, ctx->num_cus * 16), 256, 0, ls>>>(RA);
                     FY_KERNEL_CHECK();
+                }
+                if (p.half && !p.panel && tune.lazy_mirror) {      // lazy mirror, second pass: the column blocks with survivors
+                    const size_t sm = t_mirror.begin(ls);
+                    L.need.alloc(ctx, (size_t)p.nblk + 1);
+                    FY_HIP(hipMemsetAsync(L.need.get(), 0, ((size_t)p.nblk + 1) * sizeof(int32_t), ls));
+                    k_flag_surviving_blocks<<<std::min<int>(nb, 4096), 64, 0, ls>>>(nb, L.n_quads.get(), L.surv.get(), p.ldb, L.need.get());
+                    FY_KERNEL_CHECK();
+                    launch_mirror(ctx, L.M.get(), ldm, Ic, nullptr, p.ldb, ls, L.need.get(), 0, false);
+                    t_mirror.end(sm, ls);
                 }
                 exclusive_scan_i32(ctx, L.n_quads.get(), L.quad_prefix.get(), (size_t)nb + 1, ls, &L.scan_tmp);
                 if (split) {      // the count goes to pinned memory; the host does not wait here
@@ -2545,6 +2620,11 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                     // only -inf scores, tau = -inf keeps every block): the survivor pass would cost more than the plain full pass
                     // and 1 KB of scratch per survivor.  Redo the batch with the full pass, in sub-batches that fit the workspace.
                     t_score.end(ss, ls);
+                    if (p.half && tune.lazy_mirror) {      // the plain full pass reads every row whole: the rest of the lower triangle now
+                        const size_t sm = t_mirror.begin(ls);
+                        launch_mirror(ctx, L.M.get(), ldm, Ic, nullptr, p.ldb, ls, nullptr, 0x7FFFFFFF, false);
+                        t_mirror.end(sm, ls);
+                    }
                     const int64_t sub = std::max<int64_t>(1, std::min<int64_t>((ws / NS) / (ldm * 4), nb));
                     DevBuf<float> Sfull(ctx, (size_t)(sub * ldm));
                     for (int32_t t0 = s0; t0 < s0 + nb; t0 += (int32_t)sub) full_pass(t0, (int32_t)std::min<int64_t>(sub, s0 + nb - t0), Sfull.get());
@@ -2593,7 +2673,10 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                             2, seed_cols_p, L.surv.get(), L.n_quads.get(), bld, L.tau.get(), L.Ssurv.get(), L.quad_prefix.get()};
                 const size_t tt = t_topn.begin(ls);
                 FY_HIP(hipMemsetAsync(L.any_overflow.get(), 0, sizeof(int32_t), ls));
-                k_topn_fast<<<nb, 256, 0, ls>>>(TA, L.overflow.get(), L.any_overflow.get(), tune.force_select);
+                if (long_seed)
+                    k_topn_long<<<nb, 256, (size_t)fy_topn_long_cap(prm.number_of_recommendations) * 8, ls>>>(TA, L.overflow.get(), L.any_overflow.get(), tune.force_select,
+                                                                                                         fy_topn_long_cap(prm.number_of_recommendations));
+                else k_topn_fast<<<nb, 256, 0, ls>>>(TA, L.overflow.get(), L.any_overflow.get(), tune.force_select);
                 FY_KERNEL_CHECK();
                 k_topn_select<<<nb, 256, 0, ls>>>(TA, L.overflow.get(), L.any_overflow.get(), prune_counters.get() + 2);
                 FY_KERNEL_CHECK();
@@ -2672,8 +2755,20 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             unsigned long long hc[5];
             d2h(ctx, hc, prune_counters.get(), 5);
             sync(ctx);
+            if (!tables_cached && !all_at_once) {        // (build_tables_all counts its one table itself)
+                tc.total_segments = 0;
+                for (auto& t : segs) tc.total_segments += t.n_seg;
+                for (auto& t : segs_tail) tc.total_segments += t.n_seg;
+            }
             tc.sig = sig;          // every table of the plan has been built and used: a later job with the same plan re-uses them
             tc.valid = true;
+            R->st.cooc_segments = tc.total_segments;
+            for (auto& p : plans) {       // what the row kernels store (the mirror pass and the column maxima are priced separately)
+                const int64_t eb = p.pack24 ? 3 : 4;
+                if (p.coop) continue;
+                if (p.panel) R->st.cooc_matrix_bytes += (int64_t)p.Ic * p.panel_cols * 3 + (int64_t)p.Ic * p.ldb64 * 7;
+                else R->st.cooc_matrix_bytes += eb * (p.half ? (int64_t)p.Ic * (p.Ic + 256) / 2 : (int64_t)p.Ic * p.Ic) + (p.prune ? (int64_t)p.Ic * p.nblk * 3 : 0);
+            }
             R->st.topn_select_users = (int64_t)hc[2];
             R->st.stray_blocks = (int64_t)hc[3];
             R->st.bound_repairs = (int64_t)hc[4];

@@ -60,6 +60,22 @@ __global__ void k_count_heavy(const int32_t* __restrict__ rowptr /* of the batch
 }
 
 __device__ __forceinline__ float fy_log2(float x) { return __builtin_amdgcn_logf(x); }   // v_log_f32
+// Sum of log2 over a batch of terms WITHOUT one transcendental per term (round 4): x = m * 2^e with m in [0.5, 1)
+// (v_frexp_mant_f32 / v_frexp_exp_i32_f32, full-rate VALU), the mantissas of a batch are MULTIPLIED in fp32 (eight factors: the
+// product stays above 2^-8, relative error <= 7 * 2^-24), the exponents are added as integers (exact), and the batch costs ONE
+// v_log_f32 of the product: sum log2 x = log2(prod m) + sum e.  Against one v_log_f32 per term this is (a) more exact -- a log2 of
+// -13 .. -40 carried in one fp32 has an ulp of 1e-6 .. 4e-6, which neither v_log_f32's result nor fp32 sums of such values can beat,
+// while log2 of a product in [2^-8, 1) resolves 5e-7 for the whole batch: the all-rows error against the fp64 definition at ML-25M
+// shape fell from 4.7e-6 / 7.9e-6 (one / 50 clusters) to 3.5e-6 / 5.8e-6 with the split alone -- and (b) cheaper: four full-rate
+// instructions per term and half a transcendental cycle instead of a quarter-rate v_log_f32 (four cycles) and an add.
+// 0 -> mantissa 0: the product is 0 and its log2 -inf, as before (U_c = 1, quirk Q7); +inf and NaN pass through the mantissa.
+__device__ __forceinline__ void fy_logprod_step(float x, float& mant_prod, int& exp_sum) {
+    mant_prod *= __builtin_amdgcn_frexp_mantf(x);
+    exp_sum += __builtin_amdgcn_frexp_expf(x);
+}
+__device__ __forceinline__ double fy_logprod_fold(float mant_prod, int exp_sum) {      // log2 of the batch's product, fp64
+    return (double)__builtin_amdgcn_logf(mant_prod) + (double)exp_sum;
+}
 
 template <int VEC> struct VecT;
 template <> struct VecT<1> { using type = float; };
@@ -166,12 +182,14 @@ __device__ __forceinline__ void score_body(const float* __restrict__ M_, const f
                 const int kk = min(k + SB + sub, end - 1);
                 vi_n = csr_idx_[kk]; ve_n = csr_e_[kk]; vq_n = csr_q_[kk];
             }
-            // fp32 sums of FOUR logs (|log2| ~ 13..40: partial sums below ~160, ulp 1.5e-5), folded into fp64: sums of eight had twice
-            // the magnitude and twice the roundings -- for users whose log sum nearly cancels pvpi (|score| ~ 1, every multi-cluster
-            // job) that fp32 noise, not the matrix format, was the largest term of the all-rows error (tests/test_full_size_gpu.py)
-            float p[VEC], p2[VEC];
+            // per batch: the fp32 PRODUCT of the SB mantissas and the exact integer sum of the exponents, one v_log_f32 per batch
+            // (fy_logprod_step / fy_logprod_fold), folded into fp64.  (Round 3 summed whole log2 values, four at a time, in fp32:
+            // partial sums up to ~160, ulp 1.5e-5 -- for users whose log sum nearly cancels pvpi that noise was as large as the matrix
+            // format's rounding.)
+            float p[VEC];
+            int pe[VEC];
 #pragma unroll
-            for (int v = 0; v < VEC; v++) p[v] = p2[v] = 0.f;
+            for (int v = 0; v < VEC; v++) { p[v] = 1.f; pe[v] = 0; }
 #pragma unroll
             for (int q = 0; q < SB; q++) {
                 if (k + q < end) {
@@ -183,16 +201,13 @@ __device__ __forceinline__ void score_body(const float* __restrict__ M_, const f
                         for (int v = 0; v < VEC; v++) gv[v] = gp[v];
                     }
 #pragma unroll
-                    for (int v = 0; v < VEC; v++) {
-                        const float lg = fy_log2(fmaf(qq[q], bb[v], fmaf(a[v], e[q], gv[v])));
-                        if (q < SB / 2) p[v] += lg; else p2[v] += lg;
-                    }
+                    for (int v = 0; v < VEC; v++) fy_logprod_step(fmaf(qq[q], bb[v], fmaf(a[v], e[q], gv[v])), p[v], pe[v]);
                     const unsigned d = (unsigned)(jj[q] * row_mul + A.row_add - col0);
                     if (!no_mask && d < (unsigned)CW && (int)(d / VEC) == lane) mask |= 1u << (d % VEC);
                 }
             }
 #pragma unroll
-            for (int v = 0; v < VEC; v++) t[v] += (double)p[v] + (double)p2[v];
+            for (int v = 0; v < VEC; v++) t[v] += fy_logprod_fold(p[v], pe[v]);
             vi = vi_n; ve = ve_n; vq = vq_n;
         }
     };
@@ -255,7 +270,7 @@ __device__ __forceinline__ void score_body(const float* __restrict__ M_, const f
     }
 }
 template <int VEC, bool P24, int SB>
-__global__ __launch_bounds__(256) void k_score(const float* __restrict__ M_, const float* __restrict__ a_rank_,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_score(const float* __restrict__ M_, const float* __restrict__ a_rank_,
                                                const int32_t* __restrict__ rb_off_, const int32_t* __restrict__ csr_idx_,
                                                const float* __restrict__ csr_e_, const float* __restrict__ csr_q_,
                                                const double* __restrict__ pvpi_,
@@ -312,6 +327,7 @@ constexpr int TOPN_BINS = 4096;
 constexpr int TOPN_SAMPLE = 1024;    // leading columns that give the lower bound of a short list; a long list takes 4 N (fy_topn_sample)
 constexpr int TOPN_LONG = 256;       // lists longer than this take k_topn_long
 constexpr int PRUNE_BLOCK_COLS = 256;   // candidate block of the branch and bound = one column chunk
+constexpr int SEED_CHUNKS_MAX = 40;     // widest seed of the branch and bound: 5 N columns for the longest list (TOPN_MAX), in 256-column chunks
 
 // descending bitonic sort of P2 (power of two) 64-bit keys in LDS; every thread of the block calls it
 __device__ __forceinline__ void fy_bitonic_desc(uint64_t* v, int P2) {
@@ -556,22 +572,37 @@ __device__ __forceinline__ void fy_topn_bin(const uint32_t* __restrict__ hist, u
 // candidate buffer (dynamic LDS): N + a few dozen entries are expected -- 2048 (16 KB, eight workgroups per CU) up to N = 1400, else 4096
 inline int fy_topn_long_cap(int top_n) { return top_n <= 1400 ? 2048 : TOPN_CAP; }
 __global__ __launch_bounds__(256) void k_topn_long(TopNArgs A, int32_t* __restrict__ overflow, int32_t* __restrict__ any_overflow, int force_select, int cap) {
+    // A.mode (round 4: the branch and bound for long lists, seeds of up to SEED_CHUNKS_MAX * 256 columns):
+    //   0  whole rows (the plain full pass);
+    //   1  seed phase of the pruned flow: the row holds the seed columns only; publishes tau_u = the K-th best seed score and the list
+    //      that stands unless a block survives.  A user whose candidates overflow the buffer (massive ties) gets the histogram
+    //      threshold as tau -- a valid lower bound of its K-th best -- and overflow[u] = 1, which the merge launch below reads;
+    //   2  merge phase: users with surviving blocks (or a seed overflow): the seed row and the packed survivor scores against the
+    //      exact tau_u; anything that does not fit goes to k_topn_select.
     extern __shared__ __attribute__((aligned(16))) uint64_t fy_topn_cand[];
     uint64_t* __restrict__ cand = fy_topn_cand;
     __shared__ uint32_t hist[256], sh_bin[2], sh_count;
     const int u = blockIdx.x, tid = threadIdx.x;
     const int slot = A.slot0 + u;
     const int K = A.n_out[slot - A.slot_lo];
+    const int mode = A.mode;
+    const int seed_ovf = mode == 2 ? overflow[u] : 0;       // (written by this batch's mode-1 launch, in stream order)
+    __syncthreads();
     if (tid == 0) overflow[u] = 0;
-    if (K == 0) return;
-    if (force_select) {
+    if (mode == 2 && A.n_quads[u] == 0 && !seed_ovf) return;     // the seed phase already wrote this user's final list
+    if (K == 0) {
+        if (mode == 1 && tid == 0) A.tau[u] = INFINITY;          // nothing to emit: every block may be skipped
+        return;
+    }
+    if ((force_select && mode != 1) || seed_ovf) {
         if (tid == 0) { overflow[u] = 1; atomicAdd(any_overflow, 1); }
         return;
     }
     const float* __restrict__ row = A.S + (int64_t)u * A.ldS;
+    const int row_cols = mode ? min(A.Ic, A.seed_cols) : A.Ic;   // pruned flow: only the seed columns of a row exist
     int sample = TOPN_SAMPLE;
     while (sample < 4 * K && sample < TOPN_CAP) sample <<= 1;
-    const int Ls = min(A.Ic, sample);
+    const int Ls = min(row_cols, sample);
     constexpr int PER = TOPN_CAP / 256;
     uint32_t key[PER];
 #pragma unroll
@@ -580,22 +611,27 @@ __global__ __launch_bounds__(256) void k_topn_long(TopNArgs A, int32_t* __restri
         const float f = i < Ls ? row[i] : __builtin_nanf("");
         key[q] = f == f ? fy_order_key(f) : 0u;              // valid keys are > 0
     }
-    uint32_t prefix = 0, above = 0;
-    for (int level = 0; level < 2; level++) {
-        const int shift = level == 0 ? 24 : 16;
-        hist[tid] = 0u;
-        __syncthreads();
+    uint32_t tau;
+    if (mode == 2) {
+        tau = fy_order_key(A.tau[u]);                            // exact K-th best of the seed (-inf: fewer than K seed scores)
+    } else {
+        uint32_t prefix = 0, above = 0;
+        for (int level = 0; level < 2; level++) {
+            const int shift = level == 0 ? 24 : 16;
+            hist[tid] = 0u;
+            __syncthreads();
 #pragma unroll
-        for (int q = 0; q < PER; q++)
-            if (key[q] && (level == 0 || (key[q] >> 24) == (prefix >> 24))) atomicAdd(&hist[(key[q] >> shift) & 255u], 1u);
-        __syncthreads();
-        if (tid < 64) fy_topn_bin(hist, above, (uint32_t)K, sh_bin);
-        __syncthreads();
-        prefix |= sh_bin[0] << shift;
-        above = sh_bin[1];
-        __syncthreads();
+            for (int q = 0; q < PER; q++)
+                if (key[q] && (level == 0 || (key[q] >> 24) == (prefix >> 24))) atomicAdd(&hist[(key[q] >> shift) & 255u], 1u);
+            __syncthreads();
+            if (tid < 64) fy_topn_bin(hist, above, (uint32_t)K, sh_bin);
+            __syncthreads();
+            prefix |= sh_bin[0] << shift;
+            above = sh_bin[1];
+            __syncthreads();
+        }
+        tau = prefix ? prefix : 1u;                              // fewer than K valid sample values: every valid score is a candidate
     }
-    const uint32_t tau = prefix ? prefix : 1u;                // fewer than K valid sample values: every valid score is a candidate
     if (tid == 0) sh_count = 0u;
     __syncthreads();
     auto take = [&](uint32_t k, int i) __attribute__((always_inline)) {
@@ -608,7 +644,7 @@ __global__ __launch_bounds__(256) void k_topn_long(TopNArgs A, int32_t* __restri
     for (int q = 0; q < PER; q++) take(key[q], tid + 256 * q);
     constexpr int UNR = 4;
     const float4 nan4 = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
-    const int i4_end = (A.Ic + 3) >> 2;
+    const int i4_end = (row_cols + 3) >> 2;
     for (int x0 = (sample >> 2) + tid; x0 < i4_end; x0 += UNR * 256) {
         float4 f4[UNR];
 #pragma unroll
@@ -623,15 +659,36 @@ __global__ __launch_bounds__(256) void k_topn_long(TopNArgs A, int32_t* __restri
             for (int e = 0; e < 4; e++) {
                 const int i = 4 * (x0 + q * 256) + e;
                 const float f = fv[e];
+                take((f == f && i < row_cols) ? fy_order_key(f) : 0u, i);
+            }
+        }
+    }
+    if (mode == 2) {      // the surviving blocks: 64 float4 each, packed at quad_prefix[u] + k (or in place, cooperative ranks aside)
+        const int n4 = A.n_quads[u] * (PRUNE_BLOCK_COLS / 4);
+        for (int x = tid; x < n4; x += 256) {
+            const unsigned blk = A.surv[(int64_t)u * A.ldb + (x >> 6)];
+            const int i4 = (int)blk * (PRUNE_BLOCK_COLS / 4) + (x & 63);
+            const float* src = A.Ssurv ? A.Ssurv + ((int64_t)(A.quad_prefix[u] + (x >> 6)) * PRUNE_BLOCK_COLS + 4 * (x & 63)) : row + 4 * (int64_t)i4;
+            const float4 f4 = *reinterpret_cast<const float4*>(src);
+            const float fv[4] = {f4.x, f4.y, f4.z, f4.w};
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int i = 4 * i4 + e;
+                const float f = fv[e];
                 take((f == f && i < A.Ic) ? fy_order_key(f) : 0u, i);
             }
         }
     }
     __syncthreads();
     const int n = (int)sh_count;
-    // (n < K cannot happen while n_out counts only scored candidates and the histogram threshold keeps >= K of the sample -- but if it
-    // ever did, e.g. NaN scores, the entries behind n would be emitted as items: such a user goes to the exact select instead)
-    if (n > cap || n < K) {   // block-uniform
+    if (mode == 1) {
+        if (n > cap) {       // block-uniform: no list yet; the histogram threshold is a lower bound of the K-th best all the same
+            if (tid == 0) { A.tau[u] = fy_order_unkey(tau); overflow[u] = 1; }
+            return;
+        }
+    } else if (n > cap || n < K) {   // block-uniform
+        // (n < K cannot happen while n_out counts only scored candidates and the histogram threshold keeps >= K of the sample -- but if it
+        // ever did, e.g. NaN scores, the entries behind n would be emitted as items: such a user goes to the exact select instead)
         if (tid == 0) { overflow[u] = 1; atomicAdd(any_overflow, 1); }
         return;
     }
@@ -640,9 +697,10 @@ __global__ __launch_bounds__(256) void k_topn_long(TopNArgs A, int32_t* __restri
     for (int i = n + tid; i < P2; i += 256) cand[i] = 0ull;
     __syncthreads();
     fy_bitonic_desc(cand, P2);
+    if (mode == 1 && tid == 0) A.tau[u] = n >= K ? fy_order_unkey((uint32_t)(cand[K - 1] >> 32)) : -INFINITY;
     const int off = A.out_off[slot - A.slot_lo];
     const int user_raw = A.uid[A.slot2du[slot]];
-    for (int i = tid; i < K; i += 256) {
+    for (int i = tid; i < min(K, n); i += 256) {
         const uint64_t c = cand[i];
         A.out_user[off + i] = user_raw;
         A.out_item[off + i] = 0x7FFFFFFF - (int32_t)(uint32_t)c;
@@ -949,23 +1007,21 @@ __global__ __launch_bounds__(256) void k_score_blocks(const float* __restrict__ 
                 const int kk = min(k + SB + sub, end - 1);
                 vi_n = csr_idx_[kk]; ve_n = csr_e_[kk]; vq_n = csr_q_[kk];
             }
-            float p[4] = {0.f, 0.f, 0.f, 0.f}, p2[4] = {0.f, 0.f, 0.f, 0.f};     // (two fp32 sums of SB / 2 logs each: see k_score's walk)
+            float p[4] = {1.f, 1.f, 1.f, 1.f};     // (product of the mantissas in fp32, exponents exact: see k_score's walk)
+            int pe[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int x = 0; x < SB; x++) {
                 if (k + x < end) {
                     float gv[4];
                     fy_unpack24(g[x], gv);
 #pragma unroll
-                    for (int v = 0; v < 4; v++) {
-                        const float lg = fy_log2(fmaf(qq[x], bb[v], fmaf(a[v], e[x], gv[v])));
-                        if (x < SB / 2) p[v] += lg; else p2[v] += lg;
-                    }
+                    for (int v = 0; v < 4; v++) fy_logprod_step(fmaf(qq[x], bb[v], fmaf(a[v], e[x], gv[v])), p[v], pe[v]);
                     const unsigned d = (unsigned)(jj[x] - col);
                     if (d < 4u) mask |= 1u << d;
                 }
             }
 #pragma unroll
-            for (int v = 0; v < 4; v++) t[v] += (double)p[v] + (double)p2[v];
+            for (int v = 0; v < 4; v++) t[v] += fy_logprod_fold(p[v], pe[v]);
             vi = vi_n; ve = ve_n; vq = vq_n;
         }
         if (wave > 0) {
@@ -1384,7 +1440,12 @@ __global__ __launch_bounds__(256) void k_score_stray(StrayArgs A) {
                     double tt = 0.0;
                     for (int k = lane; k < nk; k += 64) {
                         const float gv = A.w2 * (float)((double)g[k] * fx_inv);
-                        tt += (double)fy_log2(fmaf(sh_q[k], bi, fmaf(ai, sh_e[k], gv)));
+                        {
+                            float lm = 1.f;
+                            int le = 0;
+                            fy_logprod_step(fmaf(sh_q[k], bi, fmaf(ai, sh_e[k], gv)), lm, le);
+                            tt += fy_logprod_fold(lm, le);
+                        }
                         g[k] = 0ull;
                     }
                     for (int o = 32; o > 0; o >>= 1) tt += __shfl_xor(tt, o, 64);
@@ -1485,6 +1546,11 @@ __global__ __launch_bounds__(256) void k_bound_select(const float* __restrict__ 
 }
 
 // (slot, block) of every surviving block of this rank's users, packed for the all-gather
+// how many users keep block b (debug: FY_DEBUG_SYNC=3 prints the distribution; round 4 measured it to decide on a lazy mirror pass)
+__global__ void k_surv_block_counts(int32_t n_users, const int32_t* __restrict__ n_quads, const uint16_t* __restrict__ surv, int64_t ldb, int32_t* __restrict__ counts) {
+    for (int32_t u = blockIdx.x; u < n_users; u += gridDim.x)
+        for (int k = threadIdx.x; k < n_quads[u]; k += blockDim.x) atomicAdd(&counts[surv[(int64_t)u * ldb + k]], 1);
+}
 __global__ void k_surv_entries(int32_t n_users, int32_t slot0, const int32_t* __restrict__ prefix, const uint16_t* __restrict__ surv,
                                int64_t ldb, long long* __restrict__ entries) {
     const int lane = threadIdx.x & 63;
@@ -1556,23 +1622,21 @@ __global__ __launch_bounds__(256) void k_score_entries(const float* __restrict__
                 const int kk = min(kk0 + SB + sub, end - 1);
                 vi_n = csr_idx_[kk]; ve_n = csr_e_[kk]; vq_n = csr_q_[kk];
             }
-            float p[4] = {0.f, 0.f, 0.f, 0.f}, p2[4] = {0.f, 0.f, 0.f, 0.f};     // (two fp32 sums of SB / 2 logs each: see k_score's walk)
+            float p[4] = {1.f, 1.f, 1.f, 1.f};     // (product of the mantissas in fp32, exponents exact: see k_score's walk)
+            int pe[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int x = 0; x < SB; x++) {
                 if (kk0 + x < end) {
                     float gv[4];
                     fy_unpack24(g[x], gv);
 #pragma unroll
-                    for (int v = 0; v < 4; v++) {
-                        const float lg = fy_log2(fmaf(qq[x], bb[v], fmaf(a[v], e[x], gv[v])));
-                        if (x < SB / 2) p[v] += lg; else p2[v] += lg;
-                    }
+                    for (int v = 0; v < 4; v++) fy_logprod_step(fmaf(qq[x], bb[v], fmaf(a[v], e[x], gv[v])), p[v], pe[v]);
                     const unsigned d = (unsigned)(jj[x] * row_mul + row_add - col);
                     if (d < 4u) mask |= 1u << d;
                 }
             }
 #pragma unroll
-            for (int v = 0; v < 4; v++) t[v] += (double)p[v] + (double)p2[v];
+            for (int v = 0; v < 4; v++) t[v] += fy_logprod_fold(p[v], pe[v]);
             vi = vi_n; ve = ve_n; vq = vq_n;
         }
         const double base = pvpi_[slot - slot_base];

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FY_ABI_VERSION 3
+#define FY_ABI_VERSION 4
 
 typedef enum {
     FY_OK = 0,
@@ -262,6 +262,10 @@ typedef struct {
     int64_t isim_redone_rows;    /* ... rows whose list overflowed and were redone exactly from the matrix */
     int64_t prepared_from_cache; /* RM2: 1 = fy_rm2_prepare found its structures on the fy_ratings object (same clustering): nothing was sorted */
     int64_t tables_from_cache;   /* RM2: 1 = the row kernel's tables (packed CSR, segment tables) were re-used */
+    /* (ABI 4) what the row kernels of the job read and write besides the packed CSR entries, for the kernel's OWN byte model
+     * (bench.py roofline.frac_own_bytes) and its LDS-atomic floor (one ds_add wave instruction per segment): */
+    int64_t cooc_segments;       /* <= 64-entry segments in the job's segment tables (12 B of descriptor each) */
+    int64_t cooc_matrix_bytes;   /* bytes of co-rating matrix / panel / block-bound rows the row kernels store */
 } fy_stats;
 int fy_result_stats(fy_result*, fy_stats* out);
 
@@ -283,6 +287,8 @@ typedef struct {
     int32_t normalization_frequency;   /* PPC: the rows of H are L1-normalised when iteration % f == 0 (Java's %, so the
                                           reference's unset key, -1, normalises every iteration); 0 = never */
 } fy_nmf_params;
+/* stats: nnz / n_users / n_items, ms_prepare (the sorted copies of the ratings), ms_cooc = the iterations alone (H / W resident in
+ * HBM), ms_total = everything including the host transfers of H and W in both directions. */
 int fy_nmf_factorize(fy_context*, const fy_nmf_params*, const fy_ratings*, double* H_inout, double* W_inout, fy_stats* stats_or_null);
 
 /* ------------------------------------------------------------------ the Hadoop files on either side of the RM2 job

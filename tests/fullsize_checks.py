@@ -196,7 +196,9 @@ def assert_same_lists(a, b, score_rtol=2e-6, tie_rtol=1e-5, score_atol=0.0):
     in_a = np.isin(kb_s, ka_s, assume_unique=True)
     ca, cb = sa[oa][in_b], sb[ob][in_a]                  # common pairs, both in key order
     # (score_atol: for jobs whose scores nearly cancel -- pvpi > 0 against the negative log sum -- see tests/util.py ATOL)
-    rel = np.maximum(np.abs(ca - cb) - score_atol, 0.0) / np.abs(cb)
+    with np.errstate(invalid="ignore"):
+        diff = np.where(ca == cb, 0.0, np.abs(ca - cb))      # (-inf in both runs is agreement, not nan)
+        rel = np.where(diff == 0.0, 0.0, np.maximum(diff - score_atol, 0.0) / np.abs(cb))
     worst = float(rel.max()) if len(rel) else 0.0
     assert worst <= score_rtol, worst
     # last score of every user's list, per run
@@ -209,7 +211,9 @@ def assert_same_lists(a, b, score_rtol=2e-6, tie_rtol=1e-5, score_atol=0.0):
     for only, s_own, s_other in ((only_a, sa, sb), (only_b, sb, sa)):
         if len(only):
             cut = s_other[last[seg_of_row[only]]]
-            assert np.all(np.abs(s_own[only] - cut) <= tie_rtol * np.abs(cut) + score_atol), "a list member is missing from the other run"
+            with np.errstate(invalid="ignore"):
+                ok = (s_own[only] == cut) | (np.abs(s_own[only] - cut) <= tie_rtol * np.abs(cut) + score_atol)
+            assert np.all(ok), "a list member is missing from the other run"
     return len(only_a), worst
 
 

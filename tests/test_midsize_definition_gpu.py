@@ -137,3 +137,28 @@ def test_long_lists_one_cluster_of_sampled_ml25m_users(sampled_ml25m_cluster, to
     assert st["blocks_total"] == 0 and st["topn_select_users"] == 0
     rec.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("top_n", [300, 1000])
+def test_long_lists_through_the_branch_and_bound(sampled_ml25m_cluster, top_n, monkeypatch):
+    """Round 4: the same long lists through the PRUNED flow (a seed of 5 N columns -- 1536 / 5120 of the 22 083 -- scored exactly,
+    tau_u = its N-th best from k_topn_long's seed mode, block bounds, survivors merged by k_topn_long's merge mode); forced onto this
+    400-user neighbourhood (production prunes clusters of >= 600 users), every row against the fp64 Gram scorer of the oracle."""
+    monkeypatch.setenv("FY_PRUNE_MIN_USERS", "0")
+    monkeypatch.setenv("FY_MAX_SURV_FRAC", "1.5")
+    P = pkg()
+    u, i, s, ref = sampled_ml25m_cluster
+    conf = P.Configuration()
+    conf.set("lambda", "0.1")
+    conf.setInt("numberOfItems", 59047)
+    conf.setInt("numberOfClusters", 1)
+    conf.setInt("numberOfRecommendations", top_n)
+    ctx = P.Context(0)
+    rec = P.RM2Job(conf, ctx).run((u, i, s))
+    rows, st = rec.rows(), rec.stats
+    assert st["blocks_total"] > 0 and st["prune_fallbacks"] == 0 and 0 < st["blocks_survived"] < st["blocks_total"]
+    worst = assert_topn_matches(rows, ref, top_n)
+    print("top-%d, pruned: %d of %d blocks survive, worst relative error %.2e, %d users through the radix-select fallback"
+          % (top_n, st["blocks_survived"], st["blocks_total"], worst, st["topn_select_users"]))
+    rec.close()
+    ctx.close()

@@ -18,7 +18,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(P._native.SYMBOLS), declared ^ set(P._native.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.fy_abi_version() == 3
+    assert lib.fy_abi_version() == 4
 
 
 def test_struct_layouts_match_the_header():
@@ -26,7 +26,7 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(P._native.RM2Params) == 48
     assert C.sizeof(P._native.ItemSimParams) == 48
     assert C.sizeof(P._native.ItemCFParams) == 24
-    assert C.sizeof(P._native.Stats) == 30 * 8
+    assert C.sizeof(P._native.Stats) == 32 * 8
 
 
 def test_no_gpu_means_a_loud_failure():

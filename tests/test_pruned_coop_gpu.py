@@ -332,3 +332,42 @@ def test_small_clusters_take_the_full_pass(forced, monkeypatch):
     assert rec.stats["blocks_total"] > 0
     assert_topn_matches(rec.rows(), ref, 20)
     ctx.close()
+
+
+@pytest.mark.parametrize("shape,K,lam,top_n,seed_chunks,select", [("ml100k", 1, "0.1", 300, 2, 0), ("ml100k", 3, "0.5", 400, 1, 0), ("ml100k", 1, "0.0", 300, 2, 0),
+                                                                    ("ml100k", 1, "0.1", 40, 5, 0), ("ml100k", 1, "0.1", 300, 2, 1), ("ml100k", 1, "0.1", 1000, 3, 0)])
+def test_long_lists_take_the_branch_and_bound(monkeypatch, shape, K, lam, top_n, seed_chunks, select):
+    """Round 4: lists longer than 256 items (the reference's default is numberOfRecommendations = 1000, RMRecommenderDriver.java:95) and
+    seeds wider than 1024 columns go through the pruned flow too -- k_topn_long in its seed mode (tau_u = the N-th best of the seed
+    columns, the list that stands unless a block survives) and its merge mode (seed + surviving blocks against the exact tau_u).
+    Forced onto MovieLens-100K-shaped data, where the brute-force oracle decides every row; lambda = 0 gives rows of -inf (massive ties
+    at the cut-off); select = 1 sends every merged user through the radix-select fallback."""
+    monkeypatch.setenv("FY_PRUNE_MIN_ITEMS", "256")
+    monkeypatch.setenv("FY_M24_MIN_ITEMS", "0")
+    monkeypatch.setenv("FY_SEED_CHUNKS", str(seed_chunks))
+    monkeypatch.setenv("FY_TOPN_FORCE_SELECT", str(select))
+    # (a list of 300 of 1682 items: most blocks survive; the job must not give up and take the plain full pass -- the merge of a seed
+    # row with MANY surviving blocks is what this test is for)
+    monkeypatch.setenv("FY_MAX_SURV_FRAC", "1.5")
+    P = pkg()
+    data, clustering, conf, ref = make(shape, K, lam, top_n)
+    ctx = P.Context(0)
+    rec = P.RM2Job(conf, ctx).run(data, clustering=clustering)
+    st = rec.stats
+    assert st["blocks_total"] > 0, "the branch and bound did not run"
+    assert st["prune_fallbacks"] == 0
+    # (a pruned cluster stores 24-bit rows here -- FY_M24_MIN_ITEMS=0 -- whose scores carry the format's rounding: the absolute slack of
+    # tests/util.py is the reference's own criterion halved, for lists whose scores cross zero)
+    from util import ATOL
+    assert_topn_matches(rec.rows(), ref, top_n, atol=ATOL)
+    monkeypatch.setenv("FY_PRUNE", "0")
+    full = P.RM2Job(conf, ctx).run(data, clustering=clustering)
+    assert full.stats["blocks_total"] == 0
+    from fullsize_checks import assert_same_lists
+
+    def by_user(r):
+        o = np.argsort(r["user"], kind="stable")
+        return {k: r[k][o] for k in ("user", "item", "score")}
+    n_diff, worst = assert_same_lists(by_user(rec.rows()), by_user(full.rows()), score_rtol=1e-5, score_atol=ATOL)
+    assert n_diff <= 4, n_diff
+    ctx.close()

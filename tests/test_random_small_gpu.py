@@ -60,7 +60,12 @@ def test_random_case(ctx, seed):
     if len(ref["rec_user"]) == 0:
         assert rec.size == 0
         return
-    assert_topn_matches(rec.rows(), ref, c["top_n"])
+    # The ONE place the absolute slack of tests/util.py is granted: clusters of 2 .. 20 users with lambda up to 1, where pvpi and the log
+    # sum cancel to |score| ~ 0.01 .. 1 while each is ~100: fp32 inputs (q, e, a, b rounded once) resolve 1e-7 per term, i.e. a few
+    # 1e-6 absolute -- 1e-5 .. 7e-5 RELATIVE on such a score, 25x inside the reference's own criterion (absolute 1e-4,
+    # T/util/HadoopIntegrationTest.java:53).  The run's tally (conftest.py) prints how many comparisons used it: 5 of 3.6 M in round 4.
+    from util import ATOL
+    assert_topn_matches(rec.rows(), ref, c["top_n"], atol=ATOL)
     sums = rec.sums()
     np.testing.assert_array_equal(sums["user_sum"], ref["user_sum"])
     assert sums["total_sum"] == ref["total_sum"]
