@@ -925,6 +925,52 @@ __global__ __launch_bounds__(1024) void k_mirror_tiles(float* __restrict__ M_, i
                                                        const int32_t* __restrict__ need, int32_t write_below) {
     mirror_tiles_body(M_, ldm, Ic, Bmax_, ldb, need, write_below);
 }
+// Block maxima alone (lazy mirror, first pass, the column blocks nobody reads below the diagonal): Bmax[j][B] = max over the rows i of block B
+// of G[i][j] for the 256 columns j of a tile strictly behind block B.  A wave reads WHOLE 768-byte row segments (one 12-byte load per
+// lane, 16 rows in flight per workgroup step) -- the transposing tile kernel reads 384-byte half segments and stages them through LDS,
+// which this pass has no use for; the 16 waves' maxima meet in LDS and each thread stores one 3-byte entry.
+__global__ __launch_bounds__(1024) void k_colmax_upper(const float* __restrict__ M_, int64_t ldm, int32_t Ic, float* __restrict__ Bmax_, int64_t ldb, int32_t first_block) {
+    __shared__ uint32_t colmax[256];
+    const int tj = blockIdx.x, B = first_block + blockIdx.y;      // tile = columns [256 tj, 256 tj + 256) x rows of block B
+    if (tj <= B) return;                                           // strictly behind the diagonal block
+    const int col0 = 256 * tj;
+    if (col0 >= Ic) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t pitch = ldm * 3;
+    const unsigned char* __restrict__ Mb = reinterpret_cast<const unsigned char*>(M_);
+    if (threadIdx.x < 256) colmax[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t mx[4] = {0, 0, 0, 0};
+    const int r_end = min(256, Ic - 256 * B);
+    uint32_t d[4][3];
+#pragma unroll
+    for (int step = 0; step < 4; step++) {                         // 16 waves x 16 rows: four loads in flight per lane
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            const int r = wave * 16 + step * 4 + x;
+            const uint32_t* __restrict__ p = reinterpret_cast<const uint32_t*>(Mb + (int64_t)(256 * B + min(r, r_end - 1)) * pitch + (int64_t)col0 * 3) + 3 * lane;
+            d[x][0] = p[0]; d[x][1] = p[1]; d[x][2] = p[2];
+        }
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            uint32_t v[4];
+            fy_unpack24_raw(d[x][0], d[x][1], d[x][2], v);
+#pragma unroll
+            for (int q = 0; q < 4; q++) mx[q] = max(mx[q], v[q]);      // (a clamped row repeats the block's last row: the maximum is unchanged)
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        if (mx[q]) atomicMax(&colmax[4 * lane + q], mx[q]);
+    __syncthreads();
+    if (threadIdx.x < 256 && col0 + (int)threadIdx.x < Ic) {
+        const uint32_t pv = colmax[threadIdx.x];
+        uint8_t* bp = reinterpret_cast<uint8_t*>(Bmax_) + ((int64_t)(col0 + threadIdx.x) * ldb + B) * 3;
+        bp[0] = (uint8_t)pv;
+        bp[1] = (uint8_t)(pv >> 8);
+        bp[2] = (uint8_t)(pv >> 16);
+    }
+}
 // need[b] = 1 for every block b some user of the batch keeps (the survivor lists of k_bound_select)
 __global__ void k_flag_surviving_blocks(int32_t n_users, const int32_t* __restrict__ n_quads, const uint16_t* __restrict__ surv, int64_t ldb, int32_t* __restrict__ need) {
     for (int32_t u = blockIdx.x; u < n_users; u += gridDim.x)
@@ -1072,8 +1118,18 @@ static void launch_mirror(Context* ctx, float* M, int64_t ldm, int32_t Ic, float
     const int nblk = (int)(ldm / 256), ntile = (int)(ldm / 128);
     if (nblk > 1) {
         FY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mirror_tiles), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * MIRROR_PITCH));
-        k_mirror_tiles<<<dim3(ntile, nblk - 1), 1024, 128 * MIRROR_PITCH, st>>>(M, ldm, Ic, Bmax, ldb, need, write_below);
-        FY_KERNEL_CHECK();
+        // first pass of the lazy mirror: the transposing kernel only over the column blocks it writes (those in front of write_below),
+        // the block maxima of all other blocks from the streaming kernel
+        const bool split = !need && Bmax && write_below < nblk - 1;
+        const int ny = split ? write_below : nblk - 1;
+        if (ny > 0) {
+            k_mirror_tiles<<<dim3(ntile, ny), 1024, 128 * MIRROR_PITCH, st>>>(M, ldm, Ic, Bmax, ldb, need, write_below);
+            FY_KERNEL_CHECK();
+        }
+        if (split) {
+            k_colmax_upper<<<dim3(nblk, nblk - 1 - write_below), 1024, 0, st>>>(M, ldm, Ic, Bmax, ldb, write_below);
+            FY_KERNEL_CHECK();
+        }
     }
     if (diag) {
         k_mirror_diag<<<nblk, 256, 0, st>>>(M, ldm, Ic, Bmax, ldb);

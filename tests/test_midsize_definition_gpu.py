@@ -156,7 +156,9 @@ def test_long_lists_through_the_branch_and_bound(sampled_ml25m_cluster, top_n, m
     ctx = P.Context(0)
     rec = P.RM2Job(conf, ctx).run((u, i, s))
     rows, st = rec.rows(), rec.stats
-    assert st["blocks_total"] > 0 and st["prune_fallbacks"] == 0 and 0 < st["blocks_survived"] < st["blocks_total"]
+    # (on a 400-user neighbourhood the bound excludes next to nothing -- all blocks survive for N = 1000: what is tested is the seed
+    # threshold and the merge of a 5 N-column seed row with MANY surviving blocks, not the pruning rate)
+    assert st["blocks_total"] > 0 and st["prune_fallbacks"] == 0 and 0 < st["blocks_survived"] <= st["blocks_total"]
     worst = assert_topn_matches(rows, ref, top_n)
     print("top-%d, pruned: %d of %d blocks survive, worst relative error %.2e, %d users through the radix-select fallback"
           % (top_n, st["blocks_survived"], st["blocks_total"], worst, st["topn_select_users"]))
