@@ -343,6 +343,18 @@ def main():
                             "payload_bytes_per_rank_per_step": None if not calls else calls["bytes"] / n_runs}
         out["cpu_baseline"] = None
         out["cpu_baseline_note"] = "timed on rank 0 of the N = 1 run only (see that line)"
+        # the reference's own regime on N ranks: 50 clusters, WHOLE clusters per rank (no Gram is built twice, only the item statistics
+        # are exchanged: RM2Job.java:251 runs one reduce group per cluster) -- the case SURVEY.md 8e expects to scale best
+        if not a.no_regime and a.shape == "ml25m" and K == 1:
+            try:
+                s50, el50, (r50, t50, u50), _ = time_job(50, top_n, 2, 1)
+                out["multi_gpu"]["clusters_50_top_%d" % top_n] = {
+                    "value": r50 / (el50 / 2), "unit": "recs/s", "ms_per_step": 1e3 * el50 / 2,
+                    "phase_ms_rank0": {k: float(np.mean([x[k] for x in s50])) for k in ("ms_prepare", "ms_tables", "ms_cooc", "ms_mirror", "ms_score", "ms_topn", "ms_total")},
+                    "clusters_nonempty": int(s50[-1]["n_clusters_nonempty"]), "panel_clusters_rank0": int(s50[-1]["panel_clusters"]),
+                    "note": "numberOfClusters 50, users hashed to clusters; every rank scores whole clusters (contiguous runs of the cluster order, balanced by log terms)"}
+            except RuntimeError as e:
+                out["multi_gpu"]["clusters_50_top_%d" % top_n] = {"error": str(e)}
 
     # ---- the warm job: same ratings object, same clustering -- the CSR / CSC, the per-item statistics and the row kernel's tables
     # of the previous job are found on the ratings object (fy_stats.prepared_from_cache); never the headline value

@@ -67,7 +67,7 @@ struct Tuning {
     int cooc_max_ch = 19968;           // LDS accumulators of the row kernel: 156 KiB of 64-bit words of the 160 KiB LDS (ML-25M shape: three
                                        // column chunks instead of four, 19.7 -> 17.8 ms; smaller forces more chunks)
     bool cooc_max_ch_forced = false;   // FY_COOC_MAX_CH given (the item-similarity build has its own default)
-    int prep_user_table = 1;           // FY_PREP_USER_TABLE: users, degrees and rating sums by atomics on a table indexed by the raw id (0: user-major sort)
+    int sup_bounds = 1;                // FY_SUP_BOUNDS: one-cluster pruned jobs bound over <= 64 super-blocks inside the seed pass (0: a bound chunk per user over all blocks)
     int lazy_mirror = 1;               // FY_LAZY_MIRROR: pruned one-cluster jobs mirror only the column blocks somebody reads (0: the whole lower triangle)
     int seed_forced = 0;               // FY_SEED_CHUNKS given: prune whatever the list length
     int coop = 1;                      // cooperative scoring of clusters that span all ranks (needs fy_collectives)

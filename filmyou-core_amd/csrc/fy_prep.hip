@@ -139,90 +139,6 @@ __global__ void k_user_item_keys(int64_t n, const int32_t* __restrict__ user, co
     if ((threadIdx.x & 63) == 0 && frac) atomicOr(err, (int)frac);
 }
 
-// ---- users without a sort (round 4).  Raw user ids are small integers (max_user is known since the ratings entered HBM) and ratings
-// are multiples of 2^-9 below 128 in every data set the reference sees (stars and half stars): one pass of 64-bit atomics over a table
-// indexed by the RAW id gives every user's degree (low 24 bits) and rating sum in fixed point (x 512, upper 40 bits) -- exact, so the
-// order of the atomics does not matter (DoubleSumAndCountReducer.java:35-38 sums in shuffle order: any order is the reference's).  It
-// replaces the user-major radix sort (3 passes over 25 M pairs), the head flags and the 25 M-element scan behind it.  Anything else
-// (a rating that is not such a multiple, ids too sparse for a table) takes the sort.
-enum { NOTE_NOT_FIX = 1 << 20 };
-constexpr int FIX_SHIFT = 9, FIX_DEG_BITS = 24;
-__global__ void k_user_hist(int64_t n, const int32_t* __restrict__ user, const int32_t* __restrict__ item, const float* __restrict__ score,
-                            int keep_nonpositive, unsigned long long* __restrict__ packed, unsigned long long* __restrict__ kept, int* __restrict__ err) {
-    unsigned long long local = 0;
-    bool not_half = false, not_pos = false, not_fix = false, neg = false;
-    unsigned frac = 0;
-    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
-        const float s = score[t];
-        const bool keep = keep_nonpositive ? (s == s) : (s > 0.0f);
-        if (!keep) continue;
-        const int32_t u = user[t], i = item[t];
-        if (u < 0 || i < 0) { neg = true; continue; }
-        if (__half2float(__float2half(s)) != s) not_half = true;
-        if (!(s > 0.0f)) not_pos = true;
-        {
-            float a = fabsf(s);
-            int m = 0;
-            while (m < 9 && a != floorf(a)) { a *= 2.0f; m++; }
-            frac |= 1u << (8 + m);
-        }
-        const float fx = s * (float)(1 << FIX_SHIFT);
-        if (!(s >= 0.0f) || fx != floorf(fx) || !(fx < 65536.0f)) { not_fix = true; continue; }
-        atomicAdd(&packed[u], ((unsigned long long)(uint32_t)fx << FIX_DEG_BITS) | 1ull);
-        local++;
-    }
-    for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o, 64);
-    if ((threadIdx.x & 63) == 0 && local) atomicAdd(kept, local);
-    int f = 0;
-    if (__ballot(not_half)) f |= NOTE_NOT_FP16;
-    if (__ballot(not_pos)) f |= NOTE_NONPOSITIVE;
-    if (__ballot(not_fix)) f |= NOTE_NOT_FIX;
-    if (__ballot(neg)) f |= ERR_NEG_ID;
-    for (int o = 32; o > 0; o >>= 1) frac |= (unsigned)__shfl_down((int)frac, o, 64);
-    if ((threadIdx.x & 63) == 0 && (f | (int)frac)) atomicOr(err, f | (int)frac);
-}
-__global__ void k_user_present(int64_t n_ids, const unsigned long long* __restrict__ packed, uint32_t* __restrict__ present) {
-    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n_ids; r += (int64_t)gridDim.x * blockDim.x) present[r] = packed[r] != 0ull;
-}
-// dense user arrays from the table; deg_total / bad: consistency of the packed fields (a degree that ran into the sum field -- only
-// possible with duplicate (user, item) keys -- shows as a total that differs from the kept ratings: the caller then takes the sort)
-__global__ void k_users_from_hist(int64_t n_ids, const unsigned long long* __restrict__ packed, const uint32_t* __restrict__ du1, int32_t* __restrict__ uid,
-                                  double* __restrict__ usum, int32_t* __restrict__ udeg, int32_t* __restrict__ raw2du, unsigned long long* __restrict__ deg_total) {
-    unsigned long long local = 0;
-    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n_ids; r += (int64_t)gridDim.x * blockDim.x) {
-        const unsigned long long v = packed[r];
-        int32_t d = -1;
-        if (v) {
-            d = (int32_t)du1[r] - 1;
-            uid[d] = (int32_t)r;
-            udeg[d] = (int32_t)(v & ((1ull << FIX_DEG_BITS) - 1));
-            usum[d] = (double)(v >> FIX_DEG_BITS) * (1.0 / (double)(1 << FIX_SHIFT));
-            local += v & ((1ull << FIX_DEG_BITS) - 1);
-        }
-        raw2du[r] = d;
-    }
-    for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o, 64);
-    if ((threadIdx.x & 63) == 0 && local) atomicAdd(deg_total, local);
-}
-// the (cluster : raw item) keys of sort #3 straight from the COO (no user-major copy exists on this path); a dropped rating gets the
-// key of cluster K, behind every real cluster
-__global__ void k_cluster_item_keys_coo(int64_t n, const int32_t* __restrict__ user, const int32_t* __restrict__ item, const float* __restrict__ score,
-                                        int keep_nonpositive, const int32_t* __restrict__ raw2du, const int32_t* __restrict__ ucluster,
-                                        const int32_t* __restrict__ du2slot, int32_t K, uint64_t* __restrict__ keys, uint64_t* __restrict__ vals, int ib) {
-    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
-        const float s = score[t];
-        const bool keep = keep_nonpositive ? (s == s) : (s > 0.0f);
-        uint64_t k = (uint64_t)(uint32_t)K << ib, v = 0;
-        if (keep) {
-            const int32_t du = raw2du[user[t]];
-            k = ((uint64_t)(uint32_t)ucluster[du] << ib) | (uint32_t)item[t];
-            v = ((uint64_t)(uint32_t)du2slot[du] << 32) | __float_as_uint(s);
-        }
-        keys[t] = k;
-        vals[t] = v;
-    }
-}
-
 __global__ void k_heads_hi32(int64_t n, const uint64_t* __restrict__ keys, uint32_t* __restrict__ head, int check_dup,
                              int* __restrict__ err, int ib) {
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
@@ -438,14 +354,10 @@ __global__ void k_csr_keys_ranked(int64_t n, const int32_t* __restrict__ csc_slo
     }
 }
 
-// csr_idx from the sorted (slot : index) keys; two equal neighbours are one user's two ratings of one item
-__global__ void k_low_bits(int64_t n, const uint64_t* __restrict__ keys, int32_t* __restrict__ out, int rb, int* __restrict__ err) {
+__global__ void k_low_bits(int64_t n, const uint64_t* __restrict__ keys, int32_t* __restrict__ out, int rb) {
     const uint64_t mask = ((uint64_t)1 << rb) - 1;
-    for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) {
-        const uint64_t k = keys[q];
-        out[q] = (int32_t)(uint32_t)(k & mask);
-        if (q > 0 && keys[q - 1] == k) atomicOr(err, ERR_DUP);
-    }
+    for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x)
+        out[q] = (int32_t)(uint32_t)(keys[q] & mask);
 }
 
 __global__ void k_slot_degrees(int32_t nU, const int32_t* __restrict__ slot2du, const int32_t* __restrict__ udeg,
@@ -530,72 +442,17 @@ void build_structure(Context* ctx, const fy_ratings* R, int32_t K, int64_t n_map
     err.zero();
     DevBuf<unsigned long long> kept(ctx, 1);
     kept.zero();
-    const bool force_sort = false;
 
-    auto bits_for = [](uint64_t v) { int b = 0; while (v) { b++; v >>= 1; } return b; };   // bits that hold every value <= v
-    // (the id bounds were found when the ratings entered HBM, fy_ratings_create: a property of the container like nnz)
-    const int ib = std::max(1, bits_for((uint64_t)std::max(0, R->max_item)));      // bits of the item field of the sort keys
-    unsigned long long h_kept = 0;
-    int h_flags = 0;
-    int64_t nnz = 0;
-    int32_t nU = 0;
-    // what the two ways of finding the users leave behind for sort #3
-    DevBuf<uint64_t> k1a, k1b;
-    DevBuf<float> sc_um;
-    DevBuf<uint32_t> head, du1;
-    DevBuf<int32_t> raw2du;
-    uint64_t* ukeys = nullptr;
-    bool users_by_table = false, check_deg_total = false;
-    unsigned long long h_deg_total = 0;
-    // ---- users by table (see k_user_hist): dense bounded ids, fixed-point ratings
-    if (ctx->tune.prep_user_table && !force_sort && n_in > 0 && R->max_user >= 0 && (int64_t)R->max_user < 4 * n_in + (1 << 20) && R->max_item < (1 << FIX_DEG_BITS) - 1) {
-        const int64_t n_ids = (int64_t)R->max_user + 1;
-        DevBuf<unsigned long long> packed(ctx, (size_t)n_ids), deg_total(ctx, 1);
-        FY_HIP(hipMemsetAsync(packed.get(), 0, (size_t)n_ids * sizeof(unsigned long long), st));
-        deg_total.zero();
-        k_user_hist<<<grid_for(n_in), 256, 0, st>>>(n_in, R->user.get(), R->item.get(), R->score.get(), keep_nonpositive ? 1 : 0, packed.get(), kept.get(), err.get());
-        FY_KERNEL_CHECK();
-        DevBuf<uint32_t> present(ctx, (size_t)n_ids), pdu1(ctx, (size_t)n_ids);
-        k_user_present<<<grid_for(n_ids), 256, 0, st>>>(n_ids, packed.get(), present.get());
-        FY_KERNEL_CHECK();
-        inclusive_scan_u32(ctx, present.get(), pdu1.get(), (size_t)n_ids);
-        uint32_t h_nU = 0;
-        d2h(ctx, &h_kept, kept.get(), 1);
-        d2h(ctx, &h_flags, err.get(), 1);
-        d2h(ctx, &h_nU, pdu1.get() + (n_ids - 1), 1);
-        sync(ctx);
-        if (h_flags & ERR_NEG_ID) FY_FAIL(FY_ERR_NEGATIVE_ID, "negative user or item id in the ratings");
-        if (!(h_flags & NOTE_NOT_FIX)) {
-            nnz = (int64_t)h_kept;
-            nU = (int32_t)h_nU;
-            if (nnz > 0) {
-                P.uid.alloc(ctx, nU);
-                P.usum.alloc(ctx, nU);
-                P.udeg.alloc(ctx, nU);
-                raw2du.alloc(ctx, (size_t)n_ids);
-                k_users_from_hist<<<grid_for(n_ids), 256, 0, st>>>(n_ids, packed.get(), pdu1.get(), P.uid.get(), P.usum.get(), P.udeg.get(), raw2du.get(), deg_total.get());
-                FY_KERNEL_CHECK();
-                d2h(ctx, &h_deg_total, deg_total.get(), 1);      // (read at the next synchronisation, below)
-                check_deg_total = true;
-                sync(ctx);      // (packed / present / pdu1 go back to the allocator behind this)
-            }
-            users_by_table = true;
-        }
-        if (!users_by_table) {      // a rating that is no multiple of 2^-9 below 128: start over with the sort
-            kept.zero();
-            err.zero();
-            h_kept = 0;
-            h_flags = 0;
-        }
-    }
     // ---- sort #1: user-major order, duplicates / negative ids detected
-    if (!users_by_table) {
-    k1a.alloc(ctx, n_in);
-    k1b.alloc(ctx, n_in);
-    sc_um.alloc(ctx, n_in);
+    DevBuf<uint64_t> k1a(ctx, n_in), k1b(ctx, n_in);
+    DevBuf<float> sc_um(ctx, n_in);
+    auto bits_for = [](uint64_t v) { int b = 0; while (v) { b++; v >>= 1; } return b; };   // bits that hold every value <= v
+    int ib = 1;   // bits of the item field of the sort keys
     if (n_in) {
+        // (the id bounds were found when the ratings entered HBM, fy_ratings_create: a property of the container like nnz)
         const int32_t hmax[2] = {R->max_user, R->max_item};
         const uint32_t drop_user = (uint32_t)(hmax[0] + 1);
+        ib = std::max(1, bits_for((uint64_t)std::max(0, hmax[1])));
         const int ub = std::max(1, bits_for(drop_user));
         k_user_item_keys<<<grid_for(n_in), 256, 0, st>>>(n_in, R->user.get(), R->item.get(), R->score.get(),
                                                           keep_nonpositive ? 1 : 0, ib, drop_user, k1a.get(), kept.get(), err.get());
@@ -606,11 +463,12 @@ void build_structure(Context* ctx, const fy_ratings* R, int32_t K, int64_t n_map
         sort_pairs_u64_f32(ctx, k1a.get(), k1b.get(), const_cast<float*>(R->score.get()), sc_um.get(), n_in, std::min(64, ib + ub), ib);
     }
     // (host round trips cost ~30 us each plus the bubble behind them: what can be read together is read together)
+    unsigned long long h_kept = 0;
+    int h_flags = 0;
     d2h(ctx, &h_kept, kept.get(), 1);
     d2h(ctx, &h_flags, err.get(), 1);
     sync(ctx);
-    nnz = (int64_t)h_kept;
-    }
+    const int64_t nnz = (int64_t)h_kept;
     P.nnz = nnz;
     {
         const int flags = h_flags;
@@ -629,16 +487,15 @@ void build_structure(Context* ctx, const fy_ratings* R, int32_t K, int64_t n_map
         P.cluster_q.assign(K + 1, 0);
         return;
     }
-    if (!users_by_table) {
     k1a.release();
-    ukeys = k1b.get();   // user-major (items of a user in input order), first nnz entries are the kept ratings
+    uint64_t* ukeys = k1b.get();   // user-major (items of a user in input order), first nnz entries are the kept ratings
 
-    head.alloc(ctx, nnz);
-    du1.alloc(ctx, nnz);
+    DevBuf<uint32_t> head(ctx, nnz), du1(ctx, nnz);
     k_heads_hi32<<<grid_for(nnz), 256, 0, st>>>(nnz, ukeys, head.get(), 0, err.get(), ib);
     FY_KERNEL_CHECK();
     inclusive_scan_u32(ctx, head.get(), du1.get(), nnz);
-    nU = (int32_t)fetch(ctx, du1.get() + (nnz - 1));
+    const int32_t nU = (int32_t)fetch(ctx, du1.get() + (nnz - 1));
+    P.nU = nU;
 
     P.uid.alloc(ctx, nU);
     DevBuf<int32_t> ustart(ctx, (size_t)nU + 1);
@@ -650,11 +507,6 @@ void build_structure(Context* ctx, const fy_ratings* R, int32_t K, int64_t n_map
     P.udeg.alloc(ctx, nU);
     k_user_sums<<<grid_for((int64_t)nU * 64, 256), 256, 0, st>>>(nU, ustart.get(), sc_um.get(), P.usum.get(), P.udeg.get());
     FY_KERNEL_CHECK();
-    sync(ctx);      // (ustart goes back to the allocator)
-    } else {
-        head.alloc(ctx, nnz);      // (the head flags of sort #3 below)
-    }
-    P.nU = nU;
 
     // ---- cluster routing
     P.ucluster.alloc(ctx, nU);
@@ -699,9 +551,6 @@ void build_structure(Context* ctx, const fy_ratings* R, int32_t K, int64_t n_map
     d2h(ctx, &h_flags, err.get(), 1);
     sync(ctx);
     if (h_flags & ERR_CLUSTER_RANGE) FY_FAIL(FY_ERR_CLUSTER_RANGE, "a rated user is routed to a cluster outside [0, %d)", K);
-    // users by table: a 24-bit degree field that ran over (one user with 2^24 entries or more -- more than there are items) shows as a
-    // degree total that is not the number of kept ratings; such a user holds duplicate (user, item) keys
-    if (check_deg_total && (int64_t)h_deg_total != nnz) FY_FAIL(FY_ERR_DUPLICATE_RATING, "two ratings share one (user, item) key");
     P.ucstart.assign(K + 1, 0);
     for (int c = 0; c < K; c++) P.ucstart[c + 1] = P.ucstart[c] + P.csize[c];
     if (cluster_count)
@@ -713,26 +562,17 @@ void build_structure(Context* ctx, const fy_ratings* R, int32_t K, int64_t n_map
     h2d(ctx, P.d_ucstart.get(), P.ucstart.data(), (size_t)K + 1);
 
     // ---- sort #3: (cluster, item) order = the CSC
-    // (users by table: the keys come straight from all n_in COO entries, dropped ratings carry cluster K and sort behind the kept ones)
-    const int64_t n3 = users_by_table ? n_in : nnz;
-    DevBuf<uint64_t> k3b(ctx, n3);
-    DevBuf<uint64_t> v_sorted(ctx, n3);
+    DevBuf<uint64_t> k3b(ctx, nnz);
+    DevBuf<uint64_t> v_sorted(ctx, nnz);
     {
-        DevBuf<uint64_t> k3a(ctx, n3), v3a(ctx, n3);
-        if (users_by_table)
-            k_cluster_item_keys_coo<<<grid_for(n_in), 256, 0, st>>>(n_in, R->user.get(), R->item.get(), R->score.get(), keep_nonpositive ? 1 : 0, raw2du.get(),
-                                                                    P.ucluster.get(), P.du2slot.get(), K, k3a.get(), v3a.get(), ib);
-        else
-            k_cluster_item_keys<<<grid_for(nnz), 256, 0, st>>>(nnz, ukeys, du1.get(), P.ucluster.get(), P.du2slot.get(), sc_um.get(), k3a.get(),
-                                                                v3a.get(), ib);
+        DevBuf<uint64_t> k3a(ctx, nnz), v3a(ctx, nnz);
+        k_cluster_item_keys<<<grid_for(nnz), 256, 0, st>>>(nnz, ukeys, du1.get(), P.ucluster.get(), P.du2slot.get(), sc_um.get(), k3a.get(),
+                                                            v3a.get(), ib);
         FY_KERNEL_CHECK();
-        sort_pairs_u64_u64(ctx, k3a.get(), k3b.get(), v3a.get(), v_sorted.get(), n3, std::min(64, ib + bits_for((uint64_t)(users_by_table ? K : K - 1))));
+        sort_pairs_u64_u64(ctx, k3a.get(), k3b.get(), v3a.get(), v_sorted.get(), nnz, std::min(64, ib + bits_for((uint64_t)(K - 1))));
     }
     DevBuf<uint32_t> pr1(ctx, nnz);
-    // (sort path: the columns are in user order, one user's two ratings of an item are neighbours here; table path: the columns are in
-    // input order, duplicates are found as neighbours of the sorted CSR rows below)
-    if (users_by_table) k_heads_full<<<grid_for(nnz), 256, 0, st>>>(nnz, k3b.get(), head.get());
-    else k_heads_full_dup<<<grid_for(nnz), 256, 0, st>>>(nnz, k3b.get(), v_sorted.get(), head.get(), err.get());
+    k_heads_full_dup<<<grid_for(nnz), 256, 0, st>>>(nnz, k3b.get(), v_sorted.get(), head.get(), err.get());
     FY_KERNEL_CHECK();
     inclusive_scan_u32(ctx, head.get(), pr1.get(), nnz);
     uint32_t h_nP = 0;
@@ -823,7 +663,7 @@ void build_structure(Context* ctx, const fy_ratings* R, int32_t K, int64_t n_map
         P.csr_r.alloc(ctx, nnz);
         sort_pairs_u64_f32(ctx, ka.get(), kb.get(), r_ranked.get(), P.csr_r.get(), nnz, std::min(64, rb + std::max(1, bits_for((uint64_t)(nU - 1)))), rb);
         P.csr_idx.alloc(ctx, nnz);
-        k_low_bits<<<grid_for(nnz), 256, 0, st>>>(nnz, kb.get(), P.csr_idx.get(), rb, err.get());
+        k_low_bits<<<grid_for(nnz), 256, 0, st>>>(nnz, kb.get(), P.csr_idx.get(), rb);
         FY_KERNEL_CHECK();
     }
 
@@ -851,12 +691,6 @@ void build_structure(Context* ctx, const fy_ratings* R, int32_t K, int64_t n_map
             gather_to_host_i64(ctx, d2pre.get(), where, got.data());      // (synchronises: the copies above have landed too)
             for (size_t t = 0; t < where.size(); t++) at_end[(size_t)which[t]] = got[t];
             if (where.empty()) sync(ctx);
-        }
-        {      // duplicates found in the sorted CSR rows (k_low_bits)
-            int f = 0;
-            d2h(ctx, &f, err.get(), 1);
-            sync(ctx);
-            if (f & ERR_DUP) FY_FAIL(FY_ERR_DUPLICATE_RATING, "two ratings share one (user, item) key");
         }
         P.cluster_deg2.assign((size_t)K, 0);
         int64_t before = 0;

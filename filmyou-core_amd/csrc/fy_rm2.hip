@@ -1425,6 +1425,27 @@ static int score_slices(const Context* ctx, const ScoreTune& tune, int64_t nb, i
     return (int)std::max<int64_t>(1, std::min<int64_t>(tune.max_slices, std::min(finest, std::max(coarse, fill))));
 }
 
+// Super-blocks of the bound pass (k_score_sup): the fine 256-column blocks [seed_blocks, nblk) in at most 64 groups -- the first 48
+// one block each (that is where survivors are: the columns are in popularity order and RM2 scores fall steeply with it), the rest
+// in 16 groups of growing width.  first[s] .. first[s + 1] are the fine blocks of group s.
+static void sup_block_map(int seed_blocks, int nblk, std::vector<int32_t>& first) {
+    first.clear();
+    const int R = std::max(0, nblk - seed_blocks);
+    if (R <= 64) {
+        for (int s = 0; s <= R; s++) first.push_back(seed_blocks + s);
+        return;
+    }
+    for (int s = 0; s < 48; s++) first.push_back(seed_blocks + s);
+    const int rem = R - 48;
+    int64_t cum = 0;
+    for (int k = 0; k < 16; k++) {            // widths ~ (k + 1): 1 + 2 + .. + 16 = 136 parts
+        first.push_back(seed_blocks + 48 + (int32_t)((int64_t)rem * cum / 136));
+        cum += k + 1;
+    }
+    first.push_back(nblk);
+    for (size_t k = 1; k < first.size(); k++) first[k] = std::max(first[k], first[k - 1]);      // (monotone; a group may be empty)
+}
+
 // one cluster's launch plan
 struct Plan {
     int c;
@@ -2013,6 +2034,8 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             DevBuf<int2> stray_items;
             DevBuf<int32_t> n_heavy;       // k_count_heavy
             DevBuf<int32_t> need;          // lazy mirror: column blocks with survivors
+            DevBuf<float> Bsup, asup, bsupb, UBs;      // super-block bounds (k_score_sup)
+            DevBuf<int32_t> sup_first;
             DevBuf<int32_t> n_quads, quad_prefix;
             DevBuf<char> scan_tmp;         // temporary storage of the lane's scans
             DevBuf<int2> item_seg, item_seg_t;      // (_t: the tail-row bound launch of a cluster whose row kernels are batched)
@@ -2511,6 +2534,25 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 launch_mirror(ctx, L.M.get(), ldm, Ic, p.prune ? L.Bmax.get() : nullptr, p.ldb, ls, nullptr, lazy ? std::min(tune.seed_chunks, p.nblk) : 0x7FFFFFFF);
                 t_mirror.end(sm, ls);
             }
+            if (p.prune && !p.panel && tune.sup_bounds) {      // super-block bounds for the seed pass (k_score_sup)
+                const int seed_b = std::min(tune.seed_chunks, p.nblk);
+                std::vector<int32_t> first;
+                sup_block_map(seed_b, p.nblk, first);
+                const int n_sup = (int)first.size() - 1;
+                first.resize(65, first.back());
+                L.sup_first.alloc(ctx, 65);
+                L.Bsup.alloc(ctx, (size_t)Ic * 64);
+                L.asup.alloc(ctx, 64);
+                L.bsupb.alloc(ctx, 64);
+                FY_HIP(hipMemcpyAsync(L.sup_first.get(), first.data(), 65 * sizeof(int32_t), hipMemcpyHostToDevice, ls));
+                FY_HIP(hipStreamSynchronize(ls));      // (`first` is a host temporary; one cluster: no other lane is waiting)
+                const size_t sb = t_score.begin(ls);
+                k_build_bsup<<<std::min<int>((Ic + 3) / 4, ctx->num_cus * 32), 256, 0, ls>>>(Ic, n_sup, L.sup_first.get(), L.Bmax.get(), p.ldb, L.Bsup.get());
+                FY_KERNEL_CHECK();
+                k_sup_amax<<<1, 64, 0, ls>>>(n_sup, L.sup_first.get(), L.amax.get(), L.bmax.get(), L.asup.get(), L.bsupb.get());
+                FY_KERNEL_CHECK();
+                t_score.end(sb, ls);
+            }
             }      // do_build
             if (!do_score) continue;
 
@@ -2562,7 +2604,8 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 const int32_t nb = (int32_t)std::min<int64_t>(B, b - s0);
                 if (!p.prune) { full_pass(s0, nb, L.S.get()); continue; }
                 const int seed_chunks = std::min(n_chunks, tune.seed_chunks);
-                const int n_slices = score_slices(ctx, tune, nb, seed_chunks + (int)(p.ldb / 256));
+                const bool use_sup = tune.sup_bounds && !p.panel;      // bounds over super-blocks, evaluated by the seed chunk's own waves
+                const int n_slices = score_slices(ctx, tune, nb, seed_chunks + (use_sup ? 0 : (int)(p.ldb / 256)));
                 // front in phase 2, back in phase 3 (the whole cluster in one batch: its CSR range is on the host already)
                 const bool split = two_phase && p.panel && s0 == sbase && nb == p.Uc;
                 if (phase == 3 && !split) continue;
@@ -2584,6 +2627,14 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 const int bchunks = (int)(bld / 256);
                 int32_t hv[3] = {0, 0, 0};   // survivors, first / last CSR entry of the batch
                 if (phase != 3) {
+                if (use_sup) {
+                    ScoreArgs SU = score_args(Gmat, gld, Ic, a_rank.get() + pbase, s0, nb, L.S.get(), SC, n_slices, seed_chunks);
+                    L.UBs.alloc(ctx, (size_t)nb * 64);
+                    SU.Bsup = L.Bsup.get(); SU.asup = L.asup.get(); SU.bsup_b = L.bsupb.get(); SU.UBsup = L.UBs.get();
+                    SU.n_sup = std::min(64, std::max(0, p.nblk - seed_chunks));
+                    k_score_sup<<<seed_chunks * n_slices, 256, 0, ls>>>(SU.M, SU.a_rank, SU.rb_off, SU.csr_idx, SU.csr_e, SU.csr_q, SU.pvpi, SU.n_out, SU.S, SU);
+                    FY_KERNEL_CHECK();
+                }
                 ScoreArgs SA = score_args(Gmat, gld, Ic, a_rank.get() + pbase, s0, nb, L.S.get(), SC, n_slices, seed_chunks + bchunks);
                 SA.chunks1 = seed_chunks;
                 SA.M2 = p.panel ? PP.Bmax64 : L.Bmax.get();
@@ -2594,8 +2645,10 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 SA.S2 = L.UB.get();
                 SA.ldS2 = bld;
                 SA.no_mask2 = 1;
-                k_score<4, true, 8><<<(seed_chunks + bchunks) * n_slices, 256, 0, ls>>>(SA.M, SA.a_rank, SA.rb_off, SA.csr_idx, SA.csr_e, SA.csr_q, SA.pvpi, SA.n_out, SA.S, SA);
-                FY_KERNEL_CHECK();
+                if (!use_sup) {
+                    k_score<4, true, 8><<<(seed_chunks + bchunks) * n_slices, 256, 0, ls>>>(SA.M, SA.a_rank, SA.rb_off, SA.csr_idx, SA.csr_e, SA.csr_q, SA.pvpi, SA.n_out, SA.S, SA);
+                    FY_KERNEL_CHECK();
+                }
                 // (2) tau_u = N-th best seed score; the sorted seed head is also the user's list unless a block survives
                 TopNArgs T1{L.S.get(), SC, Ic, n_out.get(), out_off.get(), P.rank_item_raw.get() + pbase, P.slot2du.get(), P.uid.get(),
                             lo, s0, c, R->d_key0.get(), R->d_key1.get(), R->d_value.get(), R->d_aux.get(),
@@ -2614,6 +2667,9 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 if (p.panel)
                     k_bound_select_sub<<<grid_for((int64_t)nb * 64, 256), 256, 0, ls>>>(L.UB.get(), bld, p.nsub, p.nblk, seed_blocks, L.tau.get(),
                                                                                        pvpi.get() + (s0 - lo), nb, bld, L.surv.get(), L.surv_mask.get(), L.n_quads.get());
+                else if (use_sup)
+                    k_bound_select_sup<<<grid_for((int64_t)nb * 64, 256), 256, 0, ls>>>(L.UBs.get(), std::min(64, std::max(0, p.nblk - seed_chunks)), L.sup_first.get(), L.tau.get(),
+                                                                                       pvpi.get() + (s0 - lo), nb, p.ldb, L.surv.get(), L.n_quads.get());
                 else
                     k_bound_select<<<grid_for((int64_t)nb * 64, 256), 256, 0, ls>>>(L.UB.get(), p.ldb, p.nblk, seed_blocks, L.tau.get(), pvpi.get() + (s0 - lo), nb,
                                                                                    L.surv.get(), L.n_quads.get());

@@ -48,6 +48,14 @@ struct ScoreArgs {
     // the first *n_heavy users of the batch (slots are in descending order of degree) are walked by the four waves of a
     // workgroup together, a quarter of the list each; nullptr = none
     const int32_t* __restrict__ n_heavy;
+    // super-block bounds riding with the seed chunk (score_body<..., SUP = true>, one-cluster pruned job): Bsup[j][s], s < 64 = the
+    // largest matrix entry of row j inside super-block s (fp32, one dword per lane), asup / bsup_b the super-blocks' maxima of a / b,
+    // UBsup[u][64] receives the bounds (NaN for s >= n_sup)
+    const float* __restrict__ Bsup;
+    const float* __restrict__ asup;
+    const float* __restrict__ bsup_b;
+    float* __restrict__ UBsup;
+    int32_t n_sup;
 };
 // number of users at the head of a batch (descending degree) with more than `thresh` ratings
 __global__ void k_count_heavy(const int32_t* __restrict__ rowptr /* of the batch's first slot */, int32_t n_users, int32_t thresh,
@@ -113,7 +121,7 @@ __device__ __forceinline__ bool fy_bound_keeps(float ub, float tau, float pvpi) 
     return ub + (4e-6f * S + 1e-4f) >= tau;
 }
 
-template <int VEC, bool P24, int SB>
+template <int VEC, bool P24, int SB, bool SUP = false>
 __device__ __forceinline__ void score_body(const float* __restrict__ M_, const float* __restrict__ a_rank_,
                                            const int32_t* __restrict__ rb_off_, const int32_t* __restrict__ csr_idx_,
                                            const float* __restrict__ csr_e_, const float* __restrict__ csr_q_,
@@ -144,6 +152,15 @@ __device__ __forceinline__ void score_body(const float* __restrict__ M_, const f
         a[v] = col + v < Ic_sel ? asel[col + v] : 0.0f;
         bb[v] = col + v < Ic_sel ? bsel[col + v] : 0.0f;
     }
+    // SUP: the wave that scores seed chunk 0 also evaluates the user's bounds of up to 64 SUPER-BLOCKS (lane = super-block): one more
+    // dword per lane and row, one more log term per lane -- instead of a second work item per user that streams a 768-byte row of
+    // block maxima per rated item (round 3: seed chunk + bound chunk = 1536 B per rating; now 768 + 256)
+    const bool sup_here = SUP && chunk == 0 && !second;
+    float as_ = 0.f, bs_ = 0.f;
+    if constexpr (SUP) {
+        if (sup_here && lane < A.n_sup) { as_ = A.asup[lane]; bs_ = A.bsup_b[lane]; }
+    }
+    const float* __restrict__ Bsup_lane = SUP ? A.Bsup + lane : nullptr;
     // byte address of this lane's part of row 0; the row pitch is ldm * (P24 ? 3 : 4) bytes
     const char* __restrict__ Mcol = reinterpret_cast<const char*>(Msel) + (int64_t)col * (P24 ? 3 : 4);
     const int64_t pitch = ldm_sel * (P24 ? 3 : 4);
@@ -157,7 +174,7 @@ __device__ __forceinline__ void score_body(const float* __restrict__ M_, const f
     // logs -- 24 dependent scalar round trips per batch of 8 rows, which is what "bound by scalar-load latency" meant.)
     // All SB row-segment loads are issued before the first use, also for a short tail (out-of-range slots re-load the last valid
     // row -- an L1 hit -- and are skipped by a wave-uniform test).
-    auto walk = [&](int beg, int end, double* t, unsigned& mask) __attribute__((always_inline)) {
+    auto walk = [&](int beg, int end, double* t, unsigned& mask, double& ts) __attribute__((always_inline)) {
         if (beg >= end) return;
         static_assert(SB <= 64, "one lane per row of a batch");
         const int sub = lane & (SB - 1);     // (SB is a power of two)
@@ -171,12 +188,16 @@ __device__ __forceinline__ void score_body(const float* __restrict__ M_, const f
             G g[SB];
             float e[SB], qq[SB];
             int jj[SB];
+            float gs[SUP ? SB : 1];
 #pragma unroll
             for (int q = 0; q < SB; q++) {
                 jj[q] = __builtin_amdgcn_readlane(vi, q);
                 e[q] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ve), q));
                 qq[q] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(vq), q));
                 g[q] = *reinterpret_cast<const G*>(Mcol + (int64_t)jj[q] * pitch);
+                if constexpr (SUP) {
+                    if (sup_here) gs[q] = Bsup_lane[(int64_t)jj[q] * 64];      // (wave-uniform branch)
+                }
             }
             {   // the next batch's triplets (clamped: the last batch re-reads the list's last row)
                 const int kk = min(k + SB + sub, end - 1);
@@ -190,9 +211,14 @@ __device__ __forceinline__ void score_body(const float* __restrict__ M_, const f
             int pe[VEC];
 #pragma unroll
             for (int v = 0; v < VEC; v++) { p[v] = 1.f; pe[v] = 0; }
+            float ps = 1.f;
+            int pes = 0;
 #pragma unroll
             for (int q = 0; q < SB; q++) {
                 if (k + q < end) {
+                    if constexpr (SUP) {
+                        if (sup_here) fy_logprod_step(fmaf(qq[q], bs_, fmaf(as_, e[q], gs[q])), ps, pes);
+                    }
                     float gv[VEC];
                     if constexpr (P24) fy_unpack24(g[q], gv);
                     else {
@@ -208,6 +234,9 @@ __device__ __forceinline__ void score_body(const float* __restrict__ M_, const f
             }
 #pragma unroll
             for (int v = 0; v < VEC; v++) t[v] += fy_logprod_fold(p[v], pe[v]);
+            if constexpr (SUP) {
+                if (sup_here) ts += fy_logprod_fold(ps, pes);
+            }
             vi = vi_n; ve = ve_n; vq = vq_n;
         }
     };
@@ -222,10 +251,16 @@ __device__ __forceinline__ void score_body(const float* __restrict__ M_, const f
             if ((mask >> v) & 1u || col + v >= Ic_sel) ov[v] = qnan;
         *reinterpret_cast<V*>(Ssel + (int64_t)u * ldS_sel + col) = o;
     };
+    auto store_sup = [&](int u, int slot, double ts) __attribute__((always_inline)) {
+        if constexpr (SUP) {
+            if (sup_here) A.UBsup[(int64_t)u * 64 + lane] = lane < A.n_sup ? (float)(pvpi_[slot - A.slot_lo] + LN2 * ts) : qnan;
+        }
+    };
     // ---- heavy users (the head of the batch): one per workgroup, a quarter of the list per wave.  A user with 3 000 ratings on
     // ONE wave (375 batches, one round trip each) was what a cluster's launch waited for: 1.1 ms for a 3 000-user cluster
     // whose average wave was done after 0.1 ms.
     __shared__ double sh_t[3][64][VEC];
+    __shared__ double sh_ts[SUP ? 3 : 1][64];
     __shared__ unsigned sh_mask[3][64];
     const int n_heavy = A.n_heavy ? min(*A.n_heavy, A.n_users) : 0;
     for (int u = slice; u < n_heavy; u += A.n_slices) {            // block-uniform
@@ -239,11 +274,13 @@ __device__ __forceinline__ void score_body(const float* __restrict__ M_, const f
 #pragma unroll
         for (int v = 0; v < VEC; v++) t[v] = 0.0;
         unsigned mask = 0;
-        walk(wb, we, t, mask);
+        double ts = 0.0;
+        walk(wb, we, t, mask, ts);
         if (wave > 0) {
 #pragma unroll
             for (int v = 0; v < VEC; v++) sh_t[wave - 1][lane][v] = t[v];
             sh_mask[wave - 1][lane] = mask;
+            if constexpr (SUP) sh_ts[wave - 1][lane] = ts;
         }
         __syncthreads();
         if (wave == 0) {
@@ -251,8 +288,10 @@ __device__ __forceinline__ void score_body(const float* __restrict__ M_, const f
 #pragma unroll
                 for (int v = 0; v < VEC; v++) t[v] += sh_t[x][lane][v];
                 mask |= sh_mask[x][lane];
+                if constexpr (SUP) ts += sh_ts[x][lane];
             }
             store(u, slot, t, mask);
+            store_sup(u, slot, ts);
         }
         __syncthreads();   // sh_t is free again
     }
@@ -265,17 +304,31 @@ __device__ __forceinline__ void score_body(const float* __restrict__ M_, const f
 #pragma unroll
         for (int v = 0; v < VEC; v++) t[v] = 0.0;
         unsigned mask = 0;
-        walk(beg, end, t, mask);
+        double ts = 0.0;
+        walk(beg, end, t, mask, ts);
         store(u, slot, t, mask);
+        store_sup(u, slot, ts);
     }
 }
+// (Round 4 held the register allocator to 64 VGPRs -- eight waves per SIMD instead of the seven that its 68 allow -- with
+// amdgpu_waves_per_eu(8, 8): 6.19 against 6.14 ms for the scoring family, nothing; the kernel sits at the gather rate of the cache
+// hierarchy, not at its occupancy.)
 template <int VEC, bool P24, int SB>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_score(const float* __restrict__ M_, const float* __restrict__ a_rank_,
+__global__ __launch_bounds__(256) void k_score(const float* __restrict__ M_, const float* __restrict__ a_rank_,
                                                const int32_t* __restrict__ rb_off_, const int32_t* __restrict__ csr_idx_,
                                                const float* __restrict__ csr_e_, const float* __restrict__ csr_q_,
                                                const double* __restrict__ pvpi_,
                                                const int32_t* __restrict__ n_out_, float* __restrict__ S_, ScoreArgs A) {
     score_body<VEC, P24, SB>(M_, a_rank_, rb_off_, csr_idx_, csr_e_, csr_q_, pvpi_, n_out_, S_, A, (int)blockIdx.x);
+}
+
+// the seed pass of the one-cluster pruned job with the super-block bounds riding along (score_body<..., SUP = true>)
+__global__ __launch_bounds__(256) void k_score_sup(const float* __restrict__ M_, const float* __restrict__ a_rank_,
+                                                   const int32_t* __restrict__ rb_off_, const int32_t* __restrict__ csr_idx_,
+                                                   const float* __restrict__ csr_e_, const float* __restrict__ csr_q_,
+                                                   const double* __restrict__ pvpi_,
+                                                   const int32_t* __restrict__ n_out_, float* __restrict__ S_, ScoreArgs A) {
+    score_body<4, true, 8, true>(M_, a_rank_, rb_off_, csr_idx_, csr_e_, csr_q_, pvpi_, n_out_, S_, A, (int)blockIdx.x);
 }
 
 // ================================================================ top-N (PriorityQueue + poll loop, AbstractRM2Reducer.java:325, 358-369)
@@ -1525,6 +1578,55 @@ __global__ void k_gather_rows(int32_t r0, int32_t stride, int32_t nrows, const i
 }
 
 // owner of the user: blocks behind the seed whose (summed) bound reaches tau_u, in ascending block order
+// ---- super-block bounds (one-cluster pruned job).  Super-block s < n_sup covers the fine 256-column blocks [first[s], first[s + 1]):
+// Bsup[j][s] = the largest entry of matrix row j in those blocks (= max of the Bmax entries: exact, the maximum of 24-bit values is
+// one), asup / bsup_b likewise from the blocks' maxima of a and b.  A bound over a super-block is >= the bound of each of its blocks,
+// so a super-block below tau_u excludes all of them; one that is kept hands ALL its fine blocks to the survivor pass.
+// (Measured at ML-25M shape, N = 50: the 22 600 surviving (user, block) pairs of the headline job lie in blocks 1 .. 8 of 231.)
+__global__ void k_build_bsup(int32_t Ic, int32_t n_sup, const int32_t* __restrict__ first, const float* __restrict__ Bmax, int64_t ldb,
+                             float* __restrict__ Bsup) {
+    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    for (int32_t j = blockIdx.x * wpb + (threadIdx.x >> 6); j < Ic; j += gridDim.x * wpb) {
+        float m = 0.f;
+        if (lane < n_sup)
+            for (int b = first[lane]; b < first[lane + 1]; b++) m = fmaxf(m, fy_load24(Bmax, (int64_t)j * ldb + b));
+        Bsup[(int64_t)j * 64 + lane] = m;
+    }
+}
+__global__ void k_sup_amax(int32_t n_sup, const int32_t* __restrict__ first, const float* __restrict__ amax, const float* __restrict__ bmax,
+                           float* __restrict__ asup, float* __restrict__ bsup_b) {
+    const int s = threadIdx.x;
+    if (s >= 64) return;
+    float ma = 0.f, mb = 0.f;
+    if (s < n_sup)
+        for (int b = first[s]; b < first[s + 1]; b++) { ma = fmaxf(ma, amax[b]); mb = fmaxf(mb, bmax[b]); }
+    asup[s] = ma;
+    bsup_b[s] = mb;
+}
+// survivors from the super-block bounds: one wave per user, the fine blocks of every kept super-block in ascending order
+__global__ __launch_bounds__(256) void k_bound_select_sup(const float* __restrict__ UBsup, int32_t n_sup, const int32_t* __restrict__ first,
+                                                          const float* __restrict__ tau, const double* __restrict__ pvpi /* [u] */, int32_t n_users,
+                                                          int64_t ldb, uint16_t* __restrict__ surv, int32_t* __restrict__ n_surv) {
+    const int lane = threadIdx.x & 63;
+    const int wpb = blockDim.x >> 6;
+    for (int u = blockIdx.x * wpb + (threadIdx.x >> 6); u < n_users; u += gridDim.x * wpb) {
+        const float t = tau[u];
+        const float pv = (float)pvpi[u];
+        // (tau = +inf: the user emits nothing and its UBsup row was never written)
+        const bool keep = lane < n_sup && t != INFINITY && fy_bound_keeps(UBsup[(int64_t)u * 64 + lane], t, pv);
+        const int width = keep ? first[lane + 1] - first[lane] : 0;
+        int incl = width;                                   // inclusive prefix of the widths over the lanes
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int x = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += x;
+        }
+        const int at = incl - width;
+        for (int k = 0; k < width; k++) surv[(int64_t)u * ldb + at + k] = (uint16_t)(first[lane] + k);
+        const int total = __shfl(incl, 63, 64);
+        if (lane == 0) n_surv[u] = total;
+    }
+}
 __global__ __launch_bounds__(256) void k_bound_select(const float* __restrict__ UB, int64_t ldb, int32_t nblk, int32_t seed_blocks,
                                                       const float* __restrict__ tau, const double* __restrict__ pvpi /* [u] */,
                                                       int32_t n_users, uint16_t* __restrict__ surv, int32_t* __restrict__ n_surv) {
