@@ -1913,10 +1913,20 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             // Long lists are pruned only where a few big clusters keep their dense matrices.  Measured at 50 clusters of ML-25M shape with
             // N = 1000 (round 4): 41 % of the (user, block) pairs survive the bound of a 3 250-user cluster and 10 M of them lie behind
             // the panel -- 14.9 s per job against 0.67 s for the plain full pass; one cluster: 14 % survive, 271 against 471 ms.
+            // (and on dense per-cluster matrices instead of panels: 29 568 184 of 29 568 241 blocks survive -- a 3 250-user neighbourhood's
+            // 1000th best score is no threshold -- every cluster falls back to the full pass, 957 ms)
             if (long_seed && n_pruned >= tune.panel_min_clusters && !tune.seed_forced) {
                 for (auto& p : plans)
                     if (!p.coop) p.prune = false;
                 n_pruned = 0;
+            }
+            // A cluster that takes the plain full pass reads its WHOLE matrix.  The symmetric walk + mirror pass pays where the walk is
+            // bound by its pair visits (one cluster of ML-25M shape: 6.5e9 visits, 8 ms; the mirror 2.6 ms); a cluster of many (50
+            // clusters: 1.3e8 visits each for 2.6e9 matrix elements) is bound by the rows it WRITES -- 1.65 ms for the half matrix plus 4.3 ms
+            // to mirror 7.8 GB, against ~3.3 ms for the full walk: such clusters walk full rows and skip the mirror.
+            for (auto& p : plans) {
+                const double deg2 = (size_t)p.c < P.cluster_deg2.size() ? (double)P.cluster_deg2[p.c] : (double)P.sum_deg2;
+                if (!p.prune && !p.coop && p.half && tune.full_walk_sparse && deg2 < (double)p.Ic * (double)p.Ic) p.half = false;
             }
             if (n_pruned >= tune.panel_min_clusters)
                 for (auto& p : plans)
@@ -2778,7 +2788,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 R->st.score_launches += 2;   // the fused seed + bound launch and the survivor pass
                 prune_blocks_total += blocks_checked;
                 // log terms of the seed and bound passes of this batch: (ratings of its users) x (columns walked)
-                prune_seed_terms_cols += (int64_t)(hv[2] - hv[1]) * (seed_chunks * 256 + bld);
+                prune_seed_terms_cols += (int64_t)(hv[2] - hv[1]) * (seed_chunks * 256 + (use_sup ? 64 : bld));
                 const int32_t seed_cols_p = seed_chunks * 256;
                 TopNArgs TA{L.S.get(), (int64_t)seed_cols_p, Ic, n_out.get(), out_off.get(), P.rank_item_raw.get() + pbase,
                             P.slot2du.get(), P.uid.get(), lo, s0, c, R->d_key0.get(), R->d_key1.get(), R->d_value.get(), R->d_aux.get(),
