@@ -32,16 +32,37 @@ static inline int grid_for(int64_t n, int block = 256, int cap = 256 * 16) {
     return (int)std::max<int64_t>(1, std::min<int64_t>(g, cap));
 }
 
-// one wave per item (pair): L2 norm of the item's rating column, fixed summation order
-__global__ void k_item_norms(int32_t nP, const int32_t* __restrict__ pair_start, const float* __restrict__ csc_r,
-                             double* __restrict__ norm) {
-    const int lane = threadIdx.x & 63;
-    const int wpb = blockDim.x >> 6;
-    for (int32_t p = blockIdx.x * wpb + (threadIdx.x >> 6); p < nP; p += gridDim.x * wpb) {
+// one WORKGROUP per item (pair): L2 norm of the item's rating column in a fixed summation order (thread-strided partial sums, wave
+// shuffles, the four waves' partials in order), and -- round 4 -- the column's rating sum and largest rating in the same pass (the
+// bounds of the fixed-point scale of the symmetric build; k_isim_gram_prep walked the columns a second time for them).  A wave per
+// item made both passes wait for the heaviest column: 81 k entries on one wave = 1 270 dependent trips, 0.6 ms each pass.
+__global__ __launch_bounds__(256) void k_item_norms(int32_t nP, const int32_t* __restrict__ pair_start, const float* __restrict__ csc_r,
+                                                    double* __restrict__ norm, float* __restrict__ colsum, float* __restrict__ colmax) {
+    __shared__ double sh_s[4];
+    __shared__ float sh_sum[4], sh_max[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int32_t p = blockIdx.x; p < nP; p += gridDim.x) {
         double s = 0.0;
-        for (int32_t q = pair_start[p] + lane; q < pair_start[p + 1]; q += 64) s += (double)csc_r[q] * (double)csc_r[q];
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
-        if (lane == 0) norm[p] = sqrt(s);
+        float sum = 0.0f, mx = 0.0f;
+        for (int32_t q = pair_start[p] + threadIdx.x; q < pair_start[p + 1]; q += 256) {
+            const float r = csc_r[q];
+            s += (double)r * (double)r;
+            sum += r;
+            mx = fmaxf(mx, r);
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            s += __shfl_down(s, o, 64);
+            sum += __shfl_down(sum, o, 64);
+            mx = fmaxf(mx, __shfl_down(mx, o, 64));
+        }
+        if (lane == 0) { sh_s[wave] = s; sh_sum[wave] = sum; sh_max[wave] = mx; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            norm[p] = sqrt(((sh_s[0] + sh_s[1]) + sh_s[2]) + sh_s[3]);
+            if (colsum) colsum[p] = ((sh_sum[0] + sh_sum[1]) + sh_sum[2]) + sh_sum[3];
+            if (colmax) colmax[p] = fmaxf(fmaxf(sh_max[0], sh_max[1]), fmaxf(sh_max[2], sh_max[3]));
+        }
+        __syncthreads();
     }
 }
 
@@ -710,25 +731,26 @@ __global__ void k_sum_i32(int32_t n, const int32_t* __restrict__ v, unsigned lon
     if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, s);
 }
 
-// per item in rank order: 1 / norm (fp64 and fp32) and the bounds of the fixed-point scale (largest column sum / largest rating)
-__global__ void k_isim_gram_prep(int32_t Ic, int64_t ld_pad, const int32_t* __restrict__ rank_pair, const int32_t* __restrict__ pair_start,
-                                 const float* __restrict__ csc_r, const double* __restrict__ norm, double* __restrict__ invn, float* __restrict__ invn32,
+// per item in rank order: 1 / norm (fp64 and fp32) and the bounds of the fixed-point scale (largest column sum / largest rating, from
+// k_item_norms' per-column sums and maxima: no second walk over the columns)
+__global__ void k_isim_gram_prep(int32_t Ic, int64_t ld_pad, const int32_t* __restrict__ rank_pair, const float* __restrict__ colsum,
+                                 const float* __restrict__ colmax, const double* __restrict__ norm, double* __restrict__ invn, float* __restrict__ invn32,
                                  uint32_t* __restrict__ bounds /* [0] max column sum, [1] max rating, as float bits */) {
-    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
-    for (int64_t r = blockIdx.x * wpb + (threadIdx.x >> 6); r < ld_pad; r += (int64_t)gridDim.x * wpb) {
-        if (r >= Ic) { if (lane == 0) invn32[r] = 0.0f; continue; }
+    float bs = 0.0f, bm = 0.0f;
+    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < ld_pad; r += (int64_t)gridDim.x * blockDim.x) {
+        if (r >= Ic) { invn32[r] = 0.0f; continue; }
         const int32_t pr = rank_pair[r];
-        float sum = 0.0f, mx = 0.0f;
-        for (int32_t q = pair_start[pr] + lane; q < pair_start[pr + 1]; q += 64) { sum += csc_r[q]; mx = fmaxf(mx, csc_r[q]); }
-        for (int o = 32; o > 0; o >>= 1) { sum += __shfl_down(sum, o, 64); mx = fmaxf(mx, __shfl_down(mx, o, 64)); }
-        if (lane == 0) {
-            const double inv = 1.0 / norm[pr];
-            invn[r] = inv;
-            invn32[r] = (float)inv;
-            // positive floats order like their bits; the read in front keeps 59 047 atomics off ONE address (82 M/s: 1.4 ms)
-            if (__float_as_uint(sum * 1.0001f) > bounds[0]) atomicMax(&bounds[0], __float_as_uint(sum * 1.0001f));
-            if (__float_as_uint(mx) > bounds[1]) atomicMax(&bounds[1], __float_as_uint(mx));
-        }
+        const double inv = 1.0 / norm[pr];
+        invn[r] = inv;
+        invn32[r] = (float)inv;
+        bs = fmaxf(bs, colsum[pr] * 1.0001f);
+        bm = fmaxf(bm, colmax[pr]);
+    }
+    // positive floats order like their bits; one atomic per wave (59 047 atomics on ONE address took 1.4 ms: 82 M/s)
+    for (int o = 32; o > 0; o >>= 1) { bs = fmaxf(bs, __shfl_down(bs, o, 64)); bm = fmaxf(bm, __shfl_down(bm, o, 64)); }
+    if ((threadIdx.x & 63) == 0) {
+        if (__float_as_uint(bs) > bounds[0]) atomicMax(&bounds[0], __float_as_uint(bs));
+        if (__float_as_uint(bm) > bounds[1]) atomicMax(&bounds[1], __float_as_uint(bm));
     }
 }
 __global__ void k_fill_u32(int64_t n, uint32_t v, uint32_t* __restrict__ out) {
@@ -736,8 +758,8 @@ __global__ void k_fill_u32(int64_t n, uint32_t v, uint32_t* __restrict__ out) {
 }
 
 // the symmetric build; false = not applicable here (the caller runs the row-at-a-time build).  cnt / other / sim as the other build leaves them.
-static bool itemsim_symmetric(Context* ctx, const fy_itemsim_params* prm, const Prepared& P, const double* norm, int32_t* cnt, int32_t* other,
-                              float* sim, double* ms_cooc, fy_stats* st_out) {
+static bool itemsim_symmetric(Context* ctx, const fy_itemsim_params* prm, const Prepared& P, const double* norm, const float* colsum, const float* colmax,
+                              int32_t* cnt, int32_t* other, float* sim, double* ms_cooc, fy_stats* st_out) {
     const Tuning& tune = ctx->tune;
     const int32_t Ic = P.nP, K = prm->max_similarities_per_item;
     if (tune.isim_gram == 0 || prm->world != 1 || prm->similarity != FY_SIMILARITY_COSINE || !tune.cooc_pk || !P.ratings_fp16_exact ||
@@ -751,8 +773,7 @@ static bool itemsim_symmetric(Context* ctx, const fy_itemsim_params* prm, const 
     DevBuf<float> invn32(ctx, (size_t)(ldm + slack));
     DevBuf<uint32_t> d_bounds(ctx, 2);
     d_bounds.zero();
-    k_isim_gram_prep<<<grid_for((ldm + slack) * 64, 256), 256, 0, st>>>(Ic, ldm + slack, P.rank_pair.get(), P.pair_start.get(), P.csc_r.get(), norm, invn.get(),
-                                                                        invn32.get(), d_bounds.get());
+    k_isim_gram_prep<<<grid_for(ldm + slack, 256, 256), 256, 0, st>>>(Ic, ldm + slack, P.rank_pair.get(), colsum, colmax, norm, invn.get(), invn32.get(), d_bounds.get());
     FY_KERNEL_CHECK();
     uint32_t hb[2];
     d2h(ctx, hb, d_bounds.get(), 2);
@@ -988,7 +1009,8 @@ fy_result* itemsim_build(Context* ctx, const fy_itemsim_params* prm, const fy_ra
     const Tuning& tune = ctx->tune;
     const bool use_pk = P.ratings_fp16_exact && tune.cooc_pk;
     DevBuf<double> norm(ctx, Ic), inv_norm(ctx, Ic);
-    k_item_norms<<<grid_for((int64_t)Ic * 64, 256), 256, 0, st>>>(Ic, P.pair_start.get(), P.csc_r.get(), norm.get());
+    DevBuf<float> colsum(ctx, Ic), colmax(ctx, Ic);
+    k_item_norms<<<std::min<int>(Ic, ctx->num_cus * 32), 256, 0, st>>>(Ic, P.pair_start.get(), P.csc_r.get(), norm.get(), colsum.get(), colmax.get());
     FY_KERNEL_CHECK();
     const int K = prm->max_similarities_per_item;
     const int32_t rows_mine = (Ic - prm->rank + prm->world - 1) / prm->world;
@@ -996,7 +1018,7 @@ fy_result* itemsim_build(Context* ctx, const fy_itemsim_params* prm, const fy_ra
     DevBuf<float> sim(ctx, (size_t)rows_mine * K);
     cnt.zero();
     double ms_sym = 0.0;
-    const bool symmetric = itemsim_symmetric(ctx, prm, P, norm.get(), cnt.get(), other.get(), sim.get(), &ms_sym, &Rs->st);
+    const bool symmetric = itemsim_symmetric(ctx, prm, P, norm.get(), colsum.get(), colmax.get(), cnt.get(), other.get(), sim.get(), &ms_sym, &Rs->st);
     if (symmetric) Rs->st.cooc_launches = 1;
     DevBuf<float> csc_w(ctx, symmetric ? 1 : (size_t)P.nnz), csr_w(ctx, (use_pk || symmetric) ? 1 : (size_t)P.nnz);
     DevBuf<uint32_t> csr_pk(ctx, (use_pk && !symmetric) ? (size_t)P.nnz : 1);
