@@ -144,7 +144,7 @@ class Stats(C.Structure):
                 ("panel_clusters", C.c_int64), ("stray_blocks", C.c_int64), ("bound_repairs", C.c_int64),
                 ("isim_candidates", C.c_int64), ("isim_redone_rows", C.c_int64),
                 ("prepared_from_cache", C.c_int64), ("tables_from_cache", C.c_int64),
-                ("cooc_segments", C.c_int64), ("cooc_matrix_bytes", C.c_int64)]
+                ("cooc_segments", C.c_int64), ("cooc_matrix_bytes", C.c_int64), ("rows_refined", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -29,6 +29,8 @@ void fy::load_tuning_from_env(Tuning& t) {
     if (const char* e = getenv("FY_SCORE_UPW")) { int v = atoi(e); if (v >= 1) t.users_per_wave = v; }
     if (const char* e = getenv("FY_PRUNE")) t.prune = atoi(e) != 0;
     if (const char* e = getenv("FY_LAZY_MIRROR")) t.lazy_mirror = atoi(e) != 0;
+    if (const char* e = getenv("FY_REFINE")) t.refine = atoi(e) != 0;
+    if (const char* e = getenv("FY_REFINE_C")) { double v = atof(e); if (v >= 0.0 && v < 1e6) t.refine_c = (float)v; }
     if (const char* e = getenv("FY_FULL_WALK_SPARSE")) t.full_walk_sparse = atoi(e) != 0;
     if (const char* e = getenv("FY_SUP_BOUNDS")) t.sup_bounds = atoi(e) != 0;
     if (const char* e = getenv("FY_COOP")) t.coop = atoi(e) != 0;

@@ -629,6 +629,14 @@ struct MEpilogue {
     // written per row, the rows are `pitch` elements apart (0: the pitch is the row length) and the 24-bit rounding goes up
     int64_t pitch;
     int ceil24;
+    // fp32 copies of the rows the refinement pass reads (k_refine_rows, round 4): the first head_rows rows of the matrix, whole, at
+    // pitch ld_head (symmetric walks: only the columns behind the row are meaningful), and -- symmetric panel mode, whose head rows
+    // are not walked over the tail rows' columns -- the first 256 columns of every row from tail_from on.  nullptr = off.
+    float* __restrict__ head32;
+    int64_t ld_head;
+    int32_t head_rows;
+    float* __restrict__ tail32;
+    int32_t tail_from;
 };
 
 // Epilogue of one (row, chunk) item of the RM2 row kernel: G[i][chunk] = w2 * acc -> 24-bit pack (or fp32), the block maxima, and the
@@ -657,14 +665,21 @@ __device__ __forceinline__ void cooc_rm2_epilogue(const CoocArgs& A, const MEpil
             const int qz = A.acc_quarter;
             ACC* ap = acc + (qz ? c4 - (c0 >> 2) : 4 * c4 - c0);
             const int qs = qz ? qz : 1;                       // stride between the four columns of the lane
+            float f4[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 float f;                                      // columns >= Ic were never touched: 0
                 if constexpr (std::is_integral<ACC>::value) f = (float)((double)ap[q * qs] * E.fx_inv);
                 else f = E.w2 * (float)ap[q * qs];
                 ap[q * qs] = (ACC)0;
+                f4[q] = f;
                 v[q] = (__float_as_uint(f) + radd) >> FY_P24_SHIFT;    // 0 <= f < 2: 7 exponent + 17 mantissa bits, round to nearest (or up)
             }
+            // the unrounded fp32 values of the rows / columns the refinement pass re-scores ill-conditioned list rows from
+            if (E.head32 && mrow < E.head_rows && 4 * c4 < E.ld_head)
+                *reinterpret_cast<float4*>(E.head32 + (int64_t)mrow * E.ld_head + 4 * c4) = make_float4(f4[0], f4[1], f4[2], f4[3]);
+            if (E.tail32 && row >= E.tail_from && 4 * c4 < 256)
+                *reinterpret_cast<float4*>(E.tail32 + (int64_t)(row - E.tail_from) * 256 + 4 * c4) = make_float4(f4[0], f4[1], f4[2], f4[3]);
             if (!E.panel_cols || 4 * c4 < E.panel_cols) {
                 out3[3 * c4 + 0] = v[0] | (v[1] << 24);
                 out3[3 * c4 + 1] = (v[1] >> 8) | (v[2] << 16);
@@ -1202,6 +1217,7 @@ struct TableCache {
 struct RM2Static {
     // key
     int32_t K = 0, rank = 0, world = 1;
+    int32_t max_item = -1;      // largest raw item id of the ratings (fy_ratings::max_item): the refinement pass maps raw ids to columns by table
     bool has_count = false;
     std::vector<int32_t> map_user, map_cluster, cluster_count;
     // fy_rm2_prepare
@@ -1617,6 +1633,7 @@ fy_rm2_job* fy::rm2_prepare(Context* ctx, const fy_rm2_params* prm, const fy_rat
     fresh->K = prm->number_of_clusters;
     fresh->rank = prm->rank;
     fresh->world = prm->world;
+    fresh->max_item = R->max_item;
     fresh->has_count = cluster_count != nullptr;
     if (n_map) { fresh->map_user.assign(map_user, map_user + n_map); fresh->map_cluster.assign(map_cluster, map_cluster + n_map); }
     if (cluster_count) fresh->cluster_count.assign(cluster_count, cluster_count + prm->number_of_clusters);
@@ -2045,6 +2062,8 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             DevBuf<int32_t> n_heavy;       // k_count_heavy
             DevBuf<int32_t> need;          // lazy mirror: column blocks with survivors
             DevBuf<float> Bsup, asup, bsupb, UBs;      // super-block bounds (k_score_sup)
+            DevBuf<float> head32, tail32;              // fp32 rows / columns the refinement pass reads (k_refine_rows)
+            DevBuf<int32_t> colmap;
             DevBuf<int32_t> sup_first;
             DevBuf<int32_t> n_quads, quad_prefix;
             DevBuf<char> scan_tmp;         // temporary storage of the lane's scans
@@ -2117,7 +2136,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 L.item_id.alloc(ctx, is_el);
             }
         }
-        DevBuf<unsigned long long> prune_counters(ctx, 5);   // [0] surviving blocks, [1] log terms evaluated by the three pruned passes, [2] users sent to k_topn_select, [3] stray blocks (panel mode)
+        DevBuf<unsigned long long> prune_counters(ctx, 6);   // ... [5] list rows scored again by the refinement pass   // [0] surviving blocks, [1] log terms evaluated by the three pruned passes, [2] users sent to k_topn_select, [3] stray blocks (panel mode)
         prune_counters.zero();
         int64_t prune_blocks_total = 0, prune_seed_terms_cols = 0, coop_survived = 0, fallback_survived = 0;
         for (auto& p : plans) any_coop = any_coop || p.coop;
@@ -2322,6 +2341,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
         struct PanelBuf {
             DevBuf<float> Gp, Bmax64, amax64, bmax64;
             DevBuf<uint32_t> Brep;
+            DevBuf<float> head32, tail32;      // (refinement pass: per cluster, like the panels -- built in phase 1, read in phase 3)
         };
         struct PanelPtrs {
             float *Gp, *Bmax64;
@@ -2473,6 +2493,22 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                          pack24 ? 1 : 0, (p.prune && !p.panel) ? L.Bmax.get() : nullptr, p.ldb, 0,
                          p.panel ? p.panel_cols : 0, p.panel ? PP.Bmax64 : nullptr, p.ldb64, p.panel ? PP.Brep : nullptr};
             if (p.panel) ME.M = PP.Gp;
+            // refinement (k_refine_rows): packed clusters keep the unrounded fp32 values of their first 256 rows (and, in symmetric panel
+            // mode, of the first 256 columns of the tail rows)
+            const bool refine = tune.refine && pack24 && !p.coop && fxk >= 0 && J->S->max_item >= 0 && J->S->max_item < (1 << 28);
+            const int32_t head_rows = std::min<int32_t>(256, Ic);
+            const int64_t ld_head = p.psym ? (int64_t)p.p_eff : ldm;
+            DevBuf<float>& H32 = (two_phase && p.panel) ? pbuf[pi].head32 : L.head32;
+            DevBuf<float>& T32 = (two_phase && p.panel) ? pbuf[pi].tail32 : L.tail32;
+            if (refine && do_build) {
+                H32.alloc(ctx, (size_t)head_rows * ld_head + 4);
+                if (p.psym) T32.alloc(ctx, (size_t)std::max(1, Ic - p.p_eff) * 256 + 4);
+                ME.head32 = H32.get();
+                ME.ld_head = ld_head;
+                ME.head_rows = head_rows;
+                ME.tail32 = p.psym ? T32.get() : nullptr;
+                ME.tail_from = p.p_eff;
+            }
             if (do_build) {
             if (p.panel) {
                 R->st.panel_clusters++;
@@ -2544,7 +2580,10 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 launch_mirror(ctx, L.M.get(), ldm, Ic, p.prune ? L.Bmax.get() : nullptr, p.ldb, ls, nullptr, lazy ? std::min(tune.seed_chunks, p.nblk) : 0x7FFFFFFF);
                 t_mirror.end(sm, ls);
             }
-            if (p.prune && !p.panel && tune.sup_bounds) {      // super-block bounds for the seed pass (k_score_sup)
+            // (not for long lists: their survivors -- 14 % of the blocks at N = 1000 -- spread over the whole popularity order, the 16 wide
+            // groups behind the first 48 blocks all survive and hand every block to the survivor pass: measured, the batch falls back to
+            // the full pass, 261 -> 471 ms)
+            if (p.prune && !p.panel && tune.sup_bounds && !long_seed) {      // super-block bounds for the seed pass (k_score_sup)
                 const int seed_b = std::min(tune.seed_chunks, p.nblk);
                 std::vector<int32_t> first;
                 sup_block_map(seed_b, p.nblk, first);
@@ -2587,6 +2626,34 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 }
                 return SA;
             };
+            // ill-conditioned list rows of a range of users, scored again in fp64 from the fp32 head rows (k_refine_rows); after the lists stand
+            auto refine_rows = [&](int32_t s0, int32_t nb) {
+                if (!refine || nb <= 0) return;
+                const size_t tt = t_topn.begin(ls);
+                const int32_t n_ids = J->S->max_item + 1;
+                L.colmap.alloc(ctx, (size_t)n_ids);
+                FY_HIP(hipMemsetAsync(L.colmap.get(), 0xFF, (size_t)n_ids * sizeof(int32_t), ls));
+                k_refine_colmap<<<1, 256, 0, ls>>>(head_rows, P.rank_item_raw.get() + pbase, L.colmap.get());
+                FY_KERNEL_CHECK();
+                RefineArgs RA{};
+                RA.slot0 = s0; RA.n_users = nb; RA.slot_lo = lo; RA.slot_base = sbase;
+                RA.n_out = n_out.get(); RA.out_off = out_off.get(); RA.out_item = R->d_key1.get(); RA.out_score = R->d_value.get(); RA.out_item_w = R->d_key1.get();
+                RA.rowptr = P.rowptr.get(); RA.csr_idx = P.csr_idx.get(); RA.csr_r = P.csr_r.get(); RA.usum_slot = J->usum_slot.get();
+                RA.p_rank = p_rank.get() + pbase; RA.b_rank = b_rank.get() + pbase;
+                RA.colmap = L.colmap.get(); RA.max_item = J->S->max_item;
+                RA.head32 = H32.get(); RA.ld_head = ld_head; RA.tail32 = p.psym ? T32.get() : nullptr; RA.tail_from = p.p_eff;
+                if (!RA.head32 || (p.psym && !RA.tail32)) FY_FAIL(FY_ERR_STATE, "internal: cluster %d has no fp32 rows for the refinement pass", c);
+                RA.unscale = 1.0 / (double)h_gscale[(size_t)c];
+                RA.lambda = lambda; RA.ln_items = std::log((double)prm.number_of_items); RA.ln_users = std::log((double)p.Uc);
+                RA.users_minus_1 = (double)(p.Uc - 1);
+                RA.refine_c = tune.refine_c;
+                RA.n_refined = prune_counters.get() + 5;
+                int lp2 = 64;
+                while (lp2 < std::min<int>(prm.number_of_recommendations, Ic)) lp2 <<= 1;
+                k_refine_rows<<<(nb + 3) / 4, 256, (size_t)4 * lp2 * sizeof(uint64_t), ls>>>(RA);
+                FY_KERNEL_CHECK();
+                t_topn.end(tt, ls);
+            };
             // the plain full pass over a range of users: every log term, like the reference's loop (AbstractRM2Reducer.java:332-356)
             auto full_pass = [&](int32_t s0, int32_t nb, float* Sx) {
                 const int n_slices = score_slices(ctx, tune, nb, n_chunks);
@@ -2609,12 +2676,13 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 k_topn_select<<<nb, 256, 0, ls>>>(TA, L.overflow.get(), L.any_overflow.get(), prune_counters.get() + 2);
                 FY_KERNEL_CHECK();
                 t_topn.end(tt, ls);
+                refine_rows(s0, nb);
             };
             for (int32_t s0 = a; s0 < b; s0 += (int32_t)B) {
                 const int32_t nb = (int32_t)std::min<int64_t>(B, b - s0);
                 if (!p.prune) { full_pass(s0, nb, L.S.get()); continue; }
                 const int seed_chunks = std::min(n_chunks, tune.seed_chunks);
-                const bool use_sup = tune.sup_bounds && !p.panel;      // bounds over super-blocks, evaluated by the seed chunk's own waves
+                const bool use_sup = tune.sup_bounds && !p.panel && !long_seed;      // bounds over super-blocks, evaluated by the seed chunk's own waves
                 const int n_slices = score_slices(ctx, tune, nb, seed_chunks + (use_sup ? 0 : (int)(p.ldb / 256)));
                 // front in phase 2, back in phase 3 (the whole cluster in one batch: its CSR range is on the host already)
                 const bool split = two_phase && p.panel && s0 == sbase && nb == p.Uc;
@@ -2803,6 +2871,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 k_topn_select<<<nb, 256, 0, ls>>>(TA, L.overflow.get(), L.any_overflow.get(), prune_counters.get() + 2);
                 FY_KERNEL_CHECK();
                 t_topn.end(tt, ls);
+                refine_rows(s0, nb);
                 checkpoint("back (survivors, strays, lists)");
             }
         }
@@ -2874,8 +2943,8 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
         }
         // (the guard's destructor drains the lanes and the main stream before any buffer of this scope is released)
         {
-            unsigned long long hc[5];
-            d2h(ctx, hc, prune_counters.get(), 5);
+            unsigned long long hc[6];
+            d2h(ctx, hc, prune_counters.get(), 6);
             sync(ctx);
             if (!tables_cached && !all_at_once) {        // (build_tables_all counts its one table itself)
                 tc.total_segments = 0;
@@ -2894,6 +2963,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             R->st.topn_select_users = (int64_t)hc[2];
             R->st.stray_blocks = (int64_t)hc[3];
             R->st.bound_repairs = (int64_t)hc[4];
+            R->st.rows_refined = (int64_t)hc[5];
             R->st.blocks_survived = (int64_t)hc[0] + coop_survived + fallback_survived;
             R->st.blocks_total = prune_blocks_total;
             R->st.log_terms_evaluated = prune_blocks_total ? (int64_t)hc[1] + prune_seed_terms_cols : 0;

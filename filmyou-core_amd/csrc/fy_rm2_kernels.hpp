@@ -1648,6 +1648,121 @@ __global__ __launch_bounds__(256) void k_bound_select(const float* __restrict__ 
 }
 
 // (slot, block) of every surviving block of this rank's users, packed for the all-gather
+// ================================================================ refinement of ill-conditioned list rows (round 4)
+// score(u, i) = pvpi + sum of ~n log terms of magnitude ~10 each; where the two cancel (|score| ~ 1: users with a dozen ratings, every
+// multi-cluster job) the absolute error of the production arithmetic -- 17 mantissa bits per matrix element -- is a RELATIVE error of
+// the same size: the one row that carried the all-rows maximum against the fp64 definition (6.3e-6 of north_star's 1e-5) was such a
+// row.  After a cluster's lists stand, every list row with |score| < refine_c * sqrt(n) whose item lies in the first 256 columns (the
+// popular candidates: where list items are) is scored AGAIN in fp64 from the unrounded fp32 matrix values the row kernel's epilogue
+// kept for exactly those columns (MEpilogue::head32 / tail32) and the fp64 statistics (p, b, s_u):
+//     G(j, c) = head32[min(j, c)][max(j, c)]        (row min(j, c) < 256 walked column max(j, c): G is symmetric)
+//             = tail32[j - tail_from][c]            symmetric panel mode, j a tail row (its walk covered the head columns)
+// and the user's list is put back in order (a re-scored row moves by ~1e-6 of its value).  n gathers and n fp64 logs per row.
+__global__ void k_refine_colmap(int32_t n_cols, const int32_t* __restrict__ rank_item_raw /* offset by pbase */, int32_t* __restrict__ colmap) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < n_cols) colmap[rank_item_raw[c]] = c;
+}
+struct RefineArgs {
+    int32_t slot0, n_users, slot_lo, slot_base;
+    const int32_t* __restrict__ n_out;       // by slot - slot_lo
+    const int32_t* __restrict__ out_off;
+    const int32_t* __restrict__ out_item;    // raw ids
+    float* __restrict__ out_score;
+    int32_t* __restrict__ out_item_w;        // (the same array, written when a list is re-sorted)
+    const int32_t* __restrict__ rowptr;      // global, by slot
+    const int32_t* __restrict__ csr_idx;
+    const float* __restrict__ csr_r;
+    const double* __restrict__ usum_slot;
+    const double* __restrict__ p_rank;       // offset by pbase
+    const double* __restrict__ b_rank;
+    const int32_t* __restrict__ colmap;      // raw item id -> column (< n_cols) or -1
+    int32_t max_item;
+    const float* __restrict__ head32;
+    int64_t ld_head;
+    const float* __restrict__ tail32;
+    int32_t tail_from;
+    double unscale;                          // 1 / (the 2^-c the stored matrix is scaled by)
+    double lambda, ln_items, ln_users;       // ln(numberOfItems), ln(U_c)
+    double users_minus_1;
+    float refine_c;
+    unsigned long long* __restrict__ n_refined;
+};
+__global__ __launch_bounds__(256) void k_refine_rows(RefineArgs A) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t fy_refine_keys[];      // [4 waves][lp2]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int u = blockIdx.x * 4 + w;
+    if (u >= A.n_users) return;                                   // wave-uniform; nothing below synchronises the workgroup
+    const int slot = A.slot0 + u;
+    const int K = A.n_out[slot - A.slot_lo];
+    if (K == 0) return;
+    const int beg = A.rowptr[slot], end = A.rowptr[slot + 1], n = end - beg;
+    const int off = A.out_off[slot - A.slot_lo];
+    const float thr = A.refine_c * sqrtf((float)n);
+    const double su = A.usum_slot[slot];
+    const double l = A.lambda, w2 = (1.0 - l) * (1.0 - l);
+    int changed = 0;
+    for (int r = 0; r < K; r++) {                                 // wave-uniform loop over the list
+        const float s = A.out_score[off + r];
+        if (!(fabsf(s) < thr)) continue;                          // (also skips -inf / NaN)
+        const int raw = A.out_item[off + r];
+        const int c = (raw >= 0 && raw <= A.max_item) ? A.colmap[raw] : -1;
+        if (c < 0) continue;
+        const double pc = A.p_rank[c], bc = A.b_rank[c];
+        double sum = 0.0;
+        for (int k = lane; k < n; k += 64) {
+            const int j = A.csr_idx[beg + k];
+            const double x = (double)A.csr_r[beg + k] / su;
+            float g32;
+            if (A.tail32 && j >= A.tail_from) g32 = A.tail32[(int64_t)(j - A.tail_from) * 256 + c];
+            else g32 = A.head32[(int64_t)min(j, c) * A.ld_head + max(j, c)];
+            const double pj = A.p_rank[j];
+            const double e = (1.0 - l) * (A.b_rank[j] - x) + l * A.users_minus_1 * pj;
+            const double term = (double)g32 * A.unscale + l * (1.0 - l) * pj * bc + l * pc * e;
+            (void)w2;
+            sum += log(term);
+        }
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        const double score = (double)(n - 1) * A.ln_items - (double)n * A.ln_users + sum;
+        if (lane == 0) A.out_score[off + r] = (float)score;
+        changed++;
+    }
+    if (!changed) return;
+    if (lane == 0 && A.n_refined) atomicAdd(A.n_refined, (unsigned long long)changed);
+    // back in order: descending score, ties by ascending raw item id (the top-N kernels' key)
+    int lp2 = 64;
+    while (lp2 < K) lp2 <<= 1;
+    uint64_t* __restrict__ keys = fy_refine_keys + (size_t)w * lp2;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");        // lane 0's stores above are visible to the wave's loads
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < lp2; i += 64) {
+        uint64_t kk = 0ull;
+        if (i < K) {
+            // (agent-scope load: lane 0's re-scored values must not come from a stale L1 line)
+            const uint32_t sb = __hip_atomic_load(reinterpret_cast<const uint32_t*>(A.out_score) + off + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            kk = ((uint64_t)fy_order_key(__uint_as_float(sb)) << 32) | (uint32_t)(0x7FFFFFFF - A.out_item[off + i]);
+        }
+        keys[i] = kk;
+    }
+    fy_wave_fence();
+    for (int k = 2; k <= lp2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = lane; i < lp2; i += 64) {
+                const int x = i ^ j;
+                if (x > i) {
+                    const uint64_t a = keys[i], b = keys[x];
+                    const bool desc = (i & k) == 0;
+                    if (desc ? (a < b) : (a > b)) { keys[i] = b; keys[x] = a; }
+                }
+            }
+            fy_wave_fence();
+        }
+    for (int i = lane; i < K; i += 64) {
+        const uint64_t c = keys[i];
+        A.out_item_w[off + i] = 0x7FFFFFFF - (int32_t)(uint32_t)c;
+        A.out_score[off + i] = fy_order_unkey((uint32_t)(c >> 32));
+    }
+}
+
 // how many users keep block b (debug: FY_DEBUG_SYNC=3 prints the distribution; round 4 measured it to decide on a lazy mirror pass)
 __global__ void k_surv_block_counts(int32_t n_users, const int32_t* __restrict__ n_quads, const uint16_t* __restrict__ surv, int64_t ldb, int32_t* __restrict__ counts) {
     for (int32_t u = blockIdx.x; u < n_users; u += gridDim.x)

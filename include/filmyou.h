@@ -266,6 +266,7 @@ typedef struct {
      * (bench.py roofline.frac_own_bytes) and its LDS-atomic floor (one ds_add wave instruction per segment): */
     int64_t cooc_segments;       /* <= 64-entry segments in the job's segment tables (12 B of descriptor each) */
     int64_t cooc_matrix_bytes;   /* bytes of co-rating matrix / panel / block-bound rows the row kernels store */
+    int64_t rows_refined;        /* list rows whose score nearly cancels (|score| < c sqrt(n)) and that were scored again in fp64 from the fp32 head rows */
 } fy_stats;
 int fy_result_stats(fy_result*, fy_stats* out);
 

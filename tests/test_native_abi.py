@@ -26,7 +26,7 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(P._native.RM2Params) == 48
     assert C.sizeof(P._native.ItemSimParams) == 48
     assert C.sizeof(P._native.ItemCFParams) == 24
-    assert C.sizeof(P._native.Stats) == 32 * 8
+    assert C.sizeof(P._native.Stats) == 33 * 8
 
 
 def test_no_gpu_means_a_loud_failure():

@@ -371,3 +371,50 @@ def test_long_lists_take_the_branch_and_bound(monkeypatch, shape, K, lam, top_n,
     n_diff, worst = assert_same_lists(by_user(rec.rows()), by_user(full.rows()), score_rtol=1e-5, score_atol=ATOL)
     assert n_diff <= 4, n_diff
     ctx.close()
+
+
+def test_refinement_of_rows_that_nearly_cancel(monkeypatch):
+    """Round 4: list rows with |score| < 2 sqrt(n) whose item lies in the first 256 columns are scored AGAIN in fp64 from the unrounded fp32
+    values of the head rows (k_refine_rows).  The packed 24-bit matrix forced onto MovieLens-100K-shaped data in three clusters with a
+    large numberOfItems (pvpi > 0: scores cross zero): with the pass switched off the worst relative error against the brute-force
+    oracle is that of the format (~1e-5 and more on the rows that cancel); with it the same rows come out at fp32-input precision."""
+    monkeypatch.setenv("FY_PRUNE_MIN_ITEMS", "256")
+    monkeypatch.setenv("FY_M24_MIN_ITEMS", "0")
+    monkeypatch.setenv("FY_SEED_CHUNKS", "1")
+    P, S = pkg(), synth()
+    u, i, s, facts = S.generate("ml100k")
+    u, i, s = u.numpy(), i.numpy(), s.numpy()
+    uu = np.unique(u)
+    clustering = (uu, S.hash_clustering(uu, 3))
+    M = 40_000
+    ref = oracle.rm2(u, i, s, lam=0.1, number_of_items=M, number_of_recommendations=1 << 30, number_of_clusters=3,
+                     map_user=clustering[0], map_cluster=clustering[1], n_threads=8)
+    conf = P.Configuration()
+    conf.set("lambda", "0.1")
+    conf.setInt("numberOfItems", M)
+    conf.setInt("numberOfClusters", 3)
+    conf.setInt("numberOfRecommendations", 30)
+    from util import ATOL, full_ranking
+    ranking = full_ranking(ref)
+
+    def worst_of(rows):
+        w, w_small = 0.0, 0.0
+        for uid, it, sc in zip(rows["user"].tolist(), rows["item"].tolist(), rows["score"].tolist()):
+            items, scores, _ = ranking[uid]
+            want = float(scores[np.flatnonzero(items == it)[0]])
+            rel = abs(sc - want) / abs(want)
+            w = max(w, rel)
+        return w
+    out = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("FY_REFINE", flag)
+        ctx = P.Context(0)
+        rec = P.RM2Job(conf, ctx).run((u, i, s), clustering=clustering)
+        rows, st = rec.rows(), rec.stats
+        assert_topn_matches(rows, ref, 30, atol=ATOL)
+        out[flag] = (worst_of(rows), st["rows_refined"])
+        ctx.close()
+    print("24-bit matrix forced, scores that cross zero: worst relative error without / with the refinement pass: %.2e / %.2e (%d rows re-scored)"
+          % (out["0"][0], out["1"][0], out["1"][1]))
+    assert out["0"][1] == 0 and out["1"][1] > 0
+    assert out["1"][0] <= out["0"][0] and out["1"][0] <= 1e-5
