@@ -1699,32 +1699,42 @@ __global__ __launch_bounds__(256) void k_refine_rows(RefineArgs A) {
     const int off = A.out_off[slot - A.slot_lo];
     const float thr = A.refine_c * sqrtf((float)n);
     const double su = A.usum_slot[slot];
-    const double l = A.lambda, w2 = (1.0 - l) * (1.0 - l);
+    const double l = A.lambda;
     int changed = 0;
-    for (int r = 0; r < K; r++) {                                 // wave-uniform loop over the list
-        const float s = A.out_score[off + r];
-        if (!(fabsf(s) < thr)) continue;                          // (also skips -inf / NaN)
-        const int raw = A.out_item[off + r];
-        const int c = (raw >= 0 && raw <= A.max_item) ? A.colmap[raw] : -1;
-        if (c < 0) continue;
-        const double pc = A.p_rank[c], bc = A.b_rank[c];
-        double sum = 0.0;
-        for (int k = lane; k < n; k += 64) {
-            const int j = A.csr_idx[beg + k];
-            const double x = (double)A.csr_r[beg + k] / su;
-            float g32;
-            if (A.tail32 && j >= A.tail_from) g32 = A.tail32[(int64_t)(j - A.tail_from) * 256 + c];
-            else g32 = A.head32[(int64_t)min(j, c) * A.ld_head + max(j, c)];
-            const double pj = A.p_rank[j];
-            const double e = (1.0 - l) * (A.b_rank[j] - x) + l * A.users_minus_1 * pj;
-            const double term = (double)g32 * A.unscale + l * (1.0 - l) * pj * bc + l * pc * e;
-            (void)w2;
-            sum += log(term);
+    for (int base = 0; base < K; base += 64) {                    // 64 list rows per trip: one load per lane, the rows to re-score by ballot
+        const int rl = base + lane;
+        int cl = -1;
+        if (rl < K) {
+            const float s = A.out_score[off + rl];
+            if (fabsf(s) < thr) {                                 // (also false for -inf / NaN)
+                const int raw = A.out_item[off + rl];
+                if (raw >= 0 && raw <= A.max_item) cl = A.colmap[raw];
+            }
         }
-        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-        const double score = (double)(n - 1) * A.ln_items - (double)n * A.ln_users + sum;
-        if (lane == 0) A.out_score[off + r] = (float)score;
-        changed++;
+        unsigned long long todo = __ballot(cl >= 0);
+        while (todo) {                                            // wave-uniform
+            const int bsel = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const int r = base + bsel;
+            const int c = __shfl(cl, bsel, 64);
+            const double pc = A.p_rank[c], bc = A.b_rank[c];
+            double sum = 0.0;
+            for (int k = lane; k < n; k += 64) {
+                const int j = A.csr_idx[beg + k];
+                const double x = (double)A.csr_r[beg + k] / su;
+                float g32;
+                if (A.tail32 && j >= A.tail_from) g32 = A.tail32[(int64_t)(j - A.tail_from) * 256 + c];
+                else g32 = A.head32[(int64_t)min(j, c) * A.ld_head + max(j, c)];
+                const double pj = A.p_rank[j];
+                const double e = (1.0 - l) * (A.b_rank[j] - x) + l * A.users_minus_1 * pj;
+                const double term = (double)g32 * A.unscale + l * (1.0 - l) * pj * bc + l * pc * e;
+                sum += log(term);
+            }
+            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+            const double score = (double)(n - 1) * A.ln_items - (double)n * A.ln_users + sum;
+            if (lane == 0) A.out_score[off + r] = (float)score;
+            changed++;
+        }
     }
     if (!changed) return;
     if (lane == 0 && A.n_refined) atomicAdd(A.n_refined, (unsigned long long)changed);

@@ -186,6 +186,10 @@ def test_margin_with_heavy_users_and_positive_pvpi(forced, monkeypatch):
     switched off so that the survivor pass itself is what is compared.)"""
     import os
     monkeypatch.setenv("FY_MAX_SURV_FRAC", "1e9")
+    # (the refinement pass off: this test compares the survivor pass with the full pass on the SAME arithmetic; with the pass on, a row whose
+    # |score| sits at the pass's threshold may be re-scored in one of the two runs only -- their unrefined scores differ by 4e-7 -- and
+    # then differs by the forced format's whole error, which on these 750-user clusters of heavy raters is ~1e-4 absolute)
+    monkeypatch.setenv("FY_REFINE", "0")
     P = pkg()
     S = synth()
     u, i, s, facts = S.generate("ml1m")
@@ -396,15 +400,27 @@ def test_refinement_of_rows_that_nearly_cancel(monkeypatch):
     conf.setInt("numberOfRecommendations", 30)
     from util import ATOL, full_ranking
     ranking = full_ranking(ref)
+    # column of an item inside its cluster = popularity rank (most rated first, ties by ascending raw id): the pass re-scores columns < 256
+    cl_of_user = dict(zip(clustering[0].tolist(), clustering[1].tolist()))
+    keep = s > 0
+    col = {}
+    for c in range(3):
+        m = keep & np.array([cl_of_user[x] == c for x in u.tolist()])
+        ids, cnt = np.unique(i[m], return_counts=True)
+        order = np.lexsort((ids, -cnt))
+        col[c] = {int(ids[k]): r for r, k in enumerate(order)}
+    n_of_user = dict(zip(*np.unique(u[keep], return_counts=True)))
 
     def worst_of(rows):
-        w, w_small = 0.0, 0.0
-        for uid, it, sc in zip(rows["user"].tolist(), rows["item"].tolist(), rows["score"].tolist()):
+        w_all, w_in = 0.0, 0.0
+        for uid, it, sc, c in zip(rows["user"].tolist(), rows["item"].tolist(), rows["score"].tolist(), rows["cluster"].tolist()):
             items, scores, _ = ranking[uid]
             want = float(scores[np.flatnonzero(items == it)[0]])
             rel = abs(sc - want) / abs(want)
-            w = max(w, rel)
-        return w
+            w_all = max(w_all, rel)
+            if col[c][it] < 256 and abs(want) < 1.9 * np.sqrt(n_of_user[uid]):      # (inside the pass's criterion with a margin)
+                w_in = max(w_in, rel)
+        return w_all, w_in
     out = {}
     for flag in ("0", "1"):
         monkeypatch.setenv("FY_REFINE", flag)
@@ -412,9 +428,9 @@ def test_refinement_of_rows_that_nearly_cancel(monkeypatch):
         rec = P.RM2Job(conf, ctx).run((u, i, s), clustering=clustering)
         rows, st = rec.rows(), rec.stats
         assert_topn_matches(rows, ref, 30, atol=ATOL)
-        out[flag] = (worst_of(rows), st["rows_refined"])
+        out[flag] = worst_of(rows) + (st["rows_refined"],)
         ctx.close()
-    print("24-bit matrix forced, scores that cross zero: worst relative error without / with the refinement pass: %.2e / %.2e (%d rows re-scored)"
-          % (out["0"][0], out["1"][0], out["1"][1]))
-    assert out["0"][1] == 0 and out["1"][1] > 0
-    assert out["1"][0] <= out["0"][0] and out["1"][0] <= 1e-5
+    print("24-bit matrix forced, scores that cross zero: worst relative error over the rows inside the criterion without / with the refinement pass: "
+          "%.2e / %.2e (all rows: %.2e / %.2e; %d rows re-scored)" % (out["0"][1], out["1"][1], out["0"][0], out["1"][0], out["1"][2]))
+    assert out["0"][2] == 0 and out["1"][2] > 0
+    assert out["1"][1] <= 2e-6 and out["1"][1] < out["0"][1]
