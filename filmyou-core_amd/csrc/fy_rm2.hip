@@ -61,10 +61,11 @@ __device__ __forceinline__ void fy_pair_entry(const PairPass& A, int32_t q, Pair
     const int32_t slot = A.csc_slot[q];
     const double r = (double)A.csc_r[q];
     if (slot >= A.lo && slot < A.hi) a.ps += r;
-    const double s = A.usum_slot[slot];
-    a.b += r / s;
+    const double inv = 1.0 / A.usum_slot[slot];      // ONE fp64 division per entry (round 4: r / s and r / (s * s) were two; the heavy-column
+    const double x = r * inv;                         // kernel ran with 40 spilled VGPRs around them)
+    a.b += x;
     a.w += A.deg_slot[slot];
-    const double wt = r / (s * s);
+    const double wt = x * inv;
     a.ws += wt;
     a.wm = fmaxf(a.wm, (float)wt);
     a.rm = fmaxf(a.rm, (float)r);
@@ -629,13 +630,14 @@ struct MEpilogue {
     // written per row, the rows are `pitch` elements apart (0: the pitch is the row length) and the 24-bit rounding goes up
     int64_t pitch;
     int ceil24;
-    // fp32 copies of the rows the refinement pass reads (k_refine_rows, round 4): the first head_rows rows of the matrix, whole, at
+    // UNROUNDED fp64 copies of the rows the refinement pass reads (k_refine_rows, round 4; the fixed-point sums are exact, so these are
+    // the matrix elements to 2^-53): the first head_rows rows of the matrix, whole, at
     // pitch ld_head (symmetric walks: only the columns behind the row are meaningful), and -- symmetric panel mode, whose head rows
     // are not walked over the tail rows' columns -- the first 256 columns of every row from tail_from on.  nullptr = off.
-    float* __restrict__ head32;
+    double* __restrict__ head32;      // (fp64 since the first measurement: fp32 values left 4e-5 on a forced-small row with |score| = 0.15)
     int64_t ld_head;
     int32_t head_rows;
-    float* __restrict__ tail32;
+    double* __restrict__ tail32;
     int32_t tail_from;
 };
 
@@ -665,21 +667,26 @@ __device__ __forceinline__ void cooc_rm2_epilogue(const CoocArgs& A, const MEpil
             const int qz = A.acc_quarter;
             ACC* ap = acc + (qz ? c4 - (c0 >> 2) : 4 * c4 - c0);
             const int qs = qz ? qz : 1;                       // stride between the four columns of the lane
-            float f4[4];
+            double f4[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 float f;                                      // columns >= Ic were never touched: 0
-                if constexpr (std::is_integral<ACC>::value) f = (float)((double)ap[q * qs] * E.fx_inv);
-                else f = E.w2 * (float)ap[q * qs];
+                if constexpr (std::is_integral<ACC>::value) { f4[q] = (double)ap[q * qs] * E.fx_inv; f = (float)f4[q]; }
+                else { f = E.w2 * (float)ap[q * qs]; f4[q] = (double)E.w2 * (double)ap[q * qs]; }
                 ap[q * qs] = (ACC)0;
-                f4[q] = f;
                 v[q] = (__float_as_uint(f) + radd) >> FY_P24_SHIFT;    // 0 <= f < 2: 7 exponent + 17 mantissa bits, round to nearest (or up)
             }
             // the unrounded fp32 values of the rows / columns the refinement pass re-scores ill-conditioned list rows from
-            if (E.head32 && mrow < E.head_rows && 4 * c4 < E.ld_head)
-                *reinterpret_cast<float4*>(E.head32 + (int64_t)mrow * E.ld_head + 4 * c4) = make_float4(f4[0], f4[1], f4[2], f4[3]);
-            if (E.tail32 && row >= E.tail_from && 4 * c4 < 256)
-                *reinterpret_cast<float4*>(E.tail32 + (int64_t)(row - E.tail_from) * 256 + 4 * c4) = make_float4(f4[0], f4[1], f4[2], f4[3]);
+            if (E.head32 && mrow < E.head_rows && 4 * c4 < E.ld_head) {
+                double2* hp = reinterpret_cast<double2*>(E.head32 + (int64_t)mrow * E.ld_head + 4 * c4);
+                hp[0] = make_double2(f4[0], f4[1]);
+                hp[1] = make_double2(f4[2], f4[3]);
+            }
+            if (E.tail32 && row >= E.tail_from && 4 * c4 < 256) {
+                double2* tp = reinterpret_cast<double2*>(E.tail32 + (int64_t)(row - E.tail_from) * 256 + 4 * c4);
+                tp[0] = make_double2(f4[0], f4[1]);
+                tp[1] = make_double2(f4[2], f4[3]);
+            }
             if (!E.panel_cols || 4 * c4 < E.panel_cols) {
                 out3[3 * c4 + 0] = v[0] | (v[1] << 24);
                 out3[3 * c4 + 1] = (v[1] >> 8) | (v[2] << 16);
@@ -2062,7 +2069,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             DevBuf<int32_t> n_heavy;       // k_count_heavy
             DevBuf<int32_t> need;          // lazy mirror: column blocks with survivors
             DevBuf<float> Bsup, asup, bsupb, UBs;      // super-block bounds (k_score_sup)
-            DevBuf<float> head32, tail32;              // fp32 rows / columns the refinement pass reads (k_refine_rows)
+            DevBuf<double> head32, tail32;             // unrounded fp64 rows / columns the refinement pass reads (k_refine_rows)
             DevBuf<int32_t> colmap;
             DevBuf<int32_t> sup_first;
             DevBuf<int32_t> n_quads, quad_prefix;
@@ -2341,7 +2348,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
         struct PanelBuf {
             DevBuf<float> Gp, Bmax64, amax64, bmax64;
             DevBuf<uint32_t> Brep;
-            DevBuf<float> head32, tail32;      // (refinement pass: per cluster, like the panels -- built in phase 1, read in phase 3)
+            DevBuf<double> head32, tail32;     // (refinement pass: per cluster, like the panels -- built in phase 1, read in phase 3)
         };
         struct PanelPtrs {
             float *Gp, *Bmax64;
@@ -2498,8 +2505,8 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             const bool refine = tune.refine && pack24 && !p.coop && fxk >= 0 && J->S->max_item >= 0 && J->S->max_item < (1 << 28);
             const int32_t head_rows = std::min<int32_t>(256, Ic);
             const int64_t ld_head = p.psym ? (int64_t)p.p_eff : ldm;
-            DevBuf<float>& H32 = (two_phase && p.panel) ? pbuf[pi].head32 : L.head32;
-            DevBuf<float>& T32 = (two_phase && p.panel) ? pbuf[pi].tail32 : L.tail32;
+            DevBuf<double>& H32 = (two_phase && p.panel) ? pbuf[pi].head32 : L.head32;
+            DevBuf<double>& T32 = (two_phase && p.panel) ? pbuf[pi].tail32 : L.tail32;
             if (refine && do_build) {
                 H32.alloc(ctx, (size_t)head_rows * ld_head + 4);
                 if (p.psym) T32.alloc(ctx, (size_t)std::max(1, Ic - p.p_eff) * 256 + 4);

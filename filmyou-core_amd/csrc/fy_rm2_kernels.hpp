@@ -1653,8 +1653,8 @@ __global__ __launch_bounds__(256) void k_bound_select(const float* __restrict__ 
 // multi-cluster job) the absolute error of the production arithmetic -- 17 mantissa bits per matrix element -- is a RELATIVE error of
 // the same size: the one row that carried the all-rows maximum against the fp64 definition (6.3e-6 of north_star's 1e-5) was such a
 // row.  After a cluster's lists stand, every list row with |score| < refine_c * sqrt(n) whose item lies in the first 256 columns (the
-// popular candidates: where list items are) is scored AGAIN in fp64 from the unrounded fp32 matrix values the row kernel's epilogue
-// kept for exactly those columns (MEpilogue::head32 / tail32) and the fp64 statistics (p, b, s_u):
+// popular candidates: where list items are) is scored AGAIN in fp64 from the UNROUNDED matrix values the row kernel's epilogue kept for
+// exactly those columns (MEpilogue::head32 / tail32: fp64 images of the exact fixed-point sums) and the fp64 statistics (p, b, s_u):
 //     G(j, c) = head32[min(j, c)][max(j, c)]        (row min(j, c) < 256 walked column max(j, c): G is symmetric)
 //             = tail32[j - tail_from][c]            symmetric panel mode, j a tail row (its walk covered the head columns)
 // and the user's list is put back in order (a re-scored row moves by ~1e-6 of its value).  n gathers and n fp64 logs per row.
@@ -1677,9 +1677,9 @@ struct RefineArgs {
     const double* __restrict__ b_rank;
     const int32_t* __restrict__ colmap;      // raw item id -> column (< n_cols) or -1
     int32_t max_item;
-    const float* __restrict__ head32;
+    const double* __restrict__ head32;
     int64_t ld_head;
-    const float* __restrict__ tail32;
+    const double* __restrict__ tail32;
     int32_t tail_from;
     double unscale;                          // 1 / (the 2^-c the stored matrix is scaled by)
     double lambda, ln_items, ln_users;       // ln(numberOfItems), ln(U_c)
@@ -1722,12 +1722,12 @@ __global__ __launch_bounds__(256) void k_refine_rows(RefineArgs A) {
             for (int k = lane; k < n; k += 64) {
                 const int j = A.csr_idx[beg + k];
                 const double x = (double)A.csr_r[beg + k] / su;
-                float g32;
+                double g32;
                 if (A.tail32 && j >= A.tail_from) g32 = A.tail32[(int64_t)(j - A.tail_from) * 256 + c];
                 else g32 = A.head32[(int64_t)min(j, c) * A.ld_head + max(j, c)];
                 const double pj = A.p_rank[j];
                 const double e = (1.0 - l) * (A.b_rank[j] - x) + l * A.users_minus_1 * pj;
-                const double term = (double)g32 * A.unscale + l * (1.0 - l) * pj * bc + l * pc * e;
+                const double term = g32 * A.unscale + l * (1.0 - l) * pj * bc + l * pc * e;
                 sum += log(term);
             }
             for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
