@@ -682,8 +682,8 @@ __device__ __forceinline__ void cooc_rm2_epilogue(const CoocArgs& A, const MEpil
                 hp[0] = make_double2(f4[0], f4[1]);
                 hp[1] = make_double2(f4[2], f4[3]);
             }
-            if (E.tail32 && row >= E.tail_from && 4 * c4 < 256) {
-                double2* tp = reinterpret_cast<double2*>(E.tail32 + (int64_t)(row - E.tail_from) * 256 + 4 * c4);
+            if (E.tail32 && row >= E.tail_from && 4 * c4 < E.head_rows) {
+                double2* tp = reinterpret_cast<double2*>(E.tail32 + (int64_t)(row - E.tail_from) * E.head_rows + 4 * c4);
                 tp[0] = make_double2(f4[0], f4[1]);
                 tp[1] = make_double2(f4[2], f4[3]);
             }
@@ -2502,14 +2502,15 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             if (p.panel) ME.M = PP.Gp;
             // refinement (k_refine_rows): packed clusters keep the unrounded fp32 values of their first 256 rows (and, in symmetric panel
             // mode, of the first 256 columns of the tail rows)
-            const bool refine = tune.refine && pack24 && !p.coop && fxk >= 0 && J->S->max_item >= 0 && J->S->max_item < (1 << 28);
-            const int32_t head_rows = std::min<int32_t>(256, Ic);
+            const bool refine = tune.refine && pack24 && !p.coop && fxk >= 0 && J->S->max_item >= 0 && J->S->max_item < (1 << 28) && Ic >= 8;
+            // (as many head rows / columns as the seed is wide, 256 .. 1024: N = 50 -> 256, N = 100 -> 512; a multiple of 4)
+            const int32_t head_rows = (int32_t)std::min<int64_t>(Ic & ~3, std::max<int64_t>(256, std::min<int64_t>(1024, (int64_t)tune.seed_chunks * 256)));
             const int64_t ld_head = p.psym ? (int64_t)p.p_eff : ldm;
             DevBuf<double>& H32 = (two_phase && p.panel) ? pbuf[pi].head32 : L.head32;
             DevBuf<double>& T32 = (two_phase && p.panel) ? pbuf[pi].tail32 : L.tail32;
             if (refine && do_build) {
                 H32.alloc(ctx, (size_t)head_rows * ld_head + 4);
-                if (p.psym) T32.alloc(ctx, (size_t)std::max(1, Ic - p.p_eff) * 256 + 4);
+                if (p.psym) T32.alloc(ctx, (size_t)std::max(1, Ic - p.p_eff) * head_rows + 4);
                 ME.head32 = H32.get();
                 ME.ld_head = ld_head;
                 ME.head_rows = head_rows;
@@ -2640,7 +2641,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 const int32_t n_ids = J->S->max_item + 1;
                 L.colmap.alloc(ctx, (size_t)n_ids);
                 FY_HIP(hipMemsetAsync(L.colmap.get(), 0xFF, (size_t)n_ids * sizeof(int32_t), ls));
-                k_refine_colmap<<<1, 256, 0, ls>>>(head_rows, P.rank_item_raw.get() + pbase, L.colmap.get());
+                k_refine_colmap<<<(head_rows + 255) / 256, 256, 0, ls>>>(head_rows, P.rank_item_raw.get() + pbase, L.colmap.get());
                 FY_KERNEL_CHECK();
                 RefineArgs RA{};
                 RA.slot0 = s0; RA.n_users = nb; RA.slot_lo = lo; RA.slot_base = sbase;
@@ -2648,6 +2649,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 RA.rowptr = P.rowptr.get(); RA.csr_idx = P.csr_idx.get(); RA.csr_r = P.csr_r.get(); RA.usum_slot = J->usum_slot.get();
                 RA.p_rank = p_rank.get() + pbase; RA.b_rank = b_rank.get() + pbase;
                 RA.colmap = L.colmap.get(); RA.max_item = J->S->max_item;
+                RA.head_rows = head_rows;
                 RA.head32 = H32.get(); RA.ld_head = ld_head; RA.tail32 = p.psym ? T32.get() : nullptr; RA.tail_from = p.p_eff;
                 if (!RA.head32 || (p.psym && !RA.tail32)) FY_FAIL(FY_ERR_STATE, "internal: cluster %d has no fp32 rows for the refinement pass", c);
                 RA.unscale = 1.0 / (double)h_gscale[(size_t)c];

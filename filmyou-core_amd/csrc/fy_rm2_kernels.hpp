@@ -1680,7 +1680,7 @@ struct RefineArgs {
     const double* __restrict__ head32;
     int64_t ld_head;
     const double* __restrict__ tail32;
-    int32_t tail_from;
+    int32_t tail_from, head_rows;            // head_rows: rows of head32 = columns of tail32 = columns the pass covers
     double unscale;                          // 1 / (the 2^-c the stored matrix is scaled by)
     double lambda, ln_items, ln_users;       // ln(numberOfItems), ln(U_c)
     double users_minus_1;
@@ -1723,7 +1723,7 @@ __global__ __launch_bounds__(256) void k_refine_rows(RefineArgs A) {
                 const int j = A.csr_idx[beg + k];
                 const double x = (double)A.csr_r[beg + k] / su;
                 double g32;
-                if (A.tail32 && j >= A.tail_from) g32 = A.tail32[(int64_t)(j - A.tail_from) * 256 + c];
+                if (A.tail32 && j >= A.tail_from) g32 = A.tail32[(int64_t)(j - A.tail_from) * A.head_rows + c];
                 else g32 = A.head32[(int64_t)min(j, c) * A.ld_head + max(j, c)];
                 const double pj = A.p_rank[j];
                 const double e = (1.0 - l) * (A.b_rank[j] - x) + l * A.users_minus_1 * pj;
