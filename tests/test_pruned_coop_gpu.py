@@ -440,5 +440,6 @@ def test_refinement_of_rows_that_nearly_cancel(monkeypatch):
     assert out["0"][3] == 0 and out["1"][3] > 0
     # what is left in a re-scored row is the fp32 rounding of the walk's WEIGHTS (x_vi / s_v enters the fixed-point sums as an fp32
     # product with the rating): ~3e-8 per term relative -- measured 2.8e-8 absolute on a score of 0.0015 made of 26 terms of ~4
-    assert out["1"][1] <= 3e-7 and out["1"][1] < 0.1 * out["0"][1]
+    # (and grows with the list length like everything else: ~1e-6 absolute on a 300-rating user's score of 1)
+    assert out["1"][1] <= 2e-6 and out["1"][1] < 0.1 * out["0"][1]
     assert out["1"][2] <= 2e-6
