@@ -643,20 +643,12 @@ struct MEpilogue {
 
 // Epilogue of one (row, chunk) item of the RM2 row kernel: G[i][chunk] = w2 * acc -> 24-bit pack (or fp32), the block maxima, and the
 // accumulators re-zeroed in the same pass.  All threads of the workgroup; `id` = (row of the launch << 8) | chunk.
-template <class ACC>
-__device__ __forceinline__ void cooc_rm2_epilogue(const CoocArgs& A, const MEpilogue& E, ACC* __restrict__ acc, int id) {
-    const int lrow = id >> 8;
-    const int row = A.row0 + lrow * (A.row_stride ? A.row_stride : 1);
-    const int mrow = E.local_rows ? lrow : row;
-    const int ch = id & 255;
-    const int c0 = ch * A.CH;
-    // the last chunk also writes the padding columns [Ic, ldm) so the scoring kernel may load whole 256-wide chunks
-    const int c1 = (ch == A.nch - 1) ? (int)E.ldm : min(c0 + A.CH, (int)E.ldm);
-    // symmetric walk: in the row's own chunk nothing in front of its 256-column diagonal block was accumulated (and the
-    // mirror pass writes that part of the row); the block maxima of the diagonal block are the mirror pass's too
-    const int cb = (cooc_row_is_cut(A, row) && c0 <= row) ? (row & ~255) : c0;
-    const int first_bmax_block = A.half ? (row >> 8) + 1 : 0;
-    if (E.pack24) {
+// the 24-bit branch of the epilogue; COPY: this item also stores the unrounded fp64 images of its values for the refinement pass
+// (MEpilogue::head32 / tail32) -- a separate instantiation, so that the items that do not (all but the first few hundred rows) run
+// the code of round 3 (with the stores in the one loop the row kernel took 8.3 instead of 8.1 ms)
+template <class ACC, bool COPY>
+__device__ __forceinline__ void cooc_rm2_epilogue_pack(const CoocArgs& A, const MEpilogue& E, ACC* __restrict__ acc, int row, int mrow, int c0, int c1, int cb,
+                                                       int first_bmax_block) {
         // four columns -> three dwords (c0 and c1 are multiples of 64)
         const int64_t row_cols = E.pitch ? E.pitch : (E.panel_cols ? E.panel_cols : E.ldm);
         const uint32_t radd = E.ceil24 ? (1u << FY_P24_SHIFT) - 1u : 1u << (FY_P24_SHIFT - 1);
@@ -667,16 +659,17 @@ __device__ __forceinline__ void cooc_rm2_epilogue(const CoocArgs& A, const MEpil
             const int qz = A.acc_quarter;
             ACC* ap = acc + (qz ? c4 - (c0 >> 2) : 4 * c4 - c0);
             const int qs = qz ? qz : 1;                       // stride between the four columns of the lane
-            double f4[4];
+            double f4[COPY ? 4 : 1];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 float f;                                      // columns >= Ic were never touched: 0
-                if constexpr (std::is_integral<ACC>::value) { f4[q] = (double)ap[q * qs] * E.fx_inv; f = (float)f4[q]; }
-                else { f = E.w2 * (float)ap[q * qs]; f4[q] = (double)E.w2 * (double)ap[q * qs]; }
+                if constexpr (std::is_integral<ACC>::value) { const double d = (double)ap[q * qs] * E.fx_inv; f = (float)d; if constexpr (COPY) f4[q] = d; }
+                else { f = E.w2 * (float)ap[q * qs]; if constexpr (COPY) f4[q] = (double)E.w2 * (double)ap[q * qs]; }
                 ap[q * qs] = (ACC)0;
                 v[q] = (__float_as_uint(f) + radd) >> FY_P24_SHIFT;    // 0 <= f < 2: 7 exponent + 17 mantissa bits, round to nearest (or up)
             }
-            // the unrounded fp32 values of the rows / columns the refinement pass re-scores ill-conditioned list rows from
+            // the unrounded values (fp64 images of the fixed-point sums) the refinement pass re-scores ill-conditioned list rows from
+            if constexpr (COPY) {
             if (E.head32 && mrow < E.head_rows && 4 * c4 < E.ld_head) {
                 double2* hp = reinterpret_cast<double2*>(E.head32 + (int64_t)mrow * E.ld_head + 4 * c4);
                 hp[0] = make_double2(f4[0], f4[1]);
@@ -686,6 +679,7 @@ __device__ __forceinline__ void cooc_rm2_epilogue(const CoocArgs& A, const MEpil
                 double2* tp = reinterpret_cast<double2*>(E.tail32 + (int64_t)(row - E.tail_from) * E.head_rows + 4 * c4);
                 tp[0] = make_double2(f4[0], f4[1]);
                 tp[1] = make_double2(f4[2], f4[3]);
+            }
             }
             if (!E.panel_cols || 4 * c4 < E.panel_cols) {
                 out3[3 * c4 + 0] = v[0] | (v[1] << 24);
@@ -738,6 +732,26 @@ __device__ __forceinline__ void cooc_rm2_epilogue(const CoocArgs& A, const MEpil
                 }
             }
         }
+}
+
+template <class ACC>
+__device__ __forceinline__ void cooc_rm2_epilogue(const CoocArgs& A, const MEpilogue& E, ACC* __restrict__ acc, int id) {
+    const int lrow = id >> 8;
+    const int row = A.row0 + lrow * (A.row_stride ? A.row_stride : 1);
+    const int mrow = E.local_rows ? lrow : row;
+    const int ch = id & 255;
+    const int c0 = ch * A.CH;
+    // the last chunk also writes the padding columns [Ic, ldm) so the scoring kernel may load whole 256-wide chunks
+    const int c1 = (ch == A.nch - 1) ? (int)E.ldm : min(c0 + A.CH, (int)E.ldm);
+    // symmetric walk: in the row's own chunk nothing in front of its 256-column diagonal block was accumulated (and the
+    // mirror pass writes that part of the row); the block maxima of the diagonal block are the mirror pass's too
+    const int cb = (cooc_row_is_cut(A, row) && c0 <= row) ? (row & ~255) : c0;
+    const int first_bmax_block = A.half ? (row >> 8) + 1 : 0;
+    if (E.pack24) {
+        // (block-uniform) does this item hold values the refinement pass wants?
+        const bool copy = E.head32 && (mrow < E.head_rows || (E.tail32 && row >= E.tail_from && c0 < E.head_rows));
+        if (copy) cooc_rm2_epilogue_pack<ACC, true>(A, E, acc, row, mrow, c0, c1, cb, first_bmax_block);
+        else cooc_rm2_epilogue_pack<ACC, false>(A, E, acc, row, mrow, c0, c1, cb, first_bmax_block);
     } else {
         float* __restrict__ out = E.M + (int64_t)mrow * E.ldm;
         for (int col = cb + threadIdx.x; col < c1; col += blockDim.x) {
