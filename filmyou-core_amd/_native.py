@@ -21,7 +21,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
 SYMBOLS = [
     "fy_abi_version", "fy_last_error", "fy_context_create", "fy_context_destroy", "fy_context_synchronize", "fy_context_reload_tuning", "fy_context_inject_alloc_failure",
     "fy_context_stream", "fy_ratings_create", "fy_ratings_destroy", "fy_ratings_nnz", "fy_ratings_drop_cache", "fy_rm2_prepare",
-    "fy_rm2_partial_stats", "fy_rm2_set_global_stats", "fy_rm2_set_collectives", "fy_rccl_unique_id", "fy_rccl_create", "fy_rccl_collectives", "fy_rccl_counters", "fy_rccl_destroy", "fy_rccl_detach_context", "fy_rm2_score", "fy_rm2_job_destroy", "fy_rm2_run",
+    "fy_rm2_partial_stats", "fy_rm2_stats_layout", "fy_rm2_set_global_stats", "fy_rm2_set_collectives", "fy_rccl_unique_id", "fy_rccl_create", "fy_rccl_collectives", "fy_rccl_counters", "fy_rccl_destroy", "fy_rccl_detach_context", "fy_rm2_score", "fy_rm2_job_destroy", "fy_rm2_run",
     "fy_itemsim_build", "fy_itemsim_run", "fy_itemcf_recommend", "fy_cluster_assign", "fy_nmf_factorize", "fy_result_size", "fy_result_key0", "fy_result_key1", "fy_result_value",
     "fy_result_aux", "fy_result_n_users", "fy_result_user_id", "fy_result_user_sum", "fy_result_n_items",
     "fy_result_item_id", "fy_result_item_coll", "fy_result_total_sum", "fy_result_free", "fy_result_stats",
@@ -192,6 +192,7 @@ def load():
     L.fy_rm2_prepare.argtypes = [vp, C.POINTER(RM2Params), vp, i64, vp, vp, vp, pvp]
     L.fy_rm2_partial_stats.argtypes = [vp, pvp, C.POINTER(i64)]
     L.fy_rm2_set_global_stats.argtypes = [vp, vp, i32]
+    L.fy_rm2_stats_layout.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
     L.fy_nmf_factorize.argtypes = [vp, C.POINTER(NMFParams), vp, vp, vp, C.POINTER(Stats)]
     L.fy_cluster_assign.argtypes = [vp, i32, i32, vp, C.c_int, i32, i32, i32, vp, vp, vp]
     L.fy_rm2_set_collectives.argtypes = [vp, C.POINTER(Collectives)]

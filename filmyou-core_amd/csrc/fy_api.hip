@@ -32,6 +32,7 @@ void fy::load_tuning_from_env(Tuning& t) {
     if (const char* e = getenv("FY_REFINE")) t.refine = atoi(e) != 0;
     if (const char* e = getenv("FY_REFINE_C")) { double v = atof(e); if (v >= 0.0 && v < 1e6) t.refine_c = (float)v; }
     if (const char* e = getenv("FY_FULL_WALK_SPARSE")) t.full_walk_sparse = atoi(e) != 0;
+    if (const char* e = getenv("FY_SHARD_PREP")) t.shard_prep = atoi(e) != 0;
     if (const char* e = getenv("FY_SUP_BOUNDS")) t.sup_bounds = atoi(e) != 0;
     if (const char* e = getenv("FY_COOP")) t.coop = atoi(e) != 0;
     if (const char* e = getenv("FY_COOP_FORCE")) t.coop_force = atoi(e) != 0;
@@ -217,6 +218,13 @@ int fy_rm2_partial_stats(fy_rm2_job* j, double** device_buf, int64_t* len) {
     if (!j || !device_buf || !len) { set_error("NULL argument"); return FY_ERR_INVALID_ARGUMENT; }
     FY_TRY
     fy::rm2_partial_stats(j, device_buf, len);
+    FY_CATCH
+}
+
+int fy_rm2_stats_layout(fy_rm2_job* j, int64_t* n_item_slots, int64_t* n_user_slots) {
+    if (!j || !n_item_slots || !n_user_slots) { set_error("NULL argument"); return FY_ERR_INVALID_ARGUMENT; }
+    FY_TRY
+    fy::rm2_stats_layout(j, n_item_slots, n_user_slots);
     FY_CATCH
 }
 

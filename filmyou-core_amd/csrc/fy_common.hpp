@@ -68,6 +68,7 @@ struct Tuning {
                                        // column chunks instead of four, 19.7 -> 17.8 ms; smaller forces more chunks)
     bool cooc_max_ch_forced = false;   // FY_COOC_MAX_CH given (the item-similarity build has its own default)
     int sup_bounds = 1;                // FY_SUP_BOUNDS: one-cluster pruned jobs bound over <= 64 super-blocks inside the seed pass (0: a bound chunk per user over all blocks)
+    int shard_prep = 1;                // FY_SHARD_PREP: several ranks, clusters >= ranks: a rank preps its own clusters' ratings alone (fy_prep.hpp)
     int full_walk_sparse = 1;          // FY_FULL_WALK_SPARSE: unpruned clusters whose matrix has more elements than the cluster has pair visits walk full rows (no mirror pass)
     int refine = 1;                    // FY_REFINE: list rows whose score nearly cancels are scored again in fp64 from fp32 head rows (k_refine_rows)
     float refine_c = 2.0f;             // FY_REFINE_C: ... those with |score| < refine_c * sqrt(ratings of the user)

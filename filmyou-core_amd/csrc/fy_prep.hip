@@ -96,7 +96,12 @@ __global__ void k_max_ids(int64_t n, const int32_t* __restrict__ user, const int
         mu = max(mu, __shfl_down(mu, o, 64));
         mi = max(mi, __shfl_down(mi, o, 64));
     }
-    if ((threadIdx.x & 63) == 0) {
+    // one pair of atomics per workgroup (thousands of waves on one address serialise in the L2: ~5 ns each)
+    __shared__ int32_t sh[2][16];
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = mu; sh[1][threadIdx.x >> 6] = mi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); w++) { mu = max(mu, sh[0][w]); mi = max(mi, sh[1][w]); }
         if (mu >= 0) atomicMax(&max_ids[0], mu);
         if (mi >= 0) atomicMax(&max_ids[1], mi);
     }
@@ -130,13 +135,23 @@ __global__ void k_user_item_keys(int64_t n, const int32_t* __restrict__ user, co
         }
         keys[t] = k;
     }
-    // wave reduce then one atomic per wave
-    for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o, 64);
-    if ((threadIdx.x & 63) == 0 && local) atomicAdd(kept, local);
-    if (__ballot(not_half) && (threadIdx.x & 63) == 0) atomicOr(err, NOTE_NOT_FP16);
-    if (__ballot(not_pos) && (threadIdx.x & 63) == 0) atomicOr(err, NOTE_NONPOSITIVE);
-    for (int o = 32; o > 0; o >>= 1) frac |= (unsigned)__shfl_down((int)frac, o, 64);
-    if ((threadIdx.x & 63) == 0 && frac) atomicOr(err, (int)frac);
+    // wave reduce, workgroup reduce, then ONE atomic per counter and workgroup (round 4: an atomic per wave -- 16 384 waves x 4 atomics
+    // on two addresses -- was what this kernel took its 0.25 ms for, whatever the number of ratings)
+    if (not_half) frac |= NOTE_NOT_FP16;
+    if (not_pos) frac |= NOTE_NONPOSITIVE;
+    for (int o = 32; o > 0; o >>= 1) {
+        local += __shfl_down(local, o, 64);
+        frac |= (unsigned)__shfl_down((int)frac, o, 64);
+    }
+    __shared__ unsigned long long sh_local[16];
+    __shared__ unsigned sh_frac[16];
+    if ((threadIdx.x & 63) == 0) { sh_local[threadIdx.x >> 6] = local; sh_frac[threadIdx.x >> 6] = frac; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); w++) { local += sh_local[w]; frac |= sh_frac[w]; }
+        if (local) atomicAdd(kept, local);
+        if (frac) atomicOr(err, (int)frac);
+    }
 }
 
 __global__ void k_heads_hi32(int64_t n, const uint64_t* __restrict__ keys, uint32_t* __restrict__ head, int check_dup,
@@ -208,6 +223,16 @@ __global__ void k_lookup_cluster(int32_t nU, const int32_t* __restrict__ uid, in
     }
 }
 
+// the same from a table indexed by raw user id (dense ids: no sort of the map, no search)
+__global__ void k_lookup_cluster_table(int32_t nU, const int32_t* __restrict__ uid, const int32_t* __restrict__ cl_of_raw, int32_t K,
+                                       int32_t* __restrict__ ucluster, int* __restrict__ err) {
+    for (int32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < nU; u += gridDim.x * blockDim.x) {
+        int32_t c = cl_of_raw[uid[u]];
+        if (c < 0 || c >= K) { atomicOr(err, ERR_CLUSTER_RANGE); c = 0; }
+        ucluster[u] = c;
+    }
+}
+
 __global__ void k_slot_keys(int32_t nU, const int32_t* __restrict__ ucluster, const int32_t* __restrict__ udeg,
                             uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, int32_t* __restrict__ csize) {
     for (int32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < nU; u += gridDim.x * blockDim.x) {
@@ -223,6 +248,24 @@ __global__ void k_slot_keys(int32_t nU, const int32_t* __restrict__ ucluster, co
             atomicAdd(&csize[c], 1);
         }
     }
+}
+// the same with the cluster sizes counted in LDS first (K <= SLOT_KEYS_LDS clusters: 50 clusters took one global atomic per user
+// on 50 addresses -- 86 us for the 20 000 users of a rank's share)
+constexpr int SLOT_KEYS_LDS = 4096;
+__global__ void k_slot_keys_lds(int32_t nU, int32_t K, const int32_t* __restrict__ ucluster, const int32_t* __restrict__ udeg,
+                                uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, int32_t* __restrict__ csize) {
+    __shared__ int32_t sh[SLOT_KEYS_LDS];
+    for (int c = threadIdx.x; c < K; c += blockDim.x) sh[c] = 0;
+    __syncthreads();
+    for (int32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < nU; u += gridDim.x * blockDim.x) {
+        const int c = ucluster[u];
+        keys[u] = ((uint64_t)(uint32_t)c << 32) | (0xFFFFFFFFu - (uint32_t)udeg[u]);
+        vals[u] = (uint32_t)u;
+        atomicAdd(&sh[c], 1);       // (k_lookup_cluster has put every user into [0, K))
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < K; c += blockDim.x)
+        if (sh[c]) atomicAdd(&csize[c], sh[c]);
 }
 
 __global__ void k_invert_perm(int32_t n, const uint32_t* __restrict__ perm, int32_t* __restrict__ fwd, int32_t* __restrict__ inv) {
@@ -430,8 +473,228 @@ void ratings_id_bounds(Context* ctx, fy_ratings* R) {
     R->max_item = h[1];
 }
 
+// ---------------------------------------------------------------- sharded prep: the owned clusters' ratings alone
+// (the reference partitions the ratings by cluster on the map side -- M/util/IntKeyPartitioner.java:15, RM2Job.java:130-133, 251 -- so a
+// reduce group only ever sorts its own cluster's ratings; a rank that sorted ALL ratings to score an eighth of the clusters did eight
+// times the reference's share of that work)
+
+// degree of every raw user over the kept ratings, which raw items are rated at all.  A wave adds a RUN of neighbours with one user
+// with one atomic (input grouped by user -- what a file or a Cassandra partition scan delivers -- would otherwise send 64 atomics of a wave
+// to one address: 1.1 ms at ML-25M shape; in any other order the atomics go to different addresses and do not queue).
+__global__ void k_shard_degrees(int64_t n, const int32_t* __restrict__ user, const int32_t* __restrict__ item, const float* __restrict__ score,
+                                int32_t* __restrict__ deg, int32_t* __restrict__ seen, int* __restrict__ err) {
+    const int lane = threadIdx.x & 63;
+    const int64_t n_up = (n + 63) & ~(int64_t)63;       // whole waves enter every round (ballot / shuffle below)
+    bool neg = false;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n_up; t += (int64_t)gridDim.x * blockDim.x) {
+        int32_t u = -1;
+        if (t < n && score[t] > 0.0f) {
+            u = user[t];
+            const int32_t i = item[t];
+            if (u < 0 || i < 0) { neg = true; u = -1; }
+            else if (!seen[i]) seen[i] = 1;
+        }
+        const int32_t before = __shfl_up(u, 1, 64);
+        const bool head = u >= 0 && (lane == 0 || before != u);
+        const bool breaks = lane == 0 || before != u;                 // a run ends in front of every lane whose user differs
+        const unsigned long long bm = __ballot(breaks);
+        if (head) {
+            const unsigned long long later = lane == 63 ? 0ull : (bm >> (lane + 1));
+            const int len = later ? __ffsll((long long)later) : 64 - lane;
+            atomicAdd(&deg[u], len);
+        }
+    }
+    if (__ballot(neg) && lane == 0) atomicOr(err, ERR_NEG_ID);
+}
+
+// per cluster: ratings, sum of n_u^2, rated users -- counted in LDS per workgroup, integer atomics (the same numbers on every rank);
+// own[u] is filled later (k_shard_owned)
+constexpr int SHARD_LDS_CLUSTERS = 2048;
+__global__ void k_shard_cluster_weights(int32_t n_raw_users, const int32_t* __restrict__ deg, const int32_t* __restrict__ cl_of_raw, int32_t K,
+                                        unsigned long long* __restrict__ w /* 3 K + 1 */, const int32_t* __restrict__ seen, int32_t n_raw_items,
+                                        int* __restrict__ err) {
+    __shared__ unsigned long long sh[3 * SHARD_LDS_CLUSTERS];
+    const bool lds = K <= SHARD_LDS_CLUSTERS;
+    if (lds) {
+        for (int c = threadIdx.x; c < 3 * K; c += blockDim.x) sh[c] = 0;
+        __syncthreads();
+    }
+    const int64_t t0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, step = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t u = t0; u < n_raw_users; u += step) {
+        const unsigned long long d = (unsigned long long)deg[u];
+        if (!d) continue;
+        int32_t c = cl_of_raw[u];
+        if (c < 0 || c >= K) { atomicOr(err, ERR_CLUSTER_RANGE); continue; }
+        unsigned long long* dst = lds ? sh : w;
+        atomicAdd(&dst[c], d);
+        atomicAdd(&dst[K + c], d * d);
+        atomicAdd(&dst[2 * K + c], 1ull);
+    }
+    unsigned long long items = 0;
+    for (int64_t i = t0; i < n_raw_items; i += step) items += seen[i] ? 1 : 0;
+    for (int o = 32; o > 0; o >>= 1) items += __shfl_down(items, o, 64);
+    if ((threadIdx.x & 63) == 0 && items) atomicAdd(&w[3 * K], items);
+    if (lds) {
+        __syncthreads();
+        for (int c = threadIdx.x; c < 3 * K; c += blockDim.x)
+            if (sh[c]) atomicAdd(&w[c], sh[c]);
+    }
+}
+
+// own[u] = 1: raw user u belongs to one of this rank's clusters
+__global__ void k_shard_owned(int32_t n_raw_users, const int32_t* __restrict__ cl_of_raw, const int32_t* __restrict__ owner, int32_t rank,
+                              uint8_t* __restrict__ own) {
+    for (int32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < n_raw_users; u += gridDim.x * blockDim.x) own[u] = owner[cl_of_raw[u]] == rank ? 1 : 0;
+}
+
+// The owned ratings, compacted in input order without a flag per rating: a wave's 64 keep-bits as one mask and one count (pass 1), an
+// exclusive scan of the 390 000 counts, and the kept entries written behind their wave's base (pass 2) -- 5 MB of bookkeeping
+// instead of 300 MB of flags and positions.
+__global__ void k_shard_masks(int64_t n, const int32_t* __restrict__ user, const float* __restrict__ score, const uint8_t* __restrict__ own,
+                              unsigned long long* __restrict__ mask, int32_t* __restrict__ count) {
+    const int64_t n_up = (n + 63) & ~(int64_t)63;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n_up; t += (int64_t)gridDim.x * blockDim.x) {
+        const bool keep = t < n && score[t] > 0.0f && own[user[t]];      // (ids were range-checked by k_shard_degrees)
+        const unsigned long long m = __ballot(keep);
+        if ((threadIdx.x & 63) == 0) { mask[t >> 6] = m; count[t >> 6] = (int32_t)__popcll(m); }
+    }
+}
+__global__ void k_shard_compact(int64_t n, const unsigned long long* __restrict__ mask, const int32_t* __restrict__ base, const int32_t* __restrict__ user,
+                                const int32_t* __restrict__ item, const float* __restrict__ score, int32_t* __restrict__ ou, int32_t* __restrict__ oi,
+                                float* __restrict__ os) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned long long m = mask[t >> 6];
+        if ((m >> lane) & 1ull) {
+            const int32_t p = base[t >> 6] + (int32_t)__popcll(m & ((1ull << lane) - 1ull));
+            ou[p] = user[t];
+            oi[p] = item[t];
+            os[p] = score[t];
+        }
+    }
+}
+
+// cuts `w` (one weight per position, in order) into `parts` contiguous runs with the smallest possible largest run (binary search on the
+// cap, greedy fill); returns the first position of every run (parts + 1 entries; trailing runs may be empty)
+static std::vector<int> linear_partition(const std::vector<int64_t>& w, int parts) {
+    const int n = (int)w.size();
+    auto runs_needed = [&](int64_t cap, std::vector<int>* first) -> int {
+        int runs = 1;
+        int64_t in_run = 0;
+        if (first) { first->clear(); first->push_back(0); }
+        for (int k = 0; k < n; k++) {
+            if (w[(size_t)k] > cap) return parts + 1;
+            if (in_run + w[(size_t)k] > cap && in_run > 0) { runs++; in_run = 0; if (first) first->push_back(k); }
+            in_run += w[(size_t)k];
+        }
+        return runs;
+    };
+    int64_t lo = 0, hi = 0;
+    for (int64_t x : w) hi += x;
+    while (lo < hi) {
+        const int64_t mid = lo + (hi - lo) / 2;
+        if (runs_needed(mid, nullptr) <= parts) hi = mid; else lo = mid + 1;
+    }
+    std::vector<int> first;
+    runs_needed(hi, &first);
+    while ((int)first.size() < parts + 1) first.push_back(n);
+    return first;
+}
+
+bool shard_ratings_by_cluster(Context* ctx, const fy_ratings* R, int32_t K, int64_t n_map, const int32_t* map_user, const int32_t* map_cluster,
+                              int rank, int world, fy_ratings& mine, std::vector<int32_t>& owner, DevBuf<int32_t>& d_cl) {
+    if (world <= 1 || K < world || R->nnz == 0 || R->max_user < 0 || R->max_item < 0) return false;
+    if (R->nnz >= (int64_t)0x7FFFFFF0) return false;          // (build_structure reports it)
+    const int64_t nRU = (int64_t)R->max_user + 1, nRI = (int64_t)R->max_item + 1;
+    if (nRU + nRI > ((int64_t)1 << 25)) return false;           // the exchange buffer is indexed by raw ids in this mode: 256 MB of doubles at most
+    // a cluster nobody of the map is routed to can only be cluster 0 (the users the map does not name): a quick host-side bound on the
+    // number of non-empty clusters before any device work
+    std::vector<int32_t> cl_of_raw((size_t)nRU, 0);
+    {
+        std::vector<char> named((size_t)K, 0);
+        int n_named = 1;        // cluster 0
+        named[0] = 1;
+        for (int64_t m = 0; m < n_map; m++) {
+            const int32_t u = map_user[m], c = map_cluster[m];
+            if (u < 0 || u >= nRU) continue;
+            cl_of_raw[(size_t)u] = c;                             // a later pair of the same user wins (successive TIntIntHashMap.put calls)
+            if (c >= 0 && c < K && !named[(size_t)c]) { named[(size_t)c] = 1; n_named++; }
+        }
+        if (n_named < world) return false;
+    }
+    hipStream_t st = ctx->stream;
+    SyncOnUnwind guard(st);
+    DevBuf<int32_t> deg(ctx, (size_t)nRU), seen(ctx, (size_t)nRI);
+    d_cl.alloc(ctx, (size_t)nRU);
+    DevBuf<unsigned long long> w(ctx, 3 * (size_t)K + 1);
+    DevBuf<int> err(ctx, 1);
+    h2d(ctx, d_cl.get(), cl_of_raw.data(), (size_t)nRU);
+    deg.zero();
+    seen.zero();
+    w.zero();
+    err.zero();
+    k_shard_degrees<<<grid_for(R->nnz), 256, 0, st>>>(R->nnz, R->user.get(), R->item.get(), R->score.get(), deg.get(), seen.get(), err.get());
+    FY_KERNEL_CHECK();
+    k_shard_cluster_weights<<<grid_for(std::max(nRU, nRI)), 256, 0, st>>>((int32_t)nRU, deg.get(), d_cl.get(), K, w.get(), seen.get(), (int32_t)nRI, err.get());
+    FY_KERNEL_CHECK();
+    std::vector<unsigned long long> hw(3 * (size_t)K + 1);
+    int h_err = 0;
+    d2h(ctx, hw.data(), w.get(), hw.size());
+    d2h(ctx, &h_err, err.get(), 1);
+    sync(ctx);
+    // (the failures every rank sees the same way are reported here, by every rank; the rank-local ones -- a duplicate rating, a
+    // clusteringCount mismatch inside an owned cluster -- travel with the statistics, fy_rm2.hip)
+    if (h_err & ERR_NEG_ID) FY_FAIL(FY_ERR_NEGATIVE_ID, "negative user or item id in the ratings");
+    if (h_err & ERR_CLUSTER_RANGE) FY_FAIL(FY_ERR_CLUSTER_RANGE, "a rated user is routed to a cluster outside [0, %d)", K);
+    std::vector<int32_t> ids;       // the non-empty clusters, ascending
+    std::vector<int64_t> weight;
+    const int64_t items_all = (int64_t)hw[3 * (size_t)K];
+    for (int c = 0; c < K; c++)
+        if (hw[2 * (size_t)K + c]) {
+            ids.push_back(c);
+            // what a whole cluster costs its rank: the co-rating pairs of the row kernel (sum of n_u^2) + the log terms of scoring, at
+            // most (ratings of the cluster) x (items anybody rated)
+            weight.push_back((int64_t)hw[(size_t)K + c] + (int64_t)hw[(size_t)c] * std::min<int64_t>(items_all, (int64_t)hw[(size_t)c]));
+        }
+    if ((int)ids.size() < world) return false;
+    const std::vector<int> first = linear_partition(weight, world);
+    owner.assign((size_t)K, -1);
+    for (int r = 0; r < world; r++)
+        for (int k = first[(size_t)r]; k < first[(size_t)r + 1]; k++) owner[(size_t)ids[(size_t)k]] = r;
+    for (int c = 0; c < K; c++)
+        if (owner[(size_t)c] < 0) owner[(size_t)c] = world;     // empty clusters: nobody's
+    DevBuf<int32_t> d_owner(ctx, (size_t)K);
+    h2d(ctx, d_owner.get(), owner.data(), (size_t)K);
+    DevBuf<uint8_t> own(ctx, (size_t)nRU);
+    k_shard_owned<<<grid_for(nRU), 256, 0, st>>>((int32_t)nRU, d_cl.get(), d_owner.get(), rank, own.get());
+    FY_KERNEL_CHECK();
+    const int64_t n_waves = ceil_div(R->nnz, 64);
+    DevBuf<unsigned long long> mask(ctx, (size_t)n_waves);
+    DevBuf<int32_t> count(ctx, (size_t)n_waves + 1), base(ctx, (size_t)n_waves + 1);
+    k_shard_masks<<<grid_for(R->nnz), 256, 0, st>>>(R->nnz, R->user.get(), R->score.get(), own.get(), mask.get(), count.get());
+    FY_KERNEL_CHECK();
+    k_set_i32<<<1, 1, 0, st>>>(count.get() + n_waves, 0);
+    FY_KERNEL_CHECK();
+    exclusive_scan_i32(ctx, count.get(), base.get(), (size_t)n_waves + 1);
+    const int64_t kept = (int64_t)fetch(ctx, base.get() + n_waves);
+    mine.ctx = ctx;
+    mine.nnz = kept;
+    mine.max_user = R->max_user;
+    mine.max_item = R->max_item;
+    mine.user.alloc(ctx, (size_t)kept);
+    mine.item.alloc(ctx, (size_t)kept);
+    mine.score.alloc(ctx, (size_t)kept);
+    if (kept) {
+        k_shard_compact<<<grid_for(R->nnz), 256, 0, st>>>(R->nnz, mask.get(), base.get(), R->user.get(), R->item.get(), R->score.get(), mine.user.get(),
+                                                          mine.item.get(), mine.score.get());
+        FY_KERNEL_CHECK();
+    }
+    sync(ctx);      // (the masks and the tables are released here)
+    return true;
+}
+
 void build_structure(Context* ctx, const fy_ratings* R, int32_t K, int64_t n_map, const int32_t* map_user,
-                     const int32_t* map_cluster, const int32_t* cluster_count, bool keep_nonpositive, Prepared& P) {
+                     const int32_t* map_cluster, const int32_t* cluster_count, bool keep_nonpositive, Prepared& P, const int32_t* cl_of_raw) {
     P.ctx = ctx;
     P.K = K;
     const int64_t n_in = R->nnz;
@@ -510,11 +773,30 @@ void build_structure(Context* ctx, const fy_ratings* R, int32_t K, int64_t n_map
 
     // ---- cluster routing
     P.ucluster.alloc(ctx, nU);
-    std::vector<uint64_t> hm((size_t)std::max<int64_t>(0, n_map));      // (host sources of two uploads: they live until the next synchronisation, below)
-    std::vector<uint32_t> hv((size_t)std::max<int64_t>(0, n_map));
-    SyncOnUnwind hm_hv_guard(st);      // an allocation or a sort below may throw while the two uploads are still queued
-    {
+    std::vector<uint64_t> hm;      // (host sources of two uploads: they live until the next synchronisation, below)
+    std::vector<uint32_t> hv;
+    std::vector<int32_t> h_table;
+    SyncOnUnwind hm_hv_guard(st);      // an allocation or a sort below may throw while the uploads are still queued
+    // Dense user ids (the table is at most a few times the map): cluster by raw id from a table -- filled on the host in file order (a later
+    // pair of one user wins, like successive TIntIntHashMap.put calls; users the map does not name stay in cluster 0), one upload, no
+    // sort.  The sharded prep hands its table over.
+    DevBuf<int32_t> d_table_own;
+    const int64_t nRU = (int64_t)R->max_user + 1;
+    if (!cl_of_raw && n_map > 0 && nRU <= 8 * n_map + (1 << 20)) {
+        h_table.assign((size_t)nRU, 0);
+        for (int64_t m = 0; m < n_map; m++)
+            if (map_user[m] >= 0 && map_user[m] < nRU) h_table[(size_t)map_user[m]] = map_cluster[m];
+        d_table_own.alloc(ctx, (size_t)nRU);
+        h2d(ctx, d_table_own.get(), h_table.data(), (size_t)nRU);
+        cl_of_raw = d_table_own.get();
+    }
+    if (cl_of_raw) {
+        k_lookup_cluster_table<<<grid_for(nU), 256, 0, st>>>(nU, P.uid.get(), cl_of_raw, K, P.ucluster.get(), err.get());
+        FY_KERNEL_CHECK();
+    } else {
         if (n_map >= ((int64_t)1 << 32)) FY_FAIL(FY_ERR_UNSUPPORTED, "clustering map with more than 2^32 entries");
+        hm.resize((size_t)n_map);
+        hv.resize((size_t)n_map);
         for (int64_t m = 0; m < n_map; m++) {
             // key = (user : position in the file): sorted by it, the pairs of one user keep their order -- a later pair of the same
             // user wins, like successive TIntIntHashMap.put calls.  (A negative id can never match a kept rating.)
@@ -538,7 +820,10 @@ void build_structure(Context* ctx, const fy_ratings* R, int32_t K, int64_t n_map
     {
         DevBuf<uint64_t> ka(ctx, nU), kb(ctx, nU);
         DevBuf<uint32_t> va(ctx, nU), vb(ctx, nU);
-        k_slot_keys<<<grid_for(nU), 256, 0, st>>>(nU, P.ucluster.get(), P.udeg.get(), ka.get(), va.get(), P.d_csize.get());
+        if (K > 1 && K <= SLOT_KEYS_LDS)
+            k_slot_keys_lds<<<grid_for(nU, 256, 64), 256, 0, st>>>(nU, K, P.ucluster.get(), P.udeg.get(), ka.get(), va.get(), P.d_csize.get());
+        else
+            k_slot_keys<<<grid_for(nU), 256, 0, st>>>(nU, P.ucluster.get(), P.udeg.get(), ka.get(), va.get(), P.d_csize.get());
         FY_KERNEL_CHECK();
         sort_pairs_u64_u32(ctx, ka.get(), kb.get(), va.get(), vb.get(), nU);
         P.slot2du.alloc(ctx, nU);

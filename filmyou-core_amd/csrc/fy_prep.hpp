@@ -52,7 +52,16 @@ struct Prepared {
 // Builds every structure that does not depend on the job's statistics.  map_* are host arrays (may be empty).
 // Throws fy::Failure.
 void build_structure(Context* ctx, const fy_ratings* R, int32_t n_clusters, int64_t n_map, const int32_t* map_user,
-                     const int32_t* map_cluster, const int32_t* cluster_count, bool keep_nonpositive, Prepared& P);
+                     const int32_t* map_cluster, const int32_t* cluster_count, bool keep_nonpositive, Prepared& P,
+                     const int32_t* cl_of_raw = nullptr /* device table raw user id -> cluster (max_user + 1 entries), when the caller has one */);
+
+// Sharded prep (several ranks, at least as many non-empty clusters as ranks): decides which rank owns which WHOLE cluster from counts
+// every rank finds identically in the replicated COO (owner[c] = rank, `world` for an empty cluster) and copies the kept ratings of this
+// rank's clusters into `mine` (input order kept).  false = this job does not shard (fewer clusters than ranks, ids too sparse): the
+// caller preps the replicated ratings as before.  Failures that every rank sees are thrown (fy::Failure) by every rank.
+bool shard_ratings_by_cluster(Context* ctx, const fy_ratings* R, int32_t n_clusters, int64_t n_map, const int32_t* map_user,
+                              const int32_t* map_cluster, int rank, int world, fy_ratings& mine, std::vector<int32_t>& owner,
+                              DevBuf<int32_t>& cl_of_raw /* out: the device table raw user id -> cluster it built */);
 
 // fills R->max_user / R->max_item (one pass over the COO; called by fy_ratings_create)
 void ratings_id_bounds(Context* ctx, fy_ratings* R);

@@ -92,8 +92,19 @@ __device__ __forceinline__ void fy_pair_store(const PairPass& A, int32_t pos, in
 }
 // G lanes per column: 64 for the long columns of a big cluster; 16 where the average column is short (50 clusters of ML-25M shape:
 // 2.5 M columns of 10 raters -- a wave per column spent 1.7 ms per job there, four columns per wave 0.5)
+// heavy columns are cut into chunks of PAIR_CHUNK entries, one workgroup per chunk (k_pair_chunks), summed per column in chunk order
+// (k_pair_finish).  Up to round 4 a workgroup of 1024 walked a whole heavy column: the 10^5-rater columns of ML-25M shape made
+// that 0.34 ms of latency-bound tail.
+constexpr int PAIR_CHUNK = 4096;
+struct PairHeavy {
+    int32_t* __restrict__ col;        // [k]: rank position of heavy column k
+    int32_t* __restrict__ base;       // [k]: its first chunk
+    int32_t* __restrict__ chunk_col;  // [chunk]: k
+    int32_t* __restrict__ counters;   // [0] heavy columns, [1] chunks
+    PairAcc* __restrict__ acc;        // [chunk]
+};
 template <int G>
-__global__ void k_pair_pass(int32_t nP, PairPass A, int32_t* __restrict__ heavy, int32_t* __restrict__ n_heavy) {
+__global__ void k_pair_pass(int32_t nP, PairPass A, PairHeavy H) {
     const int lane = threadIdx.x & (G - 1), gpb = blockDim.x / G;
     const int32_t stride = gridDim.x * gpb;
     // (every group of a wave runs the same number of rounds: the shuffles of the reduction need all lanes)
@@ -103,7 +114,13 @@ __global__ void k_pair_pass(int32_t nP, PairPass A, int32_t* __restrict__ heavy,
         const int32_t pr = live ? A.rank_pair[pos] : 0;
         const int32_t q0 = live ? A.pair_start[pr] : 0, q1 = live ? A.pair_start[pr + 1] : 0;
         const bool is_heavy = q1 - q0 > PAIR_HEAVY;
-        if (is_heavy && lane == 0) heavy[atomicAdd(n_heavy, 1)] = pos;
+        if (is_heavy && lane == 0) {
+            const int32_t nchk = (q1 - q0 + PAIR_CHUNK - 1) / PAIR_CHUNK;
+            const int32_t k = atomicAdd(&H.counters[0], 1), c0 = atomicAdd(&H.counters[1], nchk);
+            H.col[k] = pos;
+            H.base[k] = c0;
+            for (int32_t i = 0; i < nchk; i++) H.chunk_col[c0 + i] = k;
+        }
         PairAcc a = fy_pair_zero();
         if (!is_heavy)
             for (int32_t q = q0 + lane; q < q1; q += G) fy_pair_entry(A, q, a);
@@ -111,28 +128,40 @@ __global__ void k_pair_pass(int32_t nP, PairPass A, int32_t* __restrict__ heavy,
         if (live && !is_heavy && lane == 0) fy_pair_store(A, pos, pr, q1 - q0, a);
     }
 }
-__global__ __launch_bounds__(1024) void k_pair_pass_heavy(PairPass A, const int32_t* __restrict__ heavy, const int32_t* __restrict__ n_heavy) {
-    __shared__ PairAcc sh_a[16];
+__device__ __forceinline__ void fy_pair_add(PairAcc& t, const PairAcc& x) {
+    t.ps += x.ps; t.b += x.b; t.ws += x.ws; t.w += x.w;
+    t.wm = fmaxf(t.wm, x.wm); t.rm = fmaxf(t.rm, x.rm);
+}
+__global__ __launch_bounds__(256) void k_pair_chunks(PairPass A, PairHeavy H) {
+    __shared__ PairAcc sh_a[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int n = *n_heavy;
-    for (int k = blockIdx.x; k < n; k += gridDim.x) {
-        const int32_t pos = heavy[k];
-        const int32_t pr = A.rank_pair[pos];
-        const int32_t q0 = A.pair_start[pr], q1 = A.pair_start[pr + 1];
+    const int n = H.counters[1];
+    for (int c = blockIdx.x; c < n; c += gridDim.x) {
+        const int32_t k = H.chunk_col[c];
+        const int32_t pr = A.rank_pair[H.col[k]];
+        const int32_t q0 = A.pair_start[pr] + (c - H.base[k]) * PAIR_CHUNK, q1 = min(A.pair_start[pr + 1], q0 + PAIR_CHUNK);
         PairAcc a = fy_pair_zero();
-        for (int32_t q = q0 + threadIdx.x; q < q1; q += 1024) fy_pair_entry(A, q, a);
+#pragma unroll 4
+        for (int32_t q = q0 + (int32_t)threadIdx.x; q < q1; q += 256) fy_pair_entry(A, q, a);
         fy_pair_reduce(a);
         if (lane == 0) sh_a[wave] = a;
         __syncthreads();
         if (threadIdx.x == 0) {
-            PairAcc t = fy_pair_zero();
-            for (int x = 0; x < 16; x++) {
-                t.ps += sh_a[x].ps; t.b += sh_a[x].b; t.ws += sh_a[x].ws; t.w += sh_a[x].w;
-                t.wm = fmaxf(t.wm, sh_a[x].wm); t.rm = fmaxf(t.rm, sh_a[x].rm);
-            }
-            fy_pair_store(A, pos, pr, q1 - q0, t);
+            PairAcc t = sh_a[0];
+            for (int x = 1; x < 4; x++) fy_pair_add(t, sh_a[x]);
+            H.acc[c] = t;
         }
         __syncthreads();
+    }
+}
+__global__ void k_pair_finish(PairPass A, PairHeavy H) {
+    const int n = H.counters[0];
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        const int32_t pos = H.col[k], pr = A.rank_pair[pos];
+        const int32_t len = A.pair_start[pr + 1] - A.pair_start[pr], nchk = (len + PAIR_CHUNK - 1) / PAIR_CHUNK;
+        PairAcc t = H.acc[H.base[k]];
+        for (int32_t i = 1; i < nchk; i++) fy_pair_add(t, H.acc[H.base[k] + i]);      // chunk order: the same sum in every run
+        fy_pair_store(A, pos, pr, len, t);
     }
 }
 // per-slot copies of the user sums and degrees: one gather per CSC entry instead of two dependent ones
@@ -147,22 +176,25 @@ __global__ void k_slot_user_arrays(int32_t nU, const int32_t* __restrict__ slot2
 
 // per cluster: maxima over its items of (sum of r / s^2, largest r / s^2, largest rating) -> bounds of a Gram entry and of one contribution
 __global__ void k_cluster_fx_bounds(const int32_t* __restrict__ pcstart, const float* __restrict__ fx_rank, float* __restrict__ out) {
+    // blockIdx.x = cluster, blockIdx.y = share of its items; `out` is zeroed by the caller and the values are >= 0, so the maximum of
+    // their bit patterns is their maximum (one cluster of 59 047 items in ONE workgroup was 67 us of every prepare)
     const int c = blockIdx.x;
     float m0 = 0.f, m1 = 0.f, m2 = 0.f;
-    for (int32_t pos = pcstart[c] + threadIdx.x; pos < pcstart[c + 1]; pos += blockDim.x) {
+    for (int32_t pos = pcstart[c] + blockIdx.y * blockDim.x + threadIdx.x; pos < pcstart[c + 1]; pos += gridDim.y * blockDim.x) {
         m0 = fmaxf(m0, fx_rank[3 * (int64_t)pos]);
         m1 = fmaxf(m1, fx_rank[3 * (int64_t)pos + 1]);
         m2 = fmaxf(m2, fx_rank[3 * (int64_t)pos + 2]);
     }
-    __shared__ float sh[3][256];
-    sh[0][threadIdx.x] = m0; sh[1][threadIdx.x] = m1; sh[2][threadIdx.x] = m2;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o)
-            for (int k = 0; k < 3; k++) sh[k][threadIdx.x] = fmaxf(sh[k][threadIdx.x], sh[k][threadIdx.x + o]);
-        __syncthreads();
+    for (int o = 32; o > 0; o >>= 1) {
+        m0 = fmaxf(m0, __shfl_down(m0, o, 64));
+        m1 = fmaxf(m1, __shfl_down(m1, o, 64));
+        m2 = fmaxf(m2, __shfl_down(m2, o, 64));
     }
-    if (threadIdx.x < 3) out[3 * c + threadIdx.x] = sh[threadIdx.x][0];
+    if ((threadIdx.x & 63) == 0) {
+        if (m0 > 0.f) atomicMax(reinterpret_cast<int*>(out + 3 * c), __float_as_int(m0));
+        if (m1 > 0.f) atomicMax(reinterpret_cast<int*>(out + 3 * c + 1), __float_as_int(m1));
+        if (m2 > 0.f) atomicMax(reinterpret_cast<int*>(out + 3 * c + 2), __float_as_int(m2));
+    }
 }
 
 // quirk Q1: the Hadoop counter adds (long) s_u * 100 per user and is divided by 100 afterwards
@@ -186,6 +218,39 @@ __global__ void k_sum_gathered(int64_t len, int32_t world, const double* __restr
         for (int r = 0; r < world; r++) s += gathered[(int64_t)r * len + d];
         out[d] = s;
     }
+}
+
+// Sharded prep (whole clusters per rank, only the owned clusters' ratings prepared): a rank's dense item / user numbering is its own,
+// so the exchange buffer is laid out by RAW id -- [max_item + 1 item sums][counter][max_user + 1 user sums][failure flag] -- and the
+// job's own dense statistics are read back out of the sum over ranks.
+__global__ void k_stats_to_raw(int32_t nI, const int32_t* __restrict__ iid, const double* __restrict__ partial, int64_t n_raw_items, int32_t nU,
+                               const int32_t* __restrict__ uid, const double* __restrict__ usum, double* __restrict__ raw) {
+    const int32_t n = max(nI + 1, nU);
+    for (int32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+        if (t < nI) raw[iid[t]] = partial[t];
+        if (t == nI) raw[n_raw_items] = partial[nI];
+        if (t < nU) raw[n_raw_items + 1 + uid[t]] = usum[t];
+    }
+}
+__global__ void k_stats_from_raw(int32_t nI, const int32_t* __restrict__ iid, const double* __restrict__ raw, int64_t n_raw_items,
+                                 double* __restrict__ stats) {
+    for (int32_t t = blockIdx.x * blockDim.x + threadIdx.x; t <= nI; t += gridDim.x * blockDim.x) stats[t] = t < nI ? raw[iid[t]] : raw[n_raw_items];
+}
+__global__ void k_rank_flags(int32_t world, int64_t len, const double* __restrict__ gathered, double* __restrict__ out) {
+    if ((int)threadIdx.x < world) out[threadIdx.x] = gathered[(int64_t)threadIdx.x * len + len - 1];
+}
+__global__ void k_flag_positive(int64_t n, const double* __restrict__ v, uint32_t* __restrict__ flag) {
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) flag[t] = v[t] > 0.0 ? 1u : 0u;
+}
+// (id, value * scale) of the positive entries, ascending id
+__global__ void k_compact_positive(int64_t n, const double* __restrict__ v, const uint32_t* __restrict__ pos, const double* __restrict__ divide_by,
+                                   int32_t* __restrict__ id, double* __restrict__ val) {
+    const double d = divide_by ? *divide_by : 1.0;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x)
+        if (v[t] > 0.0) {
+            id[pos[t] - 1] = (int32_t)t;
+            val[pos[t] - 1] = divide_by ? v[t] / d : v[t];
+        }
 }
 
 // p(i|C) = itemsum / totalSum (DoubleSumAndDividerReducer.java:35-44); stats[nI] holds the counter (x100)
@@ -1245,6 +1310,14 @@ struct RM2Static {
     Prepared P;
     int32_t slot_lo = 0, slot_hi = 0;
     DevBuf<double> partial;     // nI + 1 : this rank's exchange buffer
+    // sharded prep (fy_prep.hpp: shard_ratings_by_cluster): P holds this rank's clusters alone and the exchange buffer is by raw id
+    bool sharded = false;
+    int64_t n_raw_users = 0, n_raw_items = 0;
+    std::vector<int32_t> owner;         // [cluster] -> rank (world: empty cluster)
+    DevBuf<double> partial_raw;         // n_raw_items + 1 + n_raw_users + 1
+    int deferred_code = 0;              // a failure only this rank can see (a duplicate rating / clusteringCount mismatch inside an owned
+    std::string deferred_msg;           // cluster): it travels with the statistics so that every rank fails instead of waiting for this one
+    int64_t exchange_len() const { return sharded ? n_raw_items + 1 + n_raw_users + 1 : (int64_t)P.nI + 1; }
     // per (cluster, item) in rank order, from the one CSC walk of fy_rm2_prepare (k_pair_pass)
     DevBuf<double> b_rank, usum_slot;
     DevBuf<long long> walk_rank;
@@ -1270,6 +1343,7 @@ struct fy_rm2_job {
     int32_t &slot_lo, &slot_hi;
     DevBuf<double>& partial;
     DevBuf<double> stats;       // nI + 1 : global sums (+ counter)
+    DevBuf<double> stats_raw;   // sharded prep: the sum over ranks of the raw-id exchange buffers
     bool have_global = false;
     double ms_prepare = 0;
     bool from_cache = false;
@@ -1292,6 +1366,7 @@ struct fy_rm2_job {
 // merge is per owner: equal COUNTS keep the padded reduce-scatter segments small (slots are degree-descending, the
 // work-balanced last rank would own four times the average number of users).
 static void owner_range(const fy_rm2_job* J, int k, int32_t& lo, int32_t& hi) {
+    if (J->S->sharded) { lo = 0; hi = k == J->prm.rank ? J->P.nU : 0; return; }      // this rank's structure holds its own clusters alone
     if (!J->count_balanced) { rank_slot_range(J->P, k, J->prm.world, lo, hi); return; }
     const int64_t n = J->P.nU, W = J->prm.world;
     lo = (int32_t)(n * k / W);
@@ -1661,11 +1736,52 @@ fy_rm2_job* fy::rm2_prepare(Context* ctx, const fy_rm2_params* prm, const fy_rat
     std::unique_ptr<fy_rm2_job> J(new fy_rm2_job(fresh));
     J->ctx = ctx;
     J->prm = *prm;
-    build_structure(ctx, R, prm->number_of_clusters, n_map, map_user, map_cluster, cluster_count, false, J->P);
+    // Several ranks and at least as many clusters as ranks: this rank preps the ratings of its own clusters alone (the reference's
+    // map-side partitioning by cluster, IntKeyPartitioner.java:15); the statistics are then exchanged by raw id.
+    fy_ratings mine;
+    DevBuf<int32_t> cl_table;
+    SyncOnUnwind mine_guard(ctx->stream);       // (a failure below must not free `mine` under a queued kernel)
+    RM2Static& S = *fresh;
+    if (prm->world > 1 && ctx->tune.shard_prep)
+        S.sharded = shard_ratings_by_cluster(ctx, R, prm->number_of_clusters, n_map, map_user, map_cluster, prm->rank, prm->world, mine, S.owner, cl_table);
     Prepared& P = J->P;
-    rank_slot_range(P, prm->rank, prm->world, J->slot_lo, J->slot_hi);
+    if (S.sharded) {
+        S.n_raw_users = (int64_t)R->max_user + 1;
+        S.n_raw_items = (int64_t)R->max_item + 1;
+        S.partial_raw.alloc(ctx, (size_t)S.exchange_len());
+        S.partial_raw.zero();
+        try {
+            build_structure(ctx, &mine, prm->number_of_clusters, n_map, map_user, map_cluster, cluster_count, false, J->P, cl_table.get());
+        } catch (const Failure& f) {
+            if (f.code != FY_ERR_DUPLICATE_RATING && f.code != FY_ERR_CLUSTER_COUNT) throw;
+            // only this rank's share shows it: the other ranks learn of it from the flag at the end of the exchange buffer
+            // (fy_rm2_set_global_stats fails on EVERY rank then, none waits in a collective for a rank that has gone)
+            S.deferred_code = f.code;
+            S.deferred_msg = last_error();
+            const double flag = (double)(-f.code);
+            sync(ctx);
+            FY_HIP(hipMemcpyAsync(S.partial_raw.get() + (S.exchange_len() - 1), &flag, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+            tm.end(span);
+            sync(ctx);
+            J->ms_prepare = tm.total_ms();
+            return J.release();
+        }
+        J->slot_lo = 0;
+        J->slot_hi = P.nU;
+    } else {
+        build_structure(ctx, R, prm->number_of_clusters, n_map, map_user, map_cluster, cluster_count, false, J->P);
+        rank_slot_range(P, prm->rank, prm->world, J->slot_lo, J->slot_hi);
+    }
     J->partial.alloc(ctx, (size_t)P.nI + 1);
     J->partial.zero();
+    // (sharded: the raw-id copy of the exchange buffer, queued behind the kernels that fill `partial` below)
+    auto publish_raw = [&]() {
+        if (!S.sharded) return;
+        const int32_t n = std::max(P.nI + 1, P.nU);
+        k_stats_to_raw<<<grid_for(n), 256, 0, ctx->stream>>>(P.nI, P.iid.get(), J->partial.get(), S.n_raw_items, P.nU, P.uid.get(), P.usum.get(),
+                                                              S.partial_raw.get());
+        FY_KERNEL_CHECK();
+    };
     if (P.nnz > 0) {
         DevBuf<unsigned long long> counter(ctx, 1);
         counter.zero();
@@ -1678,14 +1794,20 @@ fy_rm2_job* fy::rm2_prepare(Context* ctx, const fy_rm2_params* prm, const fy_rat
         J->walk_rank.alloc(ctx, (size_t)P.nP);
         J->cnt_rank.alloc(ctx, (size_t)P.nP);
         J->fx_rank.alloc(ctx, 3 * (size_t)P.nP);
-        DevBuf<int32_t> heavy(ctx, (size_t)P.nP), n_heavy(ctx, 1);
-        n_heavy.zero();
+        // heavy columns (more than PAIR_HEAVY raters): at most nnz / PAIR_HEAVY of them, at most nnz / PAIR_HEAVY chunks
+        const size_t max_heavy = (size_t)(P.nnz / PAIR_HEAVY) + 1;
+        DevBuf<int32_t> heavy_col(ctx, max_heavy), heavy_base(ctx, max_heavy), chunk_col(ctx, max_heavy), heavy_counters(ctx, 2);
+        DevBuf<PairAcc> chunk_acc(ctx, max_heavy);
+        heavy_counters.zero();
         const PairPass PA{P.rank_pair.get(), P.pair_start.get(), P.pair_di.get(), P.csc_slot.get(), P.csc_r.get(), J->usum_slot.get(),
                           J->deg_slot.get(), J->slot_lo, J->slot_hi, J->partial.get(), J->b_rank.get(), J->walk_rank.get(), J->cnt_rank.get(), J->fx_rank.get()};
-        if (P.nnz < 24 * (int64_t)P.nP) k_pair_pass<16><<<grid_for((int64_t)P.nP * 16, 256), 256, 0, ctx->stream>>>(P.nP, PA, heavy.get(), n_heavy.get());
-        else k_pair_pass<64><<<grid_for((int64_t)P.nP * 64, 256), 256, 0, ctx->stream>>>(P.nP, PA, heavy.get(), n_heavy.get());
+        const PairHeavy PH{heavy_col.get(), heavy_base.get(), chunk_col.get(), heavy_counters.get(), chunk_acc.get()};
+        if (P.nnz < 24 * (int64_t)P.nP) k_pair_pass<16><<<grid_for((int64_t)P.nP * 16, 256), 256, 0, ctx->stream>>>(P.nP, PA, PH);
+        else k_pair_pass<64><<<grid_for((int64_t)P.nP * 64, 256), 256, 0, ctx->stream>>>(P.nP, PA, PH);
         FY_KERNEL_CHECK();
-        k_pair_pass_heavy<<<ctx->num_cus * 2, 1024, 0, ctx->stream>>>(PA, heavy.get(), n_heavy.get());
+        k_pair_chunks<<<(unsigned)std::min<size_t>(max_heavy, (size_t)ctx->num_cus * 32), 256, 0, ctx->stream>>>(PA, PH);
+        FY_KERNEL_CHECK();
+        k_pair_finish<<<(unsigned)std::min<size_t>(ceil_div((int64_t)max_heavy, 64), 1024), 64, 0, ctx->stream>>>(PA, PH);
         FY_KERNEL_CHECK();
         if (J->slot_hi > J->slot_lo) {
             k_partial_total<<<grid_for(J->slot_hi - J->slot_lo), 256, 0, ctx->stream>>>(J->slot_lo, J->slot_hi, P.slot2du.get(),
@@ -1694,8 +1816,11 @@ fy_rm2_job* fy::rm2_prepare(Context* ctx, const fy_rm2_params* prm, const fy_rat
         }
         k_store_total<<<1, 1, 0, ctx->stream>>>(counter.get(), J->partial.get() + P.nI);
         FY_KERNEL_CHECK();
+        publish_raw();
         DevBuf<float> d_fx(ctx, 3 * (size_t)P.K);
-        k_cluster_fx_bounds<<<P.K, 256, 0, ctx->stream>>>(P.d_pcstart.get(), J->fx_rank.get(), d_fx.get());
+        d_fx.zero();
+        k_cluster_fx_bounds<<<dim3((unsigned)P.K, (unsigned)std::max<int64_t>(1, std::min<int64_t>(64, (int64_t)P.nP / ((int64_t)P.K * 1024)))), 256, 0, ctx->stream>>>(
+            P.d_pcstart.get(), J->fx_rank.get(), d_fx.get());
         FY_KERNEL_CHECK();
         J->fx_bounds.resize(3 * (size_t)P.K);
         d2h(ctx, J->fx_bounds.data(), d_fx.get(), 3 * (size_t)P.K);
@@ -1715,7 +1840,33 @@ fy_rm2_job* fy::rm2_prepare(Context* ctx, const fy_rm2_params* prm, const fy_rat
 void fy::rm2_set_global_stats(fy_rm2_job* J, const double* gathered, int32_t world) {
     Context* ctx = J->ctx;
     if (world != J->prm.world) FY_FAIL(FY_ERR_INVALID_ARGUMENT, "gathered world %d != params.world %d", world, J->prm.world);
-    const int64_t len = (int64_t)J->P.nI + 1;
+    const RM2Static& S = *J->S;
+    const int64_t len = S.exchange_len();
+    if (S.sharded) {
+        if (world > 1024) FY_FAIL(FY_ERR_UNSUPPORTED, "more than 1024 ranks");
+        // did any rank's share fail?  (the flags are read before anything is built from the sums)
+        DevBuf<double> d_flags(ctx, (size_t)world);
+        k_rank_flags<<<1, 1024, 0, ctx->stream>>>(world, len, gathered, d_flags.get());
+        FY_KERNEL_CHECK();
+        std::vector<double> flags((size_t)world);
+        d2h(ctx, flags.data(), d_flags.get(), (size_t)world);
+        sync(ctx);
+        if (S.deferred_code) { set_error("%s", S.deferred_msg.c_str()); throw Failure{S.deferred_code}; }
+        for (int r = 0; r < world; r++)
+            if (flags[(size_t)r] != 0.0) {
+                const int code = -(int)flags[(size_t)r];
+                FY_FAIL(code, "rank %d found %s in the clusters it owns", r,
+                        code == FY_ERR_DUPLICATE_RATING ? "two ratings with one (user, item) key" : "a clusteringCount that disagrees with the rated users");
+            }
+        J->stats_raw.alloc(ctx, (size_t)len);
+        k_sum_gathered<<<grid_for(len), 256, 0, ctx->stream>>>(len, world, gathered, J->stats_raw.get());
+        FY_KERNEL_CHECK();
+        J->stats.alloc(ctx, (size_t)J->P.nI + 1);
+        k_stats_from_raw<<<grid_for((int64_t)J->P.nI + 1), 256, 0, ctx->stream>>>(J->P.nI, J->P.iid.get(), J->stats_raw.get(), S.n_raw_items, J->stats.get());
+        FY_KERNEL_CHECK();
+        J->have_global = true;
+        return;
+    }
     J->stats.alloc(ctx, (size_t)len);
     k_sum_gathered<<<grid_for(len), 256, 0, ctx->stream>>>(len, world, gathered, J->stats.get());
     FY_KERNEL_CHECK();
@@ -1730,9 +1881,9 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
     if (!J->have_global) {
         if (prm.world == 1) rm2_set_global_stats(J, J->partial.get(), 1);
         else if (J->have_coll) {   // the all-gather of the per-item statistics (jobs RM2-1 / RM2-2) through the installed collectives
-            const int64_t len = (int64_t)P.nI + 1;
+            const int64_t len = J->S->exchange_len();
             J->gathered.alloc(ctx, (size_t)(len * prm.world));
-            coll_all_gather(J, J->partial.get(), J->gathered.get(), len * (int64_t)sizeof(double), st);
+            coll_all_gather(J, J->S->sharded ? J->S->partial_raw.get() : J->partial.get(), J->gathered.get(), len * (int64_t)sizeof(double), st);
             rm2_set_global_stats(J, J->gathered.get(), prm.world);
         } else
             FY_FAIL(FY_ERR_STATE, "world > 1: call fy_rm2_set_global_stats (or install fy_collectives) before fy_rm2_score");
@@ -1771,14 +1922,17 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
     bool any_coop = false;
 
     // ---- p(i|C), per-(cluster,item) statistics, per-rating values
-    R->d_icoll.alloc(ctx, nI);
+    // (sharded prep: the job's own dense items are this rank's clusters' items; the result's itemColl is the global one, built at the end)
+    DevBuf<double> icoll_mine;
+    if (J->S->sharded) icoll_mine.alloc(ctx, nI); else R->d_icoll.alloc(ctx, nI);
+    double* const d_icoll = J->S->sharded ? icoll_mine.get() : R->d_icoll.get();
     DevBuf<double> d_total(ctx, 1);
-    k_item_coll<<<grid_for(nI), 256, 0, st>>>(nI, J->stats.get(), R->d_icoll.get(), d_total.get());
+    k_item_coll<<<grid_for(nI), 256, 0, st>>>(nI, J->stats.get(), d_icoll, d_total.get());
     FY_KERNEL_CHECK();
     DevBuf<double> p_rank(ctx, nP);
     DevBuf<double>& b_rank = J->b_rank;
     DevBuf<float> a_rank(ctx, nP), b_rank32(ctx, nP);
-    k_pair_p<<<grid_for(nP), 256, 0, st>>>(nP, P.rank_pair.get(), P.pair_di.get(), R->d_icoll.get(), lambda, b_rank.get(), p_rank.get(), a_rank.get(),
+    k_pair_p<<<grid_for(nP), 256, 0, st>>>(nP, P.rank_pair.get(), P.pair_di.get(), d_icoll, lambda, b_rank.get(), p_rank.get(), a_rank.get(),
                                            b_rank32.get());
     FY_KERNEL_CHECK();
     DevBuf<float> csr_x(ctx, P.nnz), csr_e(ctx, P.nnz), csr_q(ctx, P.nnz);
@@ -1828,7 +1982,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
     t_tables.end(span_tables);
     // ---- which users this rank emits lists for
     J->count_balanced = false;
-    if (prm.world > 1 && J->have_coll && tune.coop && tune.prune && pack24_allowed) {     // (a cooperative cluster must be a packed one: checked per plan below)
+    if (prm.world > 1 && !J->S->sharded && J->have_coll && tune.coop && tune.prune && pack24_allowed) {     // (a cooperative cluster must be a packed one: checked per plan below)
         int nonempty = 0, c1 = -1;
         for (int c = 0; c < K; c++)
             if (P.csize[c] > 0) { nonempty++; c1 = c; }
@@ -2993,12 +3147,41 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
         }
     }
     // rm2/userSum and rm2/itemColl stay in HBM until somebody asks for them
-    R->d_user_id.alloc(ctx, nU);
-    R->d_user_sum.alloc(ctx, nU);
-    d2d(ctx, R->d_user_id.get(), P.uid.get(), nU);
-    d2d(ctx, R->d_user_sum.get(), P.usum.get(), nU);
-    R->d_item_id.alloc(ctx, nI);
-    d2d(ctx, R->d_item_id.get(), P.iid.get(), nI);
+    if (J->S->sharded) {
+        // the GLOBAL statistics (jobs RM2-1 / RM2-2 write one userSum and one itemColl for all clusters): out of the summed raw-id buffer
+        const RM2Static& S = *J->S;
+        const double* raw_items = J->stats_raw.get();
+        const double* raw_users = J->stats_raw.get() + S.n_raw_items + 1;
+        DevBuf<uint32_t> fi(ctx, (size_t)S.n_raw_items), pi(ctx, (size_t)S.n_raw_items), fu(ctx, (size_t)S.n_raw_users), pu(ctx, (size_t)S.n_raw_users);
+        k_flag_positive<<<grid_for(S.n_raw_items), 256, 0, st>>>(S.n_raw_items, raw_items, fi.get());
+        FY_KERNEL_CHECK();
+        k_flag_positive<<<grid_for(S.n_raw_users), 256, 0, st>>>(S.n_raw_users, raw_users, fu.get());
+        FY_KERNEL_CHECK();
+        inclusive_scan_u32(ctx, fi.get(), pi.get(), (size_t)S.n_raw_items);
+        inclusive_scan_u32(ctx, fu.get(), pu.get(), (size_t)S.n_raw_users);
+        uint32_t n_items_all = 0, n_users_all = 0;
+        d2h(ctx, &n_items_all, pi.get() + (S.n_raw_items - 1), 1);
+        d2h(ctx, &n_users_all, pu.get() + (S.n_raw_users - 1), 1);
+        sync(ctx);
+        R->d_item_id.alloc(ctx, n_items_all);
+        R->d_icoll.alloc(ctx, n_items_all);
+        R->d_user_id.alloc(ctx, n_users_all);
+        R->d_user_sum.alloc(ctx, n_users_all);
+        k_compact_positive<<<grid_for(S.n_raw_items), 256, 0, st>>>(S.n_raw_items, raw_items, pi.get(), d_total.get(), R->d_item_id.get(), R->d_icoll.get());
+        FY_KERNEL_CHECK();
+        k_compact_positive<<<grid_for(S.n_raw_users), 256, 0, st>>>(S.n_raw_users, raw_users, pu.get(), nullptr, R->d_user_id.get(), R->d_user_sum.get());
+        FY_KERNEL_CHECK();
+        R->st.n_users = n_users_all;
+        R->st.n_items = n_items_all;
+        sync(ctx);      // (the flags and positions are released here)
+    } else {
+        R->d_user_id.alloc(ctx, nU);
+        R->d_user_sum.alloc(ctx, nU);
+        d2d(ctx, R->d_user_id.get(), P.uid.get(), nU);
+        d2d(ctx, R->d_user_sum.get(), P.usum.get(), nU);
+        R->d_item_id.alloc(ctx, nI);
+        d2d(ctx, R->d_item_id.get(), P.iid.get(), nI);
+    }
     t_total.end(span_total);
     d2h(ctx, &R->total_sum, d_total.get(), 1);
     sync(ctx);
@@ -3020,8 +3203,13 @@ void fy::rm2_set_collectives(fy_rm2_job* J, const fy_collectives* c) {
 }
 
 void fy::rm2_partial_stats(fy_rm2_job* J, double** buf, int64_t* len) {
-    *buf = J->partial.get();
-    *len = (int64_t)J->P.nI + 1;
+    *buf = J->S->sharded ? J->S->partial_raw.get() : J->partial.get();
+    *len = J->S->exchange_len();
+}
+
+void fy::rm2_stats_layout(fy_rm2_job* J, int64_t* n_item_slots, int64_t* n_user_slots) {
+    *n_item_slots = J->S->sharded ? J->S->n_raw_items : (int64_t)J->P.nI;
+    *n_user_slots = J->S->sharded ? J->S->n_raw_users : 0;
 }
 
 void fy::rm2_job_destroy(fy_rm2_job* J) {

@@ -26,6 +26,7 @@ namespace fy {
 fy_rm2_job* rm2_prepare(Context*, const fy_rm2_params*, const fy_ratings*, int64_t n_map, const int32_t* map_user,
                         const int32_t* map_cluster, const int32_t* cluster_count);
 void rm2_partial_stats(fy_rm2_job*, double** buf, int64_t* len);
+void rm2_stats_layout(fy_rm2_job*, int64_t* n_item_slots, int64_t* n_user_slots);
 void rm2_set_global_stats(fy_rm2_job*, const double* gathered, int32_t world);
 void rm2_set_collectives(fy_rm2_job*, const fy_collectives*);
 fy_result* rm2_score(fy_rm2_job*);

@@ -419,10 +419,18 @@ class PreparedRM2:
 
     def partial_stats(self):
         """(device pointer, length in doubles) of the exchange buffer: per-item partial rating sums in ascending raw
-        item id order + this rank's partial of the floor-sum counter (x100)."""
+        item id order + this rank's partial of the floor-sum counter (x100) (+ user sums and a flag: stats_layout)."""
         buf, n = C.c_void_p(), C.c_int64()
         _check(self._lib.fy_rm2_partial_stats(self._h, C.byref(buf), C.byref(n)))
         return buf.value, n.value
+
+    def stats_layout(self):
+        """(n_item_slots, n_user_slots) of the exchange buffer: [n_item_slots item sums][floor-sum][n_user_slots user sums][flag if any user
+        slots].  Replicated prep: one slot per rated item (ascending raw id), no user slots.  Sharded prep (several ranks, whole clusters per
+        rank, a rank preps its own clusters' ratings alone): slots by RAW id, user sums and a failure flag behind the floor-sum."""
+        ni, nu = C.c_int64(), C.c_int64()
+        _check(self._lib.fy_rm2_stats_layout(self._h, C.byref(ni), C.byref(nu)))
+        return ni.value, nu.value
 
     def set_global_stats(self, gathered_device_ptr):
         _check(self._lib.fy_rm2_set_global_stats(self._h, gathered_device_ptr, self.world))

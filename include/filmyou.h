@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FY_ABI_VERSION 4
+#define FY_ABI_VERSION 5
 
 typedef enum {
     FY_OK = 0,
@@ -112,10 +112,16 @@ typedef struct {
  * NULL; when given it is validated.  map_* / cluster_count are HOST pointers. */
 int fy_rm2_prepare(fy_context*, const fy_rm2_params*, const fy_ratings*, int64_t n_map, const int32_t* map_user,
                    const int32_t* map_cluster, const int32_t* cluster_count, fy_rm2_job** out);
-/* The exchange buffer of this rank, in HBM: `*len` doubles = per-item partial sums in ascending raw item id order
- * followed by one double holding this rank's partial sum of floor(s_u) (quirk Q1).  All ranks hold the same item set
- * (the ratings are replicated), so `*len` agrees across ranks: all-gather it (RCCL) into world * len doubles. */
+/* The exchange buffer of this rank, in HBM: `*len` doubles, the same `*len` on every rank (the ratings are replicated):
+ * all-gather it (RCCL) into world * len doubles.  Two layouts (fy_rm2_stats_layout tells which):
+ *   replicated prep : [one partial rating sum per rated item, ascending raw item id][this rank's partial sum of floor(s_u), quirk Q1]
+ *   sharded prep    : a job of several ranks with at least as many non-empty clusters as ranks gives every rank WHOLE clusters and
+ *                     preps the ratings of its own clusters alone (the reference's map-side partitioning by cluster,
+ *                     IntKeyPartitioner.java:15); its buffer is indexed by RAW id:
+ *                     [max item id + 1 item sums][the floor-sum][max user id + 1 user sums s_u][failure flag of this rank's share]. */
 int fy_rm2_partial_stats(fy_rm2_job*, double** device_buf, int64_t* len);
+/* n_item_slots item sums, one floor-sum, n_user_slots user sums (0: replicated prep, no user sums and no flag), the flag. */
+int fy_rm2_stats_layout(fy_rm2_job*, int64_t* n_item_slots, int64_t* n_user_slots);
 /* `gathered` = world * len doubles in HBM, rank-major.  Summed in rank order (bit-reproducible).  Optional when world == 1. */
 int fy_rm2_set_global_stats(fy_rm2_job*, const double* gathered_device, int32_t world);
 /* Collectives of the process group the `world` ranks form (one process per GPU).  The signatures are RCCL's

@@ -1,6 +1,8 @@
 """The user-sharded (multi-GPU) RM2 path, rehearsed on ONE GPU: every rank's stage 1 runs in turn, the all-gather of
 the partial item statistics is played by hand (concatenation in rank order -- exactly the layout RCCL's all-gather
 produces), every rank's stage 2 runs, and the union of the ranks' rows must equal the single-rank result."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -26,6 +28,50 @@ def device_doubles(ptr, n):
 @pytest.mark.parametrize("shape,K,world", [("tiny", 1, 2), ("tiny", 5, 3), ("ml100k", 1, 4), ("ml100k", 12, 8), ("ml100k", 8, 8), ("ml100k", 50, 4)])
 def test_sharded_equals_single(ctx, shape, K, world):
     sharded_equals_single(ctx, shape, K, world)
+
+
+def test_whole_clusters_with_the_replicated_prep(monkeypatch):
+    """FY_SHARD_PREP=0: every rank preps all ratings and owns a run of whole clusters of the common slot order (round 4's first flow)."""
+    monkeypatch.setenv("FY_SHARD_PREP", "0")
+    c = pkg().Context(0)
+    try:
+        sharded_equals_single(c, "ml100k", 12, 8)
+    finally:
+        c.close()
+
+
+def test_a_failure_only_one_rank_can_see_fails_every_rank(ctx):
+    """Sharded prep: a duplicate (user, item) rating sits in ONE rank's clusters.  That rank still hands out its exchange buffer (with the
+    failure flag at its end), and fy_rm2_set_global_stats fails on every rank with the same code -- nobody waits in a collective for a
+    rank that has gone."""
+    P, S = pkg(), synth()
+    u, i, s, facts = S.generate("ml100k")
+    u, i, s = u.numpy(), i.numpy(), s.numpy()
+    uu = np.unique(u)
+    K, world = 8, 4
+    clustering = (uu, S.hash_clustering(uu, K))
+    u2, i2, s2 = np.append(u, u[0]), np.append(i, i[0]), np.append(s, s[0])
+    conf = P.Configuration()
+    conf.set("lambda", "0.1")
+    conf.setInt("numberOfItems", facts["n_items"])
+    conf.setInt("numberOfClusters", K)
+    conf.setInt("numberOfRecommendations", 20)
+    ratings = P.Ratings(ctx, u2, i2, s2)
+    job = P.RM2Job(conf, ctx)
+    prepared = [job.prepare(ratings, clustering=clustering, rank=r, world=world) for r in range(world)]     # no rank fails here
+    parts = []
+    for pr in prepared:
+        ptr, n = pr.partial_stats()
+        parts.append(device_doubles(ptr, n).clone())
+    torch.cuda.synchronize()
+    assert sorted(float(p[-1]) for p in parts) == [0.0] * (world - 1) + [7.0]        # -FY_ERR_DUPLICATE_RATING, on the owner alone
+    gathered = torch.cat(parts).contiguous()
+    for pr in prepared:
+        with pytest.raises(P.FilmYouError) as e:
+            pr.set_global_stats(gathered.data_ptr())
+        assert e.value.code == -7
+        pr.close()
+    ratings.close()
 
 
 def test_sharded_panel_mode(ctx, monkeypatch):
@@ -63,15 +109,35 @@ def sharded_equals_single(ctx, shape, K, world):
     # the partials really are partial: each is a strict part of the total, and they add up to the item sums
     total = torch.stack(parts).sum(0).cpu().numpy()
     sums = single.sums()
-    np.testing.assert_array_equal(total[:-1] / (total[-1] / 100.0), sums["item_coll"])
-    assert total[-1] / 100.0 == sums["total_sum"]
+    layouts = {pr.stats_layout() for pr in prepared}
+    assert len(layouts) == 1
+    n_item_slots, n_user_slots = layouts.pop()
+    n_nonempty = len(np.unique(clustering[1][np.isin(clustering[0], uu)]))
+    # at least as many clusters as ranks: sharded prep (a rank preps its own clusters' ratings alone), the buffer is by raw id and
+    # carries the user sums and a failure flag; otherwise one slot per rated item
+    assert (n_user_slots > 0) == (world > 1 and n_nonempty >= world and os.environ.get("FY_SHARD_PREP", "1") != "0")
+    assert len(total) == n_item_slots + 1 + (n_user_slots + 1 if n_user_slots else 0)
+    item_sums, floor_sum = total[:n_item_slots], total[n_item_slots]
+    if n_user_slots:
+        assert n_item_slots == int(i.max()) + 1 and n_user_slots == int(u.max()) + 1 and total[-1] == 0.0
+        user_sums = total[n_item_slots + 1:-1]
+        np.testing.assert_array_equal(np.nonzero(user_sums)[0], sums["user_id"])
+        np.testing.assert_array_equal(user_sums[user_sums > 0], sums["user_sum"])
+        np.testing.assert_array_equal(np.nonzero(item_sums)[0], sums["item_id"])
+        item_sums = item_sums[item_sums > 0]
+    np.testing.assert_array_equal(item_sums / (floor_sum / 100.0), sums["item_coll"])
+    assert floor_sum / 100.0 == sums["total_sum"]
     if world > 1:
-        assert all(float(p[:-1].sum()) < float(total[:-1].sum()) for p in parts)
+        assert all(float(p[:n_item_slots].sum()) < float(total[:n_item_slots].sum()) for p in parts)
     results = []
     for pr in prepared:
         pr.set_global_stats(gathered.data_ptr())
         results.append(pr.score())
         pr.close()
+    for r in results:       # every rank returns the GLOBAL side outputs (rm2/userSum, rm2/itemColl), whatever it prepared
+        if r.size:
+            for k2 in ("user_id", "user_sum", "item_id", "item_coll", "total_sum"):
+                np.testing.assert_array_equal(r.sums()[k2], sums[k2])
     rows = {k: np.concatenate([r.rows()[k] for r in results]) for k in ("user", "item", "score", "cluster")}
     # ranks own disjoint users, together all of them
     owners = [set(r.rows()["user"].tolist()) for r in results]

@@ -18,7 +18,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(P._native.SYMBOLS), declared ^ set(P._native.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.fy_abi_version() == 4
+    assert lib.fy_abi_version() == 5
 
 
 def test_struct_layouts_match_the_header():
