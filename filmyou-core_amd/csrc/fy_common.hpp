@@ -68,6 +68,7 @@ struct Tuning {
                                        // column chunks instead of four, 19.7 -> 17.8 ms; smaller forces more chunks)
     bool cooc_max_ch_forced = false;   // FY_COOC_MAX_CH given (the item-similarity build has its own default)
     int sup_bounds = 1;                // FY_SUP_BOUNDS: one-cluster pruned jobs bound over <= 64 super-blocks inside the seed pass (0: a bound chunk per user over all blocks)
+    int prep_packed = 1;               // FY_PREP_PACKED: fp16-exact scores ride in the low 16 bits of the prep's sort keys, the three nnz-sized sorts move keys alone
     int shard_prep = 1;                // FY_SHARD_PREP: several ranks, clusters >= ranks: a rank preps its own clusters' ratings alone (fy_prep.hpp)
     int full_walk_sparse = 1;          // FY_FULL_WALK_SPARSE: unpruned clusters whose matrix has more elements than the cluster has pair visits walk full rows (no mirror pass)
     int refine = 1;                    // FY_REFINE: list rows whose score nearly cancels are scored again in fp64 from fp32 head rows (k_refine_rows)
@@ -286,6 +287,9 @@ struct fy_ratings {
     // largest user / item id over ALL entries (-1: none >= 0), found once when the ratings are put into HBM: the jobs pack
     // their sort keys into the bits these ids need
     int32_t max_user = -1, max_item = -1;
+    // every score (of ANY entry; NaN aside) is exactly representable in fp16 -- half stars, integers: found in the same pass; the jobs
+    // then carry the rating inside their 64-bit sort keys (fy_prep.hip, packed mode)
+    bool scores_fp16_exact = false;
     // what the last RM2 job over these ratings built from them and its clustering alone (fy_rm2.hip: RM2Static): a later job
     // with the same clustering starts from it.  Released with the ratings (before their context), by fy_ratings_drop_cache, and
     // by a caching job whose clustering / share does not match it (BEFORE that job builds its own: never two static sets in HBM).

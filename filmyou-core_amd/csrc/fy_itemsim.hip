@@ -965,6 +965,7 @@ static std::unique_ptr<fy_ratings> filter_user_prefs(Context* ctx, const fy_rati
     F->nnz = kept;
     F->max_user = R->max_user;
     F->max_item = R->max_item;
+    F->scores_fp16_exact = R->scores_fp16_exact;
     F->user.alloc(ctx, kept);
     F->item.alloc(ctx, kept);
     F->score.alloc(ctx, kept);

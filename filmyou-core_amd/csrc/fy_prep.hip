@@ -36,6 +36,13 @@ void sort_pairs_u64_u32(Context* c, uint64_t* kin, uint64_t* kout, uint32_t* vin
 void sort_pairs_u64_f32(Context* c, uint64_t* kin, uint64_t* kout, float* vin, float* vout, size_t n, int end_bit, int begin_bit) {
     sort_pairs_impl(c, kin, kout, vin, vout, n, end_bit, begin_bit);
 }
+void sort_keys_u64(Context* c, uint64_t* kin, uint64_t* kout, size_t n, int end_bit, int begin_bit) {
+    if (n == 0) return;
+    size_t bytes = 0;
+    FY_HIP(rocprim::radix_sort_keys(nullptr, bytes, kin, kout, n, (unsigned)begin_bit, (unsigned)end_bit, c->stream));
+    DevBuf<char> tmp(c, bytes);
+    FY_HIP(rocprim::radix_sort_keys(tmp.get(), bytes, kin, kout, n, (unsigned)begin_bit, (unsigned)end_bit, c->stream));
+}
 void sort_pairs_u64_u64(Context* c, uint64_t* kin, uint64_t* kout, uint64_t* vin, uint64_t* vout, size_t n, int end_bit) {
     sort_pairs_impl(c, kin, kout, vin, vout, n, end_bit);
 }
@@ -88,10 +95,13 @@ static inline int grid_for(int64_t n, int block = 256, int cap = 256 * 16) {
 __global__ void k_max_ids(int64_t n, const int32_t* __restrict__ user, const int32_t* __restrict__ item,
                           const float* __restrict__ score, int keep_nonpositive, int32_t* __restrict__ max_ids) {
     int32_t mu = -1, mi = -1;
+    bool not_half = false;      // max_ids[2] = 1: some score (NaN aside: no job keeps one) is not exactly representable in fp16
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
         const float s = score[t];
         if (keep_nonpositive == 2 || (keep_nonpositive ? (s == s) : (s > 0.0f))) { mu = max(mu, user[t]); mi = max(mi, item[t]); }   // 2: every entry
+        if (s == s && __half2float(__float2half(s)) != s) not_half = true;
     }
+    if (__ballot(not_half) && (threadIdx.x & 63) == 0) max_ids[2] = 1;
     for (int o = 32; o > 0; o >>= 1) {
         mu = max(mu, __shfl_down(mu, o, 64));
         mi = max(mi, __shfl_down(mi, o, 64));
@@ -111,14 +121,15 @@ __global__ void k_max_ids(int64_t n, const int32_t* __restrict__ user, const int
 // sort to the end)
 __global__ void k_user_item_keys(int64_t n, const int32_t* __restrict__ user, const int32_t* __restrict__ item,
                                  const float* __restrict__ score, int keep_nonpositive, int ib, uint32_t drop_user,
-                                 uint64_t* __restrict__ keys, unsigned long long* __restrict__ kept, int* __restrict__ err) {
+                                 uint64_t* __restrict__ keys, unsigned long long* __restrict__ kept, int* __restrict__ err, int pb) {
+    // pb = 16 (packed mode: every score is exactly a half): the key carries the rating in its low 16 bits and the sorts move keys alone
     unsigned long long local = 0;
     bool not_half = false, not_pos = false;
     unsigned frac = 0;          // bit 8 + m: some kept rating needs m fractional bits (m = 9: more than eight)
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
         const float s = score[t];
         const bool keep = keep_nonpositive ? (s == s) : (s > 0.0f);   // NaN never passes "score > 0"
-        uint64_t k = (uint64_t)drop_user << ib;
+        uint64_t k = (uint64_t)drop_user << (ib + pb);
         if (keep) {
             const int32_t u = user[t], i = item[t];
             if (u < 0 || i < 0) atomicOr(err, ERR_NEG_ID);
@@ -130,7 +141,7 @@ __global__ void k_user_item_keys(int64_t n, const int32_t* __restrict__ user, co
                 while (m < 9 && t != floorf(t)) { t *= 2.0f; m++; }
                 frac |= 1u << (8 + m);
             }
-            k = ((uint64_t)(uint32_t)u << ib) | (uint32_t)i;
+            k = ((uint64_t)(uint32_t)u << (ib + pb)) | ((uint64_t)(uint32_t)i << pb) | (pb ? (uint64_t)__half_as_ushort(__float2half(s)) : 0ull);
             local++;
         }
         keys[t] = k;
@@ -192,14 +203,16 @@ __global__ void k_scatter_users(int64_t n, const uint64_t* __restrict__ keys, co
 }
 
 // one wave per user: s_u = sum of (double) score in a fixed order (DoubleSumAndCountReducer.java:35-38), degree
-__global__ void k_user_sums(int32_t nU, const int32_t* __restrict__ ustart, const float* __restrict__ score,
+__device__ __forceinline__ float fy_key_rating(uint64_t key) { return __half2float(__ushort_as_half((unsigned short)(key & 0xFFFFu))); }
+__global__ void k_user_sums(int32_t nU, const int32_t* __restrict__ ustart, const float* __restrict__ score, const uint64_t* __restrict__ pkeys,
                             double* __restrict__ usum, int32_t* __restrict__ udeg) {
     const int lane = threadIdx.x & 63;
     const int wpb = blockDim.x >> 6;
     for (int32_t u = blockIdx.x * wpb + (threadIdx.x >> 6); u < nU; u += gridDim.x * wpb) {
         const int32_t a = ustart[u], b = ustart[u + 1];
         double s = 0.0;
-        for (int32_t t = a + lane; t < b; t += 64) s += (double)score[t];
+        if (pkeys) { for (int32_t t = a + lane; t < b; t += 64) s += (double)fy_key_rating(pkeys[t]); }      // (packed mode)
+        else for (int32_t t = a + lane; t < b; t += 64) s += (double)score[t];
         for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
         if (lane == 0) { usum[u] = s; udeg[u] = b - a; }
     }
@@ -288,16 +301,45 @@ __global__ void k_cluster_item_keys(int64_t n, const uint64_t* __restrict__ ukey
     }
 }
 
+// packed mode: ONE 64-bit word per rating = (cluster : raw item : slot of the rater : rating as a half); sorted by its top bits alone
+__global__ void k_cluster_item_keys_packed(int64_t n, const uint64_t* __restrict__ ukeys, const uint32_t* __restrict__ du1,
+                                           const int32_t* __restrict__ ucluster, const int32_t* __restrict__ du2slot, uint64_t* __restrict__ keys, int ib, int sb) {
+    const uint64_t mask = ((uint64_t)1 << ib) - 1;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t du = du1[t] - 1;
+        const uint64_t uk = ukeys[t];
+        keys[t] = ((((uint64_t)(uint32_t)ucluster[du] << ib) | ((uk >> 16) & mask)) << (sb + 16)) | ((uint64_t)(uint32_t)du2slot[du] << 16) | (uk & 0xFFFFu);
+    }
+}
+__global__ void k_heads_packed_dup(int64_t n, const uint64_t* __restrict__ keys, uint32_t* __restrict__ head, int* __restrict__ err, int sb) {
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        const bool same = t > 0 && (keys[t] >> (sb + 16)) == (keys[t - 1] >> (sb + 16));
+        head[t] = !same;
+        if (same && (keys[t] >> 16) == (keys[t - 1] >> 16)) atomicOr(err, ERR_DUP);      // same column, same slot
+    }
+}
+__global__ void k_fill_csc_packed(int64_t n, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ pr1, int sb,
+                                  int32_t* __restrict__ csc_slot, float* __restrict__ csc_r, int32_t* __restrict__ csc_pair) {
+    const uint64_t smask = ((uint64_t)1 << sb) - 1;
+    for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t k = keys[q];
+        csc_slot[q] = (int32_t)((k >> 16) & smask);
+        csc_r[q] = fy_key_rating(k);
+        csc_pair[q] = (int32_t)(pr1[q] - 1);
+    }
+}
+
 __global__ void k_scatter_pairs(int64_t n, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ head,
                                 const uint32_t* __restrict__ pr1, int32_t* __restrict__ pair_cluster,
-                                int32_t* __restrict__ pair_item, int32_t* __restrict__ pair_start, int ib) {
+                                int32_t* __restrict__ pair_item, int32_t* __restrict__ pair_start, int ib, int low /* packed mode: payload bits below (cluster : item) */) {
     const uint64_t mask = ((uint64_t)1 << ib) - 1;
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x)
         if (head[t]) {
             const uint32_t p = pr1[t] - 1;
-            const int32_t c = (int32_t)(keys[t] >> ib);
+            const uint64_t k = keys[t] >> low;
+            const int32_t c = (int32_t)(k >> ib);
             pair_cluster[p] = c;
-            pair_item[p] = (int32_t)(uint32_t)(keys[t] & mask);
+            pair_item[p] = (int32_t)(uint32_t)(k & mask);
             pair_start[p] = (int32_t)t;
         }
 }
@@ -397,6 +439,24 @@ __global__ void k_csr_keys_ranked(int64_t n, const int32_t* __restrict__ csc_slo
     }
 }
 
+__global__ void k_csr_keys_ranked_packed(int64_t n, const int32_t* __restrict__ csc_slot, const int32_t* __restrict__ csc_pair, const float* __restrict__ csc_r,
+                                         const int32_t* __restrict__ pair_rank, const int32_t* __restrict__ pair_cluster, const int32_t* __restrict__ pcstart,
+                                         const int32_t* __restrict__ pair_start, const int32_t* __restrict__ rank_start, uint64_t* __restrict__ keys, int rb) {
+    for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t p = csc_pair[q];
+        const int32_t idx = pair_rank[p];
+        const int64_t dst = (int64_t)rank_start[pcstart[pair_cluster[p]] + idx] + (q - pair_start[p]);
+        keys[dst] = ((((uint64_t)(uint32_t)csc_slot[q] << rb) | (uint32_t)idx) << 16) | (uint64_t)__half_as_ushort(__float2half(csc_r[q]));
+    }
+}
+__global__ void k_csr_unpack(int64_t n, const uint64_t* __restrict__ keys, int32_t* __restrict__ idx, float* __restrict__ r, int rb) {
+    const uint64_t mask = ((uint64_t)1 << rb) - 1;
+    for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t k = keys[q];
+        idx[q] = (int32_t)(uint32_t)((k >> 16) & mask);
+        r[q] = fy_key_rating(k);
+    }
+}
 __global__ void k_low_bits(int64_t n, const uint64_t* __restrict__ keys, int32_t* __restrict__ out, int rb) {
     const uint64_t mask = ((uint64_t)1 << rb) - 1;
     for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x)
@@ -461,16 +521,19 @@ void gather_to_host_i64(Context* ctx, const int64_t* src, const std::vector<int3
 // ---------------------------------------------------------------- build
 void ratings_id_bounds(Context* ctx, fy_ratings* R) {
     R->max_user = R->max_item = -1;
+    R->scores_fp16_exact = false;
     if (R->nnz == 0) return;
-    DevBuf<int32_t> max_ids(ctx, 2);
+    DevBuf<int32_t> max_ids(ctx, 3);
     FY_HIP(hipMemsetAsync(max_ids.get(), 0xFF, 2 * sizeof(int32_t), ctx->stream));   // -1
+    FY_HIP(hipMemsetAsync(max_ids.get() + 2, 0, sizeof(int32_t), ctx->stream));
     k_max_ids<<<grid_for(R->nnz), 256, 0, ctx->stream>>>(R->nnz, R->user.get(), R->item.get(), R->score.get(), 2, max_ids.get());
     FY_KERNEL_CHECK();
-    int32_t h[2];
-    d2h(ctx, h, max_ids.get(), 2);
+    int32_t h[3];
+    d2h(ctx, h, max_ids.get(), 3);
     sync(ctx);
     R->max_user = h[0];
     R->max_item = h[1];
+    R->scores_fp16_exact = h[2] == 0;
 }
 
 // ---------------------------------------------------------------- sharded prep: the owned clusters' ratings alone
@@ -681,6 +744,7 @@ bool shard_ratings_by_cluster(Context* ctx, const fy_ratings* R, int32_t K, int6
     mine.nnz = kept;
     mine.max_user = R->max_user;
     mine.max_item = R->max_item;
+    mine.scores_fp16_exact = R->scores_fp16_exact;
     mine.user.alloc(ctx, (size_t)kept);
     mine.item.alloc(ctx, (size_t)kept);
     mine.score.alloc(ctx, (size_t)kept);
@@ -708,9 +772,20 @@ void build_structure(Context* ctx, const fy_ratings* R, int32_t K, int64_t n_map
 
     // ---- sort #1: user-major order, duplicates / negative ids detected
     DevBuf<uint64_t> k1a(ctx, n_in), k1b(ctx, n_in);
-    DevBuf<float> sc_um(ctx, n_in);
+    DevBuf<float> sc_um;
     auto bits_for = [](uint64_t v) { int b = 0; while (v) { b++; v >>= 1; } return b; };   // bits that hold every value <= v
     int ib = 1;   // bits of the item field of the sort keys
+    // PACKED mode (round 4): every score is exactly a half (found when the ratings entered HBM) and (user : item), (cluster : item : slot)
+    // and (slot : index) each leave 16 bits of a 64-bit word free: the rating rides in the low 16 bits of every sort key and the three
+    // nnz-sized sorts move KEYS ALONE -- 16 bytes per rating and pass instead of 24 / 32 / 24.
+    int pb = 0;
+    if (n_in) {
+        const int ib0 = std::max(1, bits_for((uint64_t)std::max(0, R->max_item))), ub0 = std::max(1, bits_for((uint64_t)(R->max_user + 1)));
+        const int kb0 = bits_for((uint64_t)std::max(0, K - 1));
+        // (slots and item indices never need more bits than the user / item ids they number)
+        if (ctx->tune.prep_packed && R->scores_fp16_exact && ib0 + ub0 + 16 <= 64 && kb0 + ib0 + ub0 + 16 <= 64) pb = 16;
+    }
+    if (!pb) sc_um.alloc(ctx, n_in);
     if (n_in) {
         // (the id bounds were found when the ratings entered HBM, fy_ratings_create: a property of the container like nnz)
         const int32_t hmax[2] = {R->max_user, R->max_item};
@@ -718,12 +793,13 @@ void build_structure(Context* ctx, const fy_ratings* R, int32_t K, int64_t n_map
         ib = std::max(1, bits_for((uint64_t)std::max(0, hmax[1])));
         const int ub = std::max(1, bits_for(drop_user));
         k_user_item_keys<<<grid_for(n_in), 256, 0, st>>>(n_in, R->user.get(), R->item.get(), R->score.get(),
-                                                          keep_nonpositive ? 1 : 0, ib, drop_user, k1a.get(), kept.get(), err.get());
+                                                          keep_nonpositive ? 1 : 0, ib, drop_user, k1a.get(), kept.get(), err.get(), pb);
         FY_KERNEL_CHECK();
         // by the USER bits alone (a stable sort: inside a user the ratings keep the order of the input): 3 radix passes instead of 5 at
         // ML-25M shape.  Nothing needs the items of a user in order here -- the CSR is sorted by (slot, item index) below -- except the
         // duplicate check, which moved behind the (cluster, item) sort, where one user's two ratings of an item are neighbours too.
-        sort_pairs_u64_f32(ctx, k1a.get(), k1b.get(), const_cast<float*>(R->score.get()), sc_um.get(), n_in, std::min(64, ib + ub), ib);
+        if (pb) sort_keys_u64(ctx, k1a.get(), k1b.get(), n_in, std::min(64, ib + pb + ub), ib + pb);
+        else sort_pairs_u64_f32(ctx, k1a.get(), k1b.get(), const_cast<float*>(R->score.get()), sc_um.get(), n_in, std::min(64, ib + ub), ib);
     }
     // (host round trips cost ~30 us each plus the bubble behind them: what can be read together is read together)
     unsigned long long h_kept = 0;
@@ -754,7 +830,7 @@ void build_structure(Context* ctx, const fy_ratings* R, int32_t K, int64_t n_map
     uint64_t* ukeys = k1b.get();   // user-major (items of a user in input order), first nnz entries are the kept ratings
 
     DevBuf<uint32_t> head(ctx, nnz), du1(ctx, nnz);
-    k_heads_hi32<<<grid_for(nnz), 256, 0, st>>>(nnz, ukeys, head.get(), 0, err.get(), ib);
+    k_heads_hi32<<<grid_for(nnz), 256, 0, st>>>(nnz, ukeys, head.get(), 0, err.get(), ib + pb);
     FY_KERNEL_CHECK();
     inclusive_scan_u32(ctx, head.get(), du1.get(), nnz);
     const int32_t nU = (int32_t)fetch(ctx, du1.get() + (nnz - 1));
@@ -762,13 +838,13 @@ void build_structure(Context* ctx, const fy_ratings* R, int32_t K, int64_t n_map
 
     P.uid.alloc(ctx, nU);
     DevBuf<int32_t> ustart(ctx, (size_t)nU + 1);
-    k_scatter_users<<<grid_for(nnz), 256, 0, st>>>(nnz, ukeys, head.get(), du1.get(), P.uid.get(), ustart.get(), ib);
+    k_scatter_users<<<grid_for(nnz), 256, 0, st>>>(nnz, ukeys, head.get(), du1.get(), P.uid.get(), ustart.get(), ib + pb);
     FY_KERNEL_CHECK();
     k_set_i32<<<1, 1, 0, st>>>(ustart.get() + nU, (int32_t)nnz);
     FY_KERNEL_CHECK();
     P.usum.alloc(ctx, nU);
     P.udeg.alloc(ctx, nU);
-    k_user_sums<<<grid_for((int64_t)nU * 64, 256), 256, 0, st>>>(nU, ustart.get(), sc_um.get(), P.usum.get(), P.udeg.get());
+    k_user_sums<<<grid_for((int64_t)nU * 64, 256), 256, 0, st>>>(nU, ustart.get(), sc_um.get(), pb ? ukeys : nullptr, P.usum.get(), P.udeg.get());
     FY_KERNEL_CHECK();
 
     // ---- cluster routing
@@ -848,8 +924,15 @@ void build_structure(Context* ctx, const fy_ratings* R, int32_t K, int64_t n_map
 
     // ---- sort #3: (cluster, item) order = the CSC
     DevBuf<uint64_t> k3b(ctx, nnz);
-    DevBuf<uint64_t> v_sorted(ctx, nnz);
-    {
+    DevBuf<uint64_t> v_sorted;
+    const int sb = std::max(1, bits_for((uint64_t)(nU - 1)));      // bits of a slot
+    if (pb) {
+        DevBuf<uint64_t> k3a(ctx, nnz);
+        k_cluster_item_keys_packed<<<grid_for(nnz), 256, 0, st>>>(nnz, ukeys, du1.get(), P.ucluster.get(), P.du2slot.get(), k3a.get(), ib, sb);
+        FY_KERNEL_CHECK();
+        sort_keys_u64(ctx, k3a.get(), k3b.get(), nnz, std::min(64, sb + 16 + ib + bits_for((uint64_t)(K - 1))), sb + 16);
+    } else {
+        v_sorted.alloc(ctx, nnz);
         DevBuf<uint64_t> k3a(ctx, nnz), v3a(ctx, nnz);
         k_cluster_item_keys<<<grid_for(nnz), 256, 0, st>>>(nnz, ukeys, du1.get(), P.ucluster.get(), P.du2slot.get(), sc_um.get(), k3a.get(),
                                                             v3a.get(), ib);
@@ -857,7 +940,8 @@ void build_structure(Context* ctx, const fy_ratings* R, int32_t K, int64_t n_map
         sort_pairs_u64_u64(ctx, k3a.get(), k3b.get(), v3a.get(), v_sorted.get(), nnz, std::min(64, ib + bits_for((uint64_t)(K - 1))));
     }
     DevBuf<uint32_t> pr1(ctx, nnz);
-    k_heads_full_dup<<<grid_for(nnz), 256, 0, st>>>(nnz, k3b.get(), v_sorted.get(), head.get(), err.get());
+    if (pb) k_heads_packed_dup<<<grid_for(nnz), 256, 0, st>>>(nnz, k3b.get(), head.get(), err.get(), sb);
+    else k_heads_full_dup<<<grid_for(nnz), 256, 0, st>>>(nnz, k3b.get(), v_sorted.get(), head.get(), err.get());
     FY_KERNEL_CHECK();
     inclusive_scan_u32(ctx, head.get(), pr1.get(), nnz);
     uint32_t h_nP = 0;
@@ -871,7 +955,7 @@ void build_structure(Context* ctx, const fy_ratings* R, int32_t K, int64_t n_map
     P.pair_start.alloc(ctx, (size_t)nP + 1);
     DevBuf<int32_t> pair_item(ctx, nP), pcount(ctx, (size_t)K);
     k_scatter_pairs<<<grid_for(nnz), 256, 0, st>>>(nnz, k3b.get(), head.get(), pr1.get(), P.pair_cluster.get(),
-                                                    pair_item.get(), P.pair_start.get(), ib);
+                                                    pair_item.get(), P.pair_start.get(), ib, pb ? sb + 16 : 0);
     FY_KERNEL_CHECK();
     k_cluster_pair_counts<<<grid_for(K), 256, 0, st>>>(K, nP, P.pair_cluster.get(), pcount.get());
     FY_KERNEL_CHECK();
@@ -911,7 +995,8 @@ void build_structure(Context* ctx, const fy_ratings* R, int32_t K, int64_t n_map
     P.csc_slot.alloc(ctx, nnz);
     P.csc_r.alloc(ctx, nnz);
     P.csc_pair.alloc(ctx, nnz);
-    k_fill_csc<<<grid_for(nnz), 256, 0, st>>>(nnz, v_sorted.get(), pr1.get(), P.csc_slot.get(), P.csc_r.get(), P.csc_pair.get());
+    if (pb) k_fill_csc_packed<<<grid_for(nnz), 256, 0, st>>>(nnz, k3b.get(), pr1.get(), sb, P.csc_slot.get(), P.csc_r.get(), P.csc_pair.get());
+    else k_fill_csc<<<grid_for(nnz), 256, 0, st>>>(nnz, v_sorted.get(), pr1.get(), P.csc_slot.get(), P.csc_r.get(), P.csc_pair.get());
     FY_KERNEL_CHECK();
 
     // ---- popularity rank inside the cluster = compact item index
@@ -938,18 +1023,27 @@ void build_structure(Context* ctx, const fy_ratings* R, int32_t K, int64_t n_map
         // The columns are first moved into rank order (a permutation of whole columns: coalesced), then ONE stable sort by the slot
         // bits alone puts the rows together with their indices ascending: 3 radix passes instead of 5 over (slot, index) at ML-25M shape.
         DevBuf<int32_t> rank_cnt(ctx, (size_t)nP + 1), rank_start(ctx, (size_t)nP + 1);
-        DevBuf<float> r_ranked(ctx, nnz);
         k_rank_counts<<<grid_for((int64_t)nP + 1), 256, 0, st>>>(nP, P.rank_pair.get(), P.pair_start.get(), rank_cnt.get());
         FY_KERNEL_CHECK();
         exclusive_scan_i32(ctx, rank_cnt.get(), rank_start.get(), (size_t)nP + 1);
-        k_csr_keys_ranked<<<grid_for(nnz), 256, 0, st>>>(nnz, P.csc_slot.get(), P.csc_pair.get(), P.csc_r.get(), P.pair_rank.get(), P.pair_cluster.get(),
-                                                          P.d_pcstart.get(), P.pair_start.get(), rank_start.get(), ka.get(), r_ranked.get(), rb);
-        FY_KERNEL_CHECK();
         P.csr_r.alloc(ctx, nnz);
-        sort_pairs_u64_f32(ctx, ka.get(), kb.get(), r_ranked.get(), P.csr_r.get(), nnz, std::min(64, rb + std::max(1, bits_for((uint64_t)(nU - 1)))), rb);
         P.csr_idx.alloc(ctx, nnz);
-        k_low_bits<<<grid_for(nnz), 256, 0, st>>>(nnz, kb.get(), P.csr_idx.get(), rb);
-        FY_KERNEL_CHECK();
+        if (pb && rb + sb + 16 <= 64) {
+            k_csr_keys_ranked_packed<<<grid_for(nnz), 256, 0, st>>>(nnz, P.csc_slot.get(), P.csc_pair.get(), P.csc_r.get(), P.pair_rank.get(), P.pair_cluster.get(),
+                                                                     P.d_pcstart.get(), P.pair_start.get(), rank_start.get(), ka.get(), rb);
+            FY_KERNEL_CHECK();
+            sort_keys_u64(ctx, ka.get(), kb.get(), nnz, std::min(64, 16 + rb + sb), 16 + rb);
+            k_csr_unpack<<<grid_for(nnz), 256, 0, st>>>(nnz, kb.get(), P.csr_idx.get(), P.csr_r.get(), rb);
+            FY_KERNEL_CHECK();
+        } else {
+            DevBuf<float> r_ranked(ctx, nnz);
+            k_csr_keys_ranked<<<grid_for(nnz), 256, 0, st>>>(nnz, P.csc_slot.get(), P.csc_pair.get(), P.csc_r.get(), P.pair_rank.get(), P.pair_cluster.get(),
+                                                              P.d_pcstart.get(), P.pair_start.get(), rank_start.get(), ka.get(), r_ranked.get(), rb);
+            FY_KERNEL_CHECK();
+            sort_pairs_u64_f32(ctx, ka.get(), kb.get(), r_ranked.get(), P.csr_r.get(), nnz, std::min(64, rb + sb), rb);
+            k_low_bits<<<grid_for(nnz), 256, 0, st>>>(nnz, kb.get(), P.csr_idx.get(), rb);
+            FY_KERNEL_CHECK();
+        }
     }
 
     // ---- row pointers, work model

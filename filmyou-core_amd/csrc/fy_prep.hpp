@@ -72,6 +72,7 @@ void rank_slot_range(const Prepared& P, int rank, int world, int32_t& lo, int32_
 // generic device helpers implemented with rocPRIM (radix sort / scan), all on ctx->stream
 void sort_pairs_u64_u32(Context*, uint64_t* kin, uint64_t* kout, uint32_t* vin, uint32_t* vout, size_t n, int end_bit = 64);
 void sort_pairs_u64_f32(Context*, uint64_t* kin, uint64_t* kout, float* vin, float* vout, size_t n, int end_bit = 64, int begin_bit = 0);
+void sort_keys_u64(Context*, uint64_t* kin, uint64_t* kout, size_t n, int end_bit = 64, int begin_bit = 0);
 void sort_pairs_u64_u64(Context*, uint64_t* kin, uint64_t* kout, uint64_t* vin, uint64_t* vout, size_t n, int end_bit = 64);
 void inclusive_scan_u32(Context*, const uint32_t* in, uint32_t* out, size_t n);
 // scratch: a buffer of the caller for the scan's temporary storage (grown when too small); it must outlive the work queued on st

@@ -285,6 +285,45 @@ def test_two_runs_give_bit_identical_rows():
     ctx.close()
 
 
+@pytest.mark.parametrize("K", [1, 6])
+def test_prep_with_the_ratings_inside_or_beside_the_sort_keys(monkeypatch, K):
+    """fy_prep's packed mode (scores exactly representable in fp16 ride in the low 16 bits of the three sort keys, the sorts move keys
+    alone) against the general mode (rating as the sort's value): same structure, so bit-identical rows and statistics; a data set
+    with ONE score that is no half takes the general mode by itself and still agrees with the oracle."""
+    P = pkg()
+    S = synth()
+    u, i, s, facts = S.generate("ml100k", seed_offset=9)
+    u, i, s = u.numpy(), i.numpy(), (np.round(s.numpy() * 2) / 2).astype(np.float32)
+    uu = np.unique(u)
+    conf = P.Configuration()
+    conf.set("lambda", "0.1")
+    conf.setInt("numberOfItems", facts["n_items"])
+    conf.setInt("numberOfClusters", K)
+    conf.setInt("numberOfRecommendations", 25)
+    clustering = (uu, S.hash_clustering(uu, K))
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("FY_PREP_PACKED", mode)
+        ctx = P.Context(0)
+        rec = P.RM2Job(conf, ctx).run((u, i, s), clustering=clustering)
+        out[mode] = (rec.rows(), rec.sums())
+        ctx.close()
+    for k in ("user", "item", "cluster"):
+        np.testing.assert_array_equal(out["1"][0][k], out["0"][0][k])
+    assert out["1"][0]["score"].tobytes() == out["0"][0]["score"].tobytes()
+    for k in ("user_id", "user_sum", "item_id", "item_coll"):
+        np.testing.assert_array_equal(out["1"][1][k], out["0"][1][k])
+    monkeypatch.delenv("FY_PREP_PACKED")
+    s2 = s.copy()
+    s2[7] = np.float32(3.3)          # not a half: the whole data set takes the general mode
+    ctx = P.Context(0)
+    rows = P.RM2Job(conf, ctx).run((u, i, s2), clustering=clustering).rows()
+    ctx.close()
+    ref = oracle.rm2(u, i, s2, lam=0.1, number_of_items=facts["n_items"], number_of_recommendations=1 << 30, number_of_clusters=K,
+                     map_user=clustering[0], map_cluster=clustering[1], n_threads=8)
+    assert_topn_matches(rows, ref, 25)
+
+
 def test_two_ranks_from_the_references_file_layout(tmp_path, rm_golden):
     """RM2Job.run_from_files with world = 2 (two threads, one context each, ThreadCollectives): every rank writes ITS part file into the
     shared output directory and nobody deletes it, rank 0 alone wipes <directory>/rm2 and writes the global statistics once; the
