@@ -330,7 +330,7 @@ def main():
         "lists_per_s": total_users / (elapsed / a.steps), "log_terms_per_step": total_terms,
         "phase_ms_rank0": phases, "datagen_s": gen_s,
         "job_stats_rank0": {k: int(st[k]) for k in ("n_clusters_nonempty", "cooc_launches", "score_launches", "panel_clusters", "blocks_total",
-                                                     "blocks_survived", "stray_blocks", "bound_repairs", "prune_fallbacks", "topn_select_users")},
+                                                     "blocks_survived", "stray_blocks", "bound_repairs", "prune_fallbacks", "topn_select_users", "rows_refined")},
         "roofline": roofline, "roofline_other_kernel": other, "roofline_phases": roofline_phases,
         "kernel_source_rev": rev,
     }
@@ -385,7 +385,7 @@ def main():
                                                                  if (s2[-1]["blocks_total"] == 0 and np.mean([x["ms_score"] for x in s2]) > 0) else None,
                              "log_terms_evaluated": int(s2[-1]["log_terms_evaluated"]) if s2[-1]["blocks_total"] else int(s2[-1]["log_terms"]),
                              "blocks_survived_frac": (s2[-1]["blocks_survived"] / s2[-1]["blocks_total"]) if s2[-1]["blocks_total"] else None,
-                             "stray_blocks": int(s2[-1]["stray_blocks"]), "bound_repairs": int(s2[-1]["bound_repairs"])}
+                             "stray_blocks": int(s2[-1]["stray_blocks"]), "bound_repairs": int(s2[-1]["bound_repairs"]), "rows_refined": int(s2[-1]["rows_refined"])}
             except RuntimeError as e:
                 reg[name] = {"error": str(e)}
         out["reference_regime"] = reg
