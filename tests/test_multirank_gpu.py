@@ -74,6 +74,91 @@ def test_a_failure_only_one_rank_can_see_fails_every_rank(ctx):
     ratings.close()
 
 
+def test_sharded_prep_with_ragged_input(ctx):
+    """Sharded prep on input that is not tidy: users the clustering map does not name (cluster 0, quirk Q2), map entries of users who
+    rated nothing, a repeated map entry (the later one wins), clusters nobody is routed to, ratings <= 0 (dropped), scores that are no
+    halves (the prep's general mode) -- the ranks' rows together are the one-rank rows, bit for bit, and the clusteringCount is checked
+    by the rank that owns the cluster."""
+    P, S = pkg(), synth()
+    u, i, s, facts = S.generate("ml100k", seed_offset=3)
+    u, i, s = u.numpy().copy(), i.numpy().copy(), s.numpy().copy()
+    s[::17] = 0.0
+    s[5::23] = -1.0
+    s[3] = np.float32(2.7)
+    uu = np.unique(u)
+    K, world = 11, 4
+    named = uu[uu % 5 != 0]                                  # a fifth of the users is not in the map
+    cl = S.hash_clustering(named, K)
+    cl[cl == 7] = 2                                          # nobody in cluster 7
+    cl[cl == 9] = 3                                          # nor in 9
+    map_user = np.concatenate([named, [int(uu.max()) + 50, int(uu.max()) + 51], named[:3]]).astype(np.int32)
+    map_cluster = np.concatenate([cl, [7, 4], [(int(cl[0]) + 1) % 7, int(cl[1]), int(cl[2])]]).astype(np.int32)
+    clustering = (map_user, map_cluster)
+    conf = P.Configuration()
+    conf.set("lambda", "0.2")
+    conf.setInt("numberOfItems", facts["n_items"])
+    conf.setInt("numberOfClusters", K)
+    conf.setInt("numberOfRecommendations", 15)
+    ratings = P.Ratings(ctx, u, i, s)
+    job = P.RM2Job(conf, ctx)
+    single = job.run(ratings, clustering=clustering)
+    # a valid clusteringCount file: the rated users (some rating > 0) per cluster, by the map's own rules
+    rows1 = single.rows()
+    route = {}
+    for mu, mc in zip(map_user.tolist(), map_cluster.tolist()):
+        route[mu] = mc                                       # a later entry of a user wins
+    count = np.zeros(K, dtype=np.int32)
+    for usr in np.unique(u[s > 0]).tolist():
+        count[route.get(usr, 0)] += 1
+    assert count[7] == 0 and count[9] == 0 and (count > 0).sum() >= world
+    prepared = [job.prepare(ratings, clustering=clustering, clustering_count=count, rank=r, world=world) for r in range(world)]
+    assert all(pr.stats_layout()[1] > 0 for pr in prepared)      # sharded
+    parts = []
+    for pr in prepared:
+        ptr, n = pr.partial_stats()
+        parts.append(device_doubles(ptr, n).clone())
+    torch.cuda.synchronize()
+    gathered = torch.cat(parts).contiguous()
+    results = []
+    for pr in prepared:
+        pr.set_global_stats(gathered.data_ptr())
+        results.append(pr.score())
+        pr.close()
+    rows = {k: np.concatenate([r.rows()[k] for r in results]) for k in ("user", "item", "score", "cluster")}
+    order = np.lexsort((rows["item"], rows["user"]))
+    order1 = np.lexsort((rows1["item"], rows1["user"]))
+    for k in ("user", "item", "cluster"):
+        np.testing.assert_array_equal(rows[k][order], rows1[k][order1])
+    # (one score is no half, so the item sums are fp64 sums of inexact terms: summed per rank and then over ranks they may differ from the
+    # one-rank sum in the last bit, and so may a score -- as in any exchange of partial sums; with half stars everything is bit-identical,
+    # test_sharded_equals_single)
+    a_, b_ = rows["score"][order].astype(np.float64), rows1["score"][order1].astype(np.float64)
+    assert np.max(np.abs(a_ - b_) / np.abs(b_)) < 1e-6
+    for r in results:
+        if r.size:
+            for k2 in ("user_id", "item_id"):
+                np.testing.assert_array_equal(r.sums()[k2], single.sums()[k2])
+            for k2 in ("user_sum", "item_coll", "total_sum"):
+                np.testing.assert_allclose(r.sums()[k2], single.sums()[k2], rtol=1e-14, atol=0)
+    # a clusteringCount that is wrong for ONE cluster: only its owner can see it, every rank fails with FY_ERR_CLUSTER_COUNT
+    bad = count.copy()
+    bad[int(np.flatnonzero(count)[-1])] += 1
+    prepared = [job.prepare(ratings, clustering=clustering, clustering_count=bad, rank=r, world=world, cache=False) for r in range(world)]
+    parts = []
+    for pr in prepared:
+        ptr, n = pr.partial_stats()
+        parts.append(device_doubles(ptr, n).clone())
+    torch.cuda.synchronize()
+    assert sorted(float(p[-1]) for p in parts) == [0.0] * (world - 1) + [6.0]
+    gathered = torch.cat(parts).contiguous()
+    for pr in prepared:
+        with pytest.raises(P.FilmYouError) as e:
+            pr.set_global_stats(gathered.data_ptr())
+        assert e.value.code == -6
+        pr.close()
+    ratings.close()
+
+
 def test_sharded_panel_mode(ctx, monkeypatch):
     """The many-cluster (column-panel) path with the users of every cluster split over three ranks: each rank builds the
     cluster's panel and bounds for its own users (forced onto small data like tests/test_pruned_coop_gpu.py does)."""
