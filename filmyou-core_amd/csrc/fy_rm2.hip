@@ -269,10 +269,11 @@ __global__ void k_item_coll(int32_t nI, const double* __restrict__ stats, double
 // p(i|C) of every (cluster, item) in rank order, a = l * p, b rounded once to fp32
 __global__ void k_pair_p(int32_t nP, const int32_t* __restrict__ rank_pair, const int32_t* __restrict__ pair_di,
                          const double* __restrict__ icoll, double lambda, const double* __restrict__ b_rank,
-                         double* __restrict__ p_rank, float* __restrict__ a_rank, float* __restrict__ b_rank32) {
+                         double* __restrict__ p_rank, float* __restrict__ a_rank, float* __restrict__ b_rank32, double2* __restrict__ pb_rank) {
     for (int32_t pos = blockIdx.x * blockDim.x + threadIdx.x; pos < nP; pos += gridDim.x * blockDim.x) {
         const double p = icoll[pair_di[rank_pair[pos]]];
         p_rank[pos] = p;
+        pb_rank[pos] = make_double2(p, b_rank[pos]);      // (p, b) side by side: k_csr_values gathers both with one 16-byte load per rating
         a_rank[pos] = (float)(lambda * p);
         b_rank32[pos] = (float)b_rank[pos];
     }
@@ -362,7 +363,7 @@ __global__ void k_csr_values(int32_t nU, const int32_t* __restrict__ rowptr, con
                              const float* __restrict__ csr_r, const int32_t* __restrict__ slot2du,
                              const int32_t* __restrict__ ucluster, const double* __restrict__ usum,
                              const int32_t* __restrict__ csize, const int32_t* __restrict__ pcstart,
-                             const double* __restrict__ p_rank, const double* __restrict__ b_rank, double lambda,
+                             const double2* __restrict__ pb_rank, double lambda,
                              const float* __restrict__ gscale /* [cluster]: 2^-c of the packed matrix format, 1 for fp32 rows */,
                              float* __restrict__ csr_x, float* __restrict__ csr_e, float* __restrict__ csr_q) {
     const int lane = threadIdx.x & 63;
@@ -377,11 +378,12 @@ __global__ void k_csr_values(int32_t nU, const int32_t* __restrict__ rowptr, con
         for (int32_t f = rowptr[s] + lane; f < rowptr[s + 1]; f += 64) {
             const int32_t j = csr_idx[f];
             const double x = (double)csr_r[f] / sum;
-            double e = (1.0 - lambda) * (b_rank[pb + j] - x) + lambda * Uc1 * p_rank[pb + j];
+            const double2 pbj = pb_rank[pb + j];       // (p(j|C), b_j)
+            double e = (1.0 - lambda) * (pbj.y - x) + lambda * Uc1 * pbj.x;
             if (!(e > 0.0)) e = 0.0;
             csr_x[f] = (float)x;
             csr_e[f] = (float)(e * gs);
-            csr_q[f] = (float)(lambda * (1.0 - lambda) * p_rank[pb + j] * gs);     // q_j: the rank-one part of a term is q_j b_i
+            csr_q[f] = (float)(lambda * (1.0 - lambda) * pbj.x * gs);     // q_j: the rank-one part of a term is q_j b_i
         }
     }
 }
@@ -475,34 +477,44 @@ struct Half {
 };
 __device__ __forceinline__ void seg_counts_body(const int32_t* __restrict__ csc_slot, const int32_t* __restrict__ chunk_off, int32_t slot_base,
                                                 int32_t q0, int32_t nq, int32_t nch, int32_t* __restrict__ cnt, const Half& H) {
-    // one thread per CSC entry: the rater's nch + 1 chunk offsets are one contiguous gather
+    // one thread per CSC entry: the rater's nch + 1 chunk offsets are one contiguous gather -- ONE 16-byte load where a row of the
+    // table is four offsets (three chunks: ML-25M shape).  Round 4: the kernel ran at 72 % of the L2's request rate (6.5 requests per
+    // entry, TCP_TCC_READ_REQ), most of them the same 16 bytes fetched offset by offset from 64 different rows per wave instruction.
+    const bool row4 = nch == 3 && (reinterpret_cast<uintptr_t>(chunk_off) & 15) == 0;      // (kernel-uniform)
+    const bool row2 = nch == 1 && (reinterpret_cast<uintptr_t>(chunk_off) & 7) == 0;       // one chunk (Netflix shape): two offsets, 8 bytes
     for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q <= nq; q += (int64_t)gridDim.x * blockDim.x) {
         const bool live = q < nq && !(H.only_rows && H.only_rows[q0 + q] < H.only_from);
         const int32_t* co = live ? chunk_off + (int64_t)(csc_slot[q0 + q] - slot_base) * (nch + 1) : nullptr;
-        int32_t prev = live ? co[0] : 0;
+        int4 c4 = make_int4(0, 0, 0, 0);
+        if (live && row4) c4 = *reinterpret_cast<const int4*>(co);
+        if (live && row2) { const int2 v = *reinterpret_cast<const int2*>(co); c4.x = v.x; c4.y = v.y; }
+        auto CO = [&](int k) -> int32_t { return (row4 || row2) ? (k == 0 ? c4.x : k == 1 ? c4.y : k == 2 ? c4.z : c4.w) : co[k]; };
+        int32_t prev = live ? CO(0) : 0;
         int32_t own = -1, behind = 0, climit = nch;
-        if (live && H.row_of_entry && H.lim_chunks > 0 && H.row_of_entry[q0 + q] >= H.lim_from) climit = H.lim_chunks;
-        if (live && H.row_of_entry && (H.sym_rows == 0 || H.row_of_entry[q0 + q] < H.sym_rows)) {
-            const int32_t r = H.row_of_entry[q0 + q];
+        const int32_t r_e = (live && H.row_of_entry) ? H.row_of_entry[q0 + q] : 0;
+        if (live && H.row_of_entry && H.lim_chunks > 0 && r_e >= H.lim_from) climit = H.lim_chunks;
+        if (live && H.row_of_entry && (H.sym_rows == 0 || r_e < H.sym_rows)) {
+            const int32_t r = r_e;
             own = r / H.CH;
             // Where does the slice behind (v, i) start?  Exactly: behind the position of i in the rater's row -- a binary search over the
             // row slice in the 100-400 MB csr_idx per CSC entry (1.6 ms of the ML-25M job, 10.6 ms at Netflix shape, round 2).  Now: the
             // last aligned CSR position inside the slice whose entry is <= r, found in the SAMPLES (every 2^FY_SAMPLE_SHIFT-th entry: a few MB,
             // cache-resident, a handful of probes); the few entries between it and i are masked by the row kernel (column <= row).
             constexpr int SS = FY_SAMPLE_SHIFT;
-            int32_t klo = (co[own] + (1 << SS) - 1) >> SS, khi = (co[own + 1] + (1 << SS) - 1) >> SS;      // samples inside the slice: [klo, khi)
+            const int32_t co_own = CO(own), co_next = CO(own + 1);
+            int32_t klo = (co_own + (1 << SS) - 1) >> SS, khi = (co_next + (1 << SS) - 1) >> SS;      // samples inside the slice: [klo, khi)
             while (klo < khi) {                                                    // first k with samp[k] > r
                 const int32_t mid = (klo + khi) >> 1;
                 if (H.samp[mid] <= r) klo = mid + 1; else khi = mid;
             }
-            const int32_t lo = max(co[own], (klo - 1) << SS);                     // (no sample <= r inside the slice: its beginning)
+            const int32_t lo = max(co_own, (klo - 1) << SS);                      // (no sample <= r inside the slice: its beginning)
             behind = lo;
             H.start[q] = lo;
         }
         for (int32_t ch = 0; ch < nch; ch++) {
             int32_t n = 0;
             if (live) {
-                const int32_t next = co[ch + 1];
+                const int32_t next = CO(ch + 1);
                 const int32_t first = ch == own ? behind : prev;
                 n = (ch < own || ch >= climit) ? 0 : (next - first + 63) >> 6;
                 prev = next;
@@ -541,54 +553,93 @@ __global__ void k_seg_counts_multi(const SegDesc* __restrict__ D, const int32_t*
 __device__ __forceinline__ void seg_fill_body(const int32_t* __restrict__ csc_slot, const float* __restrict__ csc_w, const int32_t* __restrict__ chunk_off,
                                               int32_t slot_base, int32_t q0, int32_t nq, int32_t nch, const int32_t* __restrict__ ptr,
                                               int2* __restrict__ seg, float* __restrict__ seg_w, const Half& H) {
+    // A wave takes the group's entries through up to CB chunks at once: what is per ENTRY (rater slot, row, weight) is loaded once, and the
+    // loads that are per (entry, chunk) -- chunk offsets, segment prefixes -- are all in flight before the first segment is written.
+    // (Round 4: one (group, chunk) per wave iteration meant one dependent chain slot -> chunk offsets -> prefix per ~100 segments: the fill
+    // ran at 1.4 TB/s of stores, bound by that latency.)
+    constexpr int CB = 4;
+    const bool row4 = nch == 3 && (reinterpret_cast<uintptr_t>(chunk_off) & 15) == 0;      // a table row = four offsets = one 16-byte load
+    const bool row2 = nch == 1 && (reinterpret_cast<uintptr_t>(chunk_off) & 7) == 0;       // two offsets = one 8-byte load
     const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
     const int64_t n_groups = ((int64_t)nq + 63) >> 6;
-    const int64_t total_work = n_groups * nch;
+    const int32_t n_cb = (nch + CB - 1) / CB;
+    const int64_t total_work = n_groups * n_cb;
     for (int64_t gw = blockIdx.x * (int64_t)wpb + (threadIdx.x >> 6); gw < total_work; gw += (int64_t)gridDim.x * wpb) {
-        const int32_t ch = (int32_t)(gw / n_groups);
-        const int64_t g = gw - (int64_t)ch * n_groups;
+        const int32_t ch0 = (int32_t)(gw / n_groups) * CB;
+        const int64_t g = gw - (int64_t)(ch0 / CB) * n_groups;
         const int64_t q = g * 64 + lane;
-        int32_t f0 = 0, len = 0, start = 0;
-        float w = 0.0f;
-        const int32_t* __restrict__ pp = ptr + (int64_t)ch * (nq + 1);
-        if (q < nq) {
-            const int32_t* co = chunk_off + (int64_t)(csc_slot[q0 + q] - slot_base) * (nch + 1) + ch;
-            f0 = co[0];
-            len = co[1] - f0;
-            if (H.row_of_entry) {
-                const int32_t r = H.row_of_entry[q0 + q];
-                if (H.sym_rows == 0 || r < H.sym_rows) {
-                    const int32_t own = r / H.CH;
-                    if (ch < own) len = 0;
-                    else if (ch == own) { f0 = H.start[q]; len = co[1] - f0; }
-                }
-                if (H.lim_chunks > 0 && r >= H.lim_from && ch >= H.lim_chunks) len = 0;
-            }
-            if (H.only_rows && H.only_rows[q0 + q] < H.only_from) len = 0;
-            w = csc_w[q0 + q];
-            start = pp[q];
-        }
-        const int32_t base = __shfl(start, 0, 64);
         const int64_t q_end = min((int64_t)nq, g * 64 + 64);
-        const int32_t total = pp[q_end] - base;             // segments of the whole group
-        if (q >= nq) start = base + total;                    // inactive lanes sit behind the last segment
-        const int32_t rel = start - base;
-        for (int32_t kk = 0; kk < total; kk += 64) {         // wave-uniform trip count: the shuffles need every lane alive
-            const int32_t k = kk + lane;
-            int lo = 0, hi = 63;                              // largest lane j with rel_j <= k (rel is non-decreasing)
+        const bool live = q < nq;
+        int32_t cov[CB + 1], startv[CB], endv[CB];
+        int32_t r = 0, own = -1, own_start = 0;
+        bool dead = false, limited = false;
+        float w = 0.0f;
 #pragma unroll
-            for (int it = 0; it < 6; it++) {
-                const int mid = (lo + hi + 1) >> 1;
-                const int32_t rm = __shfl(rel, mid, 64);
-                if (rm <= k) lo = mid; else hi = mid - 1;
+        for (int c = 0; c < CB; c++) {      // (wave-uniform tests)
+            startv[c] = 0;
+            endv[c] = ch0 + c < nch ? ptr[(int64_t)(ch0 + c) * (nq + 1) + q_end] : 0;
+            if (live && ch0 + c < nch) startv[c] = ptr[(int64_t)(ch0 + c) * (nq + 1) + q];
+        }
+#pragma unroll
+        for (int c = 0; c <= CB; c++) cov[c] = 0;
+        if (live) {
+            const int32_t* co = chunk_off + (int64_t)(csc_slot[q0 + q] - slot_base) * (nch + 1) + ch0;
+            if (row4) {
+                const int4 v = *reinterpret_cast<const int4*>(co);      // (ch0 = 0: the whole row)
+                cov[0] = v.x; cov[1] = v.y; cov[2] = v.z; cov[3] = v.w;
+            } else if (row2) {
+                const int2 v = *reinterpret_cast<const int2*>(co);
+                cov[0] = v.x; cov[1] = v.y;
+            } else {
+#pragma unroll
+                for (int c = 0; c <= CB; c++)
+                    if (ch0 + c <= nch) cov[c] = co[c];
             }
-            // entries with zero segments share their rel with the next entry: the owner is the LAST lane with rel <= k
-            const int32_t off = k - __shfl(rel, lo, 64);
-            const int32_t of0 = __shfl(f0, lo, 64), olen = __shfl(len, lo, 64);
-            const float ow = __shfl(w, lo, 64);
-            if (k < total) {
-                seg[base + k] = make_int2(of0 + 64 * off, min(64, olen - 64 * off));
-                seg_w[base + k] = ow;
+            if (H.row_of_entry) {
+                r = H.row_of_entry[q0 + q];
+                if (H.sym_rows == 0 || r < H.sym_rows) {
+                    own = r / H.CH;
+                    if (own >= ch0 && own < ch0 + CB) own_start = H.start[q];
+                }
+                limited = H.lim_chunks > 0 && r >= H.lim_from;
+            }
+            if (H.only_rows && H.only_rows[q0 + q] < H.only_from) dead = true;
+            w = csc_w[q0 + q];
+        }
+#pragma unroll
+        for (int c = 0; c < CB; c++) {
+            const int32_t ch = ch0 + c;
+            if (ch >= nch) break;                             // wave-uniform
+            int32_t f0 = cov[c], len = cov[c + 1] - cov[c], start = startv[c];
+            if (live) {
+                if (own >= 0) {
+                    if (ch < own) len = 0;
+                    else if (ch == own) { f0 = own_start; len = cov[c + 1] - f0; }
+                }
+                if (limited && ch >= H.lim_chunks) len = 0;
+                if (dead) len = 0;
+            } else len = 0;
+            const int32_t base = __shfl(start, 0, 64);
+            const int32_t total = endv[c] - base;                 // segments of the whole group
+            if (!live) start = base + total;                      // inactive lanes sit behind the last segment
+            const int32_t rel = start - base;
+            for (int32_t kk = 0; kk < total; kk += 64) {         // wave-uniform trip count: the shuffles need every lane alive
+                const int32_t k = kk + lane;
+                int lo = 0, hi = 63;                              // largest lane j with rel_j <= k (rel is non-decreasing)
+#pragma unroll
+                for (int it = 0; it < 6; it++) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    const int32_t rm = __shfl(rel, mid, 64);
+                    if (rm <= k) lo = mid; else hi = mid - 1;
+                }
+                // entries with zero segments share their rel with the next entry: the owner is the LAST lane with rel <= k
+                const int32_t off = k - __shfl(rel, lo, 64);
+                const int32_t of0 = __shfl(f0, lo, 64), olen = __shfl(len, lo, 64);
+                const float ow = __shfl(w, lo, 64);
+                if (k < total) {
+                    seg[base + k] = make_int2(of0 + 64 * off, min(64, olen - 64 * off));
+                    seg_w[base + k] = ow;
+                }
             }
         }
     }
@@ -1938,8 +1989,9 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
     DevBuf<double> p_rank(ctx, nP);
     DevBuf<double>& b_rank = J->b_rank;
     DevBuf<float> a_rank(ctx, nP), b_rank32(ctx, nP);
+    DevBuf<double2> pb_rank(ctx, nP);
     k_pair_p<<<grid_for(nP), 256, 0, st>>>(nP, P.rank_pair.get(), P.pair_di.get(), d_icoll, lambda, b_rank.get(), p_rank.get(), a_rank.get(),
-                                           b_rank32.get());
+                                           b_rank32.get(), pb_rank.get());
     FY_KERNEL_CHECK();
     DevBuf<float> csr_x(ctx, P.nnz), csr_e(ctx, P.nnz), csr_q(ctx, P.nnz);
     const bool use_pk = tune.cooc_pk && P.ratings_fp16_exact;   // packed CSR for the row kernel
@@ -1982,7 +2034,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
     h2d(ctx, d_cshift.get(), h_cshift.data(), (size_t)K);
     k_csr_values<<<grid_for((int64_t)nU * 64, 256), 256, 0, st>>>(nU, P.rowptr.get(), P.csr_idx.get(), P.csr_r.get(), P.slot2du.get(),
                                                                    P.ucluster.get(), P.usum.get(), P.d_csize.get(), P.d_pcstart.get(),
-                                                                   p_rank.get(), b_rank.get(), lambda, d_gscale.get(), csr_x.get(), csr_e.get(), csr_q.get());
+                                                                   pb_rank.get(), lambda, d_gscale.get(), csr_x.get(), csr_e.get(), csr_q.get());
     FY_KERNEL_CHECK();
 
     t_tables.end(span_tables);
