@@ -42,9 +42,12 @@ struct PairPass {
     const int32_t* __restrict__ pair_di;
     const int32_t* __restrict__ csc_slot;
     const float* __restrict__ csc_r;
-    const double* __restrict__ usum_slot;
-    const int32_t* __restrict__ deg_slot;
+    const double2* __restrict__ ud_slot;   // [slot] = (s_v, n_v): ONE 16-byte gather per entry (the pass runs at the L2's request rate)
     int32_t lo, hi;
+    // x = r / s_v per CSC entry (the walk's weights, fy_cooc.hpp) written on the way -- the gather of s_v is this pass's anyway (round 4:
+    // a kernel of its own, k_csc_x, with the same 25 M gathers); x / s_v only for the packed walk (null otherwise)
+    float* __restrict__ csc_x;
+    float* __restrict__ csc_x_over_s;
     double* __restrict__ partial;      // by dense item (several clusters may add to one item)
     double* __restrict__ b_rank;       // by rank position
     long long* __restrict__ walk_rank; // by rank position: sum of the raters' degrees
@@ -61,10 +64,16 @@ __device__ __forceinline__ void fy_pair_entry(const PairPass& A, int32_t q, Pair
     const int32_t slot = A.csc_slot[q];
     const double r = (double)A.csc_r[q];
     if (slot >= A.lo && slot < A.hi) a.ps += r;
-    const double inv = 1.0 / A.usum_slot[slot];      // ONE fp64 division per entry (round 4: r / s and r / (s * s) were two; the heavy-column
-    const double x = r * inv;                         // kernel ran with 40 spilled VGPRs around them)
+    const double2 ud = A.ud_slot[slot];
+    const double inv = 1.0 / ud.x;                    // ONE fp64 division per entry for the column sums (round 4: r / s and r / (s * s) were two;
+    const double x = r * inv;                         // the heavy-column kernel ran with 40 spilled VGPRs around them)
+    if (A.csc_x || A.csc_x_over_s) {                  // (kernel-uniform) the stored weights keep their own roundings: r / s, then / s
+        const double xd = r / ud.x;
+        if (A.csc_x) A.csc_x[q] = (float)xd;
+        if (A.csc_x_over_s) A.csc_x_over_s[q] = (float)(xd / ud.x);
+    }
     a.b += x;
-    a.w += A.deg_slot[slot];
+    a.w += (long long)ud.y;
     const double wt = x * inv;
     a.ws += wt;
     a.wm = fmaxf(a.wm, (float)wt);
@@ -166,11 +175,13 @@ __global__ void k_pair_finish(PairPass A, PairHeavy H) {
 }
 // per-slot copies of the user sums and degrees: one gather per CSC entry instead of two dependent ones
 __global__ void k_slot_user_arrays(int32_t nU, const int32_t* __restrict__ slot2du, const double* __restrict__ usum,
-                                   const int32_t* __restrict__ udeg, double* __restrict__ usum_slot, int32_t* __restrict__ deg_slot) {
+                                   const int32_t* __restrict__ udeg, double* __restrict__ usum_slot, int32_t* __restrict__ deg_slot,
+                                   double2* __restrict__ ud_slot) {
     for (int32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < nU; s += gridDim.x * blockDim.x) {
         const int32_t du = slot2du[s];
         usum_slot[s] = usum[du];
         deg_slot[s] = udeg[du];
+        ud_slot[s] = make_double2(usum[du], (double)udeg[du]);
     }
 }
 
@@ -1844,9 +1855,16 @@ fy_rm2_job* fy::rm2_prepare(Context* ctx, const fy_rm2_params* prm, const fy_rat
         counter.zero();
         J->usum_slot.alloc(ctx, (size_t)P.nU);
         J->deg_slot.alloc(ctx, (size_t)P.nU);
+        DevBuf<double2> ud_slot(ctx, (size_t)P.nU);
         k_slot_user_arrays<<<grid_for(P.nU), 256, 0, ctx->stream>>>(P.nU, P.slot2du.get(), P.usum.get(), P.udeg.get(), J->usum_slot.get(),
-                                                                    J->deg_slot.get());
+                                                                    J->deg_slot.get(), ud_slot.get());
         FY_KERNEL_CHECK();
+        // the walk's per-rating weights are written by the statistics pass (same gather): x / s_v for the packed walk, x for the plain one
+        TableCache& tc0 = S.tables;
+        const bool use_pk0 = ctx->tune.cooc_pk && P.ratings_fp16_exact;
+        tc0.csc_x.alloc(ctx, (size_t)P.nnz);      // (x itself is also what the stray blocks of the panel mode are scored from)
+        tc0.csc_x_over_s.alloc(ctx, use_pk0 ? (size_t)P.nnz : 1);
+        tc0.have_x = true;
         J->b_rank.alloc(ctx, (size_t)P.nP);
         J->walk_rank.alloc(ctx, (size_t)P.nP);
         J->cnt_rank.alloc(ctx, (size_t)P.nP);
@@ -1856,8 +1874,9 @@ fy_rm2_job* fy::rm2_prepare(Context* ctx, const fy_rm2_params* prm, const fy_rat
         DevBuf<int32_t> heavy_col(ctx, max_heavy), heavy_base(ctx, max_heavy), chunk_col(ctx, max_heavy), heavy_counters(ctx, 2);
         DevBuf<PairAcc> chunk_acc(ctx, max_heavy);
         heavy_counters.zero();
-        const PairPass PA{P.rank_pair.get(), P.pair_start.get(), P.pair_di.get(), P.csc_slot.get(), P.csc_r.get(), J->usum_slot.get(),
-                          J->deg_slot.get(), J->slot_lo, J->slot_hi, J->partial.get(), J->b_rank.get(), J->walk_rank.get(), J->cnt_rank.get(), J->fx_rank.get()};
+        const PairPass PA{P.rank_pair.get(), P.pair_start.get(), P.pair_di.get(), P.csc_slot.get(), P.csc_r.get(), ud_slot.get(), J->slot_lo, J->slot_hi,
+                          tc0.csc_x.get(), use_pk0 ? tc0.csc_x_over_s.get() : nullptr,
+                          J->partial.get(), J->b_rank.get(), J->walk_rank.get(), J->cnt_rank.get(), J->fx_rank.get()};
         const PairHeavy PH{heavy_col.get(), heavy_base.get(), chunk_col.get(), heavy_counters.get(), chunk_acc.get()};
         if (P.nnz < 24 * (int64_t)P.nP) k_pair_pass<16><<<grid_for((int64_t)P.nP * 16, 256), 256, 0, ctx->stream>>>(P.nP, PA, PH);
         else k_pair_pass<64><<<grid_for((int64_t)P.nP * 64, 256), 256, 0, ctx->stream>>>(P.nP, PA, PH);
@@ -2001,6 +2020,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
     DevBuf<uint32_t>&csr_pk = tc.csr_pk, &y_pk = tc.y_pk;
     DevBuf<int32_t>& csc_rank = tc.csc_rank;
     std::vector<SegTable>&segs = tc.segs, &segs_tail = tc.segs_tail;
+    // (normally written by fy_rm2_prepare's statistics pass; here only when the walk's kind changed between the two calls)
     if (!tc.have_x || csc_x.size() != (size_t)P.nnz || csc_x_over_s.size() != (use_pk ? (size_t)P.nnz : 1)) {
         tc.valid = tc.have_x = false;
         csc_x.alloc(ctx, P.nnz);
