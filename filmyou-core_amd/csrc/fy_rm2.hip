@@ -2992,7 +2992,12 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 } else {
                     int lp2 = 64;                   // the sort's size: the seed columns, at most TOPN_SAMPLE
                     while (lp2 < std::min<int>(std::min<int>(Ic, seed_chunks * 256), TOPN_SAMPLE)) lp2 <<= 1;
-                    k_topn_seed<<<(nb + 3) / 4, 256, (size_t)4 * lp2 * sizeof(uint64_t), ls>>>(T1, nb, L.overflow.get(), lp2);
+                    const unsigned sg = (unsigned)((nb + 3) / 4);
+                    if (lp2 <= 64) k_topn_seed<1><<<sg, 256, 0, ls>>>(T1, nb, L.overflow.get());
+                    else if (lp2 == 128) k_topn_seed<2><<<sg, 256, 0, ls>>>(T1, nb, L.overflow.get());
+                    else if (lp2 == 256) k_topn_seed<4><<<sg, 256, 0, ls>>>(T1, nb, L.overflow.get());
+                    else if (lp2 == 512) k_topn_seed<8><<<sg, 256, 0, ls>>>(T1, nb, L.overflow.get());
+                    else k_topn_seed<16><<<sg, 256, 0, ls>>>(T1, nb, L.overflow.get());
                 }
                 FY_KERNEL_CHECK();
                 // (4) the blocks whose bound reaches tau_u, in ascending order
