@@ -33,6 +33,7 @@ void fy::load_tuning_from_env(Tuning& t) {
     if (const char* e = getenv("FY_REFINE_C")) { double v = atof(e); if (v >= 0.0 && v < 1e6) t.refine_c = (float)v; }
     if (const char* e = getenv("FY_FULL_WALK_SPARSE")) t.full_walk_sparse = atoi(e) != 0;
     if (const char* e = getenv("FY_PREP_PACKED")) t.prep_packed = atoi(e) != 0;
+    if (const char* e = getenv("FY_OVERLAP_VALUES")) t.overlap_values = atoi(e) != 0;
     if (const char* e = getenv("FY_SHARD_PREP")) t.shard_prep = atoi(e) != 0;
     if (const char* e = getenv("FY_SUP_BOUNDS")) t.sup_bounds = atoi(e) != 0;
     if (const char* e = getenv("FY_COOP")) t.coop = atoi(e) != 0;

@@ -69,6 +69,7 @@ struct Tuning {
     bool cooc_max_ch_forced = false;   // FY_COOC_MAX_CH given (the item-similarity build has its own default)
     int sup_bounds = 1;                // FY_SUP_BOUNDS: one-cluster pruned jobs bound over <= 64 super-blocks inside the seed pass (0: a bound chunk per user over all blocks)
     int prep_packed = 1;               // FY_PREP_PACKED: fp16-exact scores ride in the low 16 bits of the prep's sort keys, the three nnz-sized sorts move keys alone
+    int overlap_values = 1;            // FY_OVERLAP_VALUES: the per-rating values of the scoring kernels are computed on a side stream beside the one-cluster job's row kernel
     int shard_prep = 1;                // FY_SHARD_PREP: several ranks, clusters >= ranks: a rank preps its own clusters' ratings alone (fy_prep.hpp)
     int full_walk_sparse = 1;          // FY_FULL_WALK_SPARSE: unpruned clusters whose matrix has more elements than the cluster has pair visits walk full rows (no mirror pass)
     int refine = 1;                    // FY_REFINE: list rows whose score nearly cancels are scored again in fp64 from fp32 head rows (k_refine_rows)

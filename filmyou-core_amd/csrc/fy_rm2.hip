@@ -2052,10 +2052,50 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
     DevBuf<int32_t> d_cshift(ctx, (size_t)K);
     h2d(ctx, d_gscale.get(), h_gscale.data(), (size_t)K);
     h2d(ctx, d_cshift.get(), h_cshift.data(), (size_t)K);
-    k_csr_values<<<grid_for((int64_t)nU * 64, 256), 256, 0, st>>>(nU, P.rowptr.get(), P.csr_idx.get(), P.csr_r.get(), P.slot2du.get(),
-                                                                   P.ucluster.get(), P.usum.get(), P.d_csize.get(), P.d_pcstart.get(),
-                                                                   pb_rank.get(), lambda, d_gscale.get(), csr_x.get(), csr_e.get(), csr_q.get());
-    FY_KERNEL_CHECK();
+    // The per-rating values (x, e, q: what the SCORING kernels read) are computed on a side stream: nothing in front of the scoring reads
+    // them, and the row kernel that follows leaves half of every CU's wave slots and most of the memory system idle (its 157 KB of LDS
+    // accumulators hold one workgroup per CU; it waits on LDS atomics).  The main stream -- and with it every lane -- joins either at once
+    // (several lanes, cooperative ranks, flat batches: FY_OVERLAP_VALUES=0 everywhere) or behind the launch of the one row kernel.
+    struct SideValues {
+        Context* ctx;
+        hipStream_t sv = nullptr;
+        hipEvent_t in = nullptr, out = nullptr;
+        bool joined = true;
+        void join(hipStream_t s) {
+            if (joined) return;
+            joined = true;
+            FY_HIP(hipStreamWaitEvent(s, out, 0));
+        }
+        ~SideValues() {     // (a failed job: the side kernel must not outlive the arrays it writes)
+            if (!joined && sv) (void)hipStreamSynchronize(sv);
+            if (in) (void)hipEventDestroy(in);
+            if (out) (void)hipEventDestroy(out);
+        }
+    } side{ctx};
+    {
+        hipStream_t vs = st;
+        if (tune.overlap_values) {
+            if (ctx->aux.empty()) {
+                hipStream_t x;
+                FY_HIP(hipStreamCreateWithFlags(&x, hipStreamNonBlocking));
+                ctx->aux.push_back(x);
+            }
+            side.sv = ctx->aux[0];
+            FY_HIP(hipEventCreateWithFlags(&side.in, hipEventDisableTiming));
+            FY_HIP(hipEventCreateWithFlags(&side.out, hipEventDisableTiming));
+            FY_HIP(hipEventRecord(side.in, st));
+            FY_HIP(hipStreamWaitEvent(side.sv, side.in, 0));
+            vs = side.sv;
+        }
+        k_csr_values<<<grid_for((int64_t)nU * 64, 256), 256, 0, vs>>>(nU, P.rowptr.get(), P.csr_idx.get(), P.csr_r.get(), P.slot2du.get(),
+                                                                       P.ucluster.get(), P.usum.get(), P.d_csize.get(), P.d_pcstart.get(),
+                                                                       pb_rank.get(), lambda, d_gscale.get(), csr_x.get(), csr_e.get(), csr_q.get());
+        FY_KERNEL_CHECK();
+        if (tune.overlap_values) {
+            FY_HIP(hipEventRecord(side.out, side.sv));
+            side.joined = false;
+        }
+    }
 
     t_tables.end(span_tables);
     // ---- which users this rank emits lists for
@@ -2300,6 +2340,8 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
         // on the lanes: measured at 50 clusters, ms per job: 2 lanes 98.0, 4: 95.9, 8: 93.1)
         const int want_lanes = tune.lanes_forced ? tune.lanes : (two_phase ? std::max(tune.lanes, 8) : (any_panel ? std::min(tune.lanes, tune.panel_lanes) : tune.lanes));
         const int NS = (int)std::min<size_t>(plans.size() > 1 ? (size_t)want_lanes : 1, plans.size());
+        // (the side stream's per-rating values, see above: only the plain one-cluster flow lets them run beside its row kernel)
+        if (!(NS == 1 && plans.size() == 1 && !plans[0].coop && !plans[0].flat && !plans[0].panel)) side.join(st);
         struct Lane {
             hipStream_t st;
             DevBuf<float> M, S;
@@ -2823,6 +2865,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 }
             }
             t_cooc.end(sp, ls);
+            side.join(ls);      // (the scoring kernels behind this point read the per-rating values)
             checkpoint("row kernel queued / run");
             if (!batched) R->st.cooc_launches++;
             if (p.half) {    // lower triangle + the block maxima in front of / on the diagonal
