@@ -2052,29 +2052,26 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
     DevBuf<int32_t> d_cshift(ctx, (size_t)K);
     h2d(ctx, d_gscale.get(), h_gscale.data(), (size_t)K);
     h2d(ctx, d_cshift.get(), h_cshift.data(), (size_t)K);
-    // The per-rating values (x, e, q: what the SCORING kernels read) are computed on a side stream: nothing in front of the scoring reads
-    // them, and the row kernel that follows leaves half of every CU's wave slots and most of the memory system idle (its 157 KB of LDS
-    // accumulators hold one workgroup per CU; it waits on LDS atomics).  The main stream -- and with it every lane -- joins either at once
-    // (several lanes, cooperative ranks, flat batches: FY_OVERLAP_VALUES=0 everywhere) or behind the launch of the one row kernel.
+    // The per-rating values (x, e, q: what the SCORING kernels read): with the packed walk nothing in front of the scoring reads them, and
+    // what runs until then -- the table kernels, then the one-cluster job's row kernel with ONE workgroup per CU beside its 157 KB of LDS
+    // accumulators -- leaves wave slots and most of the memory system idle.  They are computed on a side stream; the plain one-cluster
+    // flow joins behind its row kernel, every other flow (several lanes, cooperative ranks, flat batches) before its lanes start.
     struct SideValues {
         Context* ctx;
         hipStream_t sv = nullptr;
         hipEvent_t in = nullptr, out = nullptr;
-        bool joined = true;
-        void join(hipStream_t s) {
-            if (joined) return;
-            joined = true;
-            FY_HIP(hipStreamWaitEvent(s, out, 0));
-        }
+        bool launched = false, joined = true;
         ~SideValues() {     // (a failed job: the side kernel must not outlive the arrays it writes)
             if (!joined && sv) (void)hipStreamSynchronize(sv);
             if (in) (void)hipEventDestroy(in);
             if (out) (void)hipEventDestroy(out);
         }
     } side{ctx};
-    {
-        hipStream_t vs = st;
-        if (tune.overlap_values) {
+    auto launch_values = [&](hipStream_t main_stream, bool beside) {
+        if (side.launched) return;
+        side.launched = true;
+        hipStream_t vs = main_stream;
+        if (beside && tune.overlap_values) {
             if (ctx->aux.empty()) {
                 hipStream_t x;
                 FY_HIP(hipStreamCreateWithFlags(&x, hipStreamNonBlocking));
@@ -2083,7 +2080,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
             side.sv = ctx->aux[0];
             FY_HIP(hipEventCreateWithFlags(&side.in, hipEventDisableTiming));
             FY_HIP(hipEventCreateWithFlags(&side.out, hipEventDisableTiming));
-            FY_HIP(hipEventRecord(side.in, st));
+            FY_HIP(hipEventRecord(side.in, main_stream));
             FY_HIP(hipStreamWaitEvent(side.sv, side.in, 0));
             vs = side.sv;
         }
@@ -2091,11 +2088,20 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                                                                        P.ucluster.get(), P.usum.get(), P.d_csize.get(), P.d_pcstart.get(),
                                                                        pb_rank.get(), lambda, d_gscale.get(), csr_x.get(), csr_e.get(), csr_q.get());
         FY_KERNEL_CHECK();
-        if (tune.overlap_values) {
+        if (vs != main_stream) {
             FY_HIP(hipEventRecord(side.out, side.sv));
             side.joined = false;
         }
-    }
+    };
+    auto join_values = [&](hipStream_t s) {
+        if (side.joined) return;
+        side.joined = true;
+        FY_HIP(hipStreamWaitEvent(s, side.out, 0));
+    };
+    // (the packed walk reads the packed CSR; the PLAIN walk's row kernel reads x itself: no overlap there.  Measured on one box, ML-25M
+    // shape, ms per cold job: side stream from here 20.08, launched right in front of the row kernel 20.15, main stream 20.30 / 20.48 --
+    // the table kernels in between wait on the L2's request rate and on dependent loads, and leave more room than the row kernel.)
+    launch_values(st, use_pk);
 
     t_tables.end(span_tables);
     // ---- which users this rank emits lists for
@@ -2341,7 +2347,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
         const int want_lanes = tune.lanes_forced ? tune.lanes : (two_phase ? std::max(tune.lanes, 8) : (any_panel ? std::min(tune.lanes, tune.panel_lanes) : tune.lanes));
         const int NS = (int)std::min<size_t>(plans.size() > 1 ? (size_t)want_lanes : 1, plans.size());
         // (the side stream's per-rating values, see above: only the plain one-cluster flow lets them run beside its row kernel)
-        if (!(NS == 1 && plans.size() == 1 && !plans[0].coop && !plans[0].flat && !plans[0].panel)) side.join(st);
+        if (!(NS == 1 && plans.size() == 1 && !plans[0].coop && !plans[0].flat && !plans[0].panel)) join_values(st);
         struct Lane {
             hipStream_t st;
             DevBuf<float> M, S;
@@ -2865,7 +2871,7 @@ fy_result* fy::rm2_score(fy_rm2_job* J) {
                 }
             }
             t_cooc.end(sp, ls);
-            side.join(ls);      // (the scoring kernels behind this point read the per-rating values)
+            join_values(ls);      // (the scoring kernels behind this point read the per-rating values)
             checkpoint("row kernel queued / run");
             if (!batched) R->st.cooc_launches++;
             if (p.half) {    // lower triangle + the block maxima in front of / on the diagonal
