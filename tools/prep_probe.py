@@ -1,4 +1,4 @@
-"""Where a cold fy_rm2_prepare spends its time: `python tools/prep_probe.py <clusters> <world> [rank]` prints ms_prepare of a few cold
+"""Where a cold fy_rm2_prepare spends its time: `python tools/prep_probe.py <clusters> <world> [rank] [shape]` prints ms_prepare of a few cold
 prepares of one rank (ML-25M shape; run it under `rocprofv3 --kernel-trace --stats` for the kernels behind the number)."""
 import importlib
 import os
@@ -15,9 +15,10 @@ sys.path.insert(0, ROOT)
 def main():
     K, world = int(sys.argv[1]), int(sys.argv[2])
     rank = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    shape = sys.argv[4] if len(sys.argv) > 4 else "ml25m"
     P = importlib.import_module("filmyou-core_amd")
     S = importlib.import_module("filmyou-core_amd.synth")
-    user, item, score, facts = S.generate("ml25m", device=torch.device("cuda", 0))
+    user, item, score, facts = S.generate(shape, device=torch.device("cuda", 0))
     uu = np.arange(1, facts["n_users"] + 1, dtype=np.int32)
     clustering = (uu, S.hash_clustering(uu, K)) if K > 1 else None
     conf = P.Configuration()
