@@ -169,8 +169,23 @@ def main():
             exchange = par.StatsExchange(local_rank)
             transport = "statistics all-gather only (torch.distributed/%s)" % dist.get_backend()
         elif not rehearsal and hasattr(par, "RcclCollectives") and os.environ.get("FY_BENCH_TORCH_COLLECTIVES") != "1":
-            collectives = par.RcclCollectives(ctx, rank, world)
-            transport = "librccl.so through the library's compiled fy_collectives (ncclAllGather / ncclReduceScatter on the job's stream)"
+            # the compiled transport, or -- decided by ALL ranks together, so that no rank waits in a communicator the
+            # others never joined -- torch.distributed's RCCL group on the job's stream (the same library underneath)
+            why = ""
+            try:
+                collectives = par.RcclCollectives(ctx, rank, world)
+            except RuntimeError as e:
+                why = str(e)
+            ok = torch.tensor([0.0 if why else 1.0], dtype=torch.float64, device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if float(ok.item()) >= 1.0:
+                transport = "librccl.so through the library's compiled fy_collectives (ncclAllGather / ncclReduceScatter on the job's stream)"
+            else:
+                if collectives is not None:
+                    collectives.close()
+                collectives = par.TorchCollectives(local_rank)
+                transport = ("torch.distributed/%s on the job's stream (the compiled fy_rccl transport did not start on every rank%s)"
+                             % (dist.get_backend(), ": " + why if why else ""))
         else:
             collectives = par.TorchCollectives(local_rank)
             transport = "torch.distributed/%s on the job's stream" % dist.get_backend()

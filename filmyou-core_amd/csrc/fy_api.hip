@@ -2,7 +2,9 @@
 #include <algorithm>
 #include <cstdlib>
 #include <memory>
+#include <mutex>
 #include <new>
+#include <unordered_map>
 
 #include "fy_prep.hpp"
 #include "fy_rm2.hpp"
@@ -74,6 +76,23 @@ void fy::load_tuning_from_env(Tuning& t) {
     if (const char* e = getenv("FY_ISIM_ACC32")) t.isim_acc32 = atoi(e) != 0;
     if (const char* e = getenv("FY_ISIM_PIECE")) { int v = atoi(e); if (v >= 64 && v <= 8192 && v % 64 == 0) t.isim_piece = v; }
 }
+
+// Every entry point that reaches the GPU selects its context's device first: allocations, new streams and kernel attributes
+// go to the calling thread's CURRENT device, and a host that drives several GPUs from one process (or hands a job to
+// another thread) would otherwise build one context's job in another GPU's memory.  The job handle is opaque in this file,
+// so the contexts of live jobs are kept here (fy_rm2_prepare ... fy_rm2_job_destroy).
+namespace {
+std::mutex g_jobs_mu;
+std::unordered_map<const fy_rm2_job*, fy::Context*> g_jobs;
+fy::Context* job_context(const fy_rm2_job* j) {
+    std::lock_guard<std::mutex> g(g_jobs_mu);
+    auto it = g_jobs.find(j);
+    return it == g_jobs.end() ? nullptr : it->second;
+}
+inline void select_device(const fy::Context* ctx) {
+    if (ctx) FY_HIP(hipSetDevice(ctx->device));
+}
+}  // namespace
 
 // every entry point: no exception may cross the ABI
 #define FY_TRY try {
@@ -152,6 +171,7 @@ int fy_context_reload_tuning(fy_context* c) {
 int fy_context_synchronize(fy_context* c) {
     if (!c) { set_error("context is NULL"); return FY_ERR_INVALID_ARGUMENT; }
     FY_TRY
+    select_device(&c->c);
     FY_HIP(hipStreamSynchronize(c->c.stream));
     FY_CATCH
 }
@@ -188,12 +208,14 @@ int fy_ratings_create(fy_context* c, int64_t nnz, const int32_t* user, const int
 void fy_ratings_destroy(fy_ratings* r) {
     if (!r) return;
     fy::Context* ctx = r->ctx;
+    if (ctx) (void)hipSetDevice(ctx->device);
     delete r;
     if (ctx) (void)hipStreamSynchronize(ctx->stream);
 }
 int64_t fy_ratings_nnz(const fy_ratings* r) { return r ? r->nnz : 0; }
 void fy_ratings_drop_cache(fy_ratings* r) {
     if (!r) return;
+    if (r->ctx) (void)hipSetDevice(r->ctx->device);
     std::shared_ptr<void> old;
     {
         std::lock_guard<std::mutex> g(r->cache_mu);
@@ -213,12 +235,17 @@ int fy_rm2_prepare(fy_context* c, const fy_rm2_params* p, const fy_ratings* r, i
     FY_TRY
     FY_HIP(hipSetDevice(c->c.device));
     *out = fy::rm2_prepare(&c->c, p, r, n_map, map_user, map_cluster, cluster_count);
+    {
+        std::lock_guard<std::mutex> g(g_jobs_mu);
+        g_jobs[*out] = &c->c;
+    }
     FY_CATCH
 }
 
 int fy_rm2_partial_stats(fy_rm2_job* j, double** device_buf, int64_t* len) {
     if (!j || !device_buf || !len) { set_error("NULL argument"); return FY_ERR_INVALID_ARGUMENT; }
     FY_TRY
+    select_device(job_context(j));
     fy::rm2_partial_stats(j, device_buf, len);
     FY_CATCH
 }
@@ -233,6 +260,7 @@ int fy_rm2_stats_layout(fy_rm2_job* j, int64_t* n_item_slots, int64_t* n_user_sl
 int fy_rm2_set_global_stats(fy_rm2_job* j, const double* gathered_device, int32_t world) {
     if (!j || !gathered_device) { set_error("NULL argument"); return FY_ERR_INVALID_ARGUMENT; }
     FY_TRY
+    select_device(job_context(j));
     fy::rm2_set_global_stats(j, gathered_device, world);
     FY_CATCH
 }
@@ -249,11 +277,22 @@ int fy_rm2_score(fy_rm2_job* j, fy_result** out) {
     *out = nullptr;
     if (!j) { set_error("job is NULL"); return FY_ERR_INVALID_ARGUMENT; }
     FY_TRY
+    select_device(job_context(j));
     *out = fy::rm2_score(j);
     FY_CATCH
 }
 
-void fy_rm2_job_destroy(fy_rm2_job* j) { fy::rm2_job_destroy(j); }
+void fy_rm2_job_destroy(fy_rm2_job* j) {
+    if (!j) return;
+    fy::Context* ctx = nullptr;
+    {
+        std::lock_guard<std::mutex> g(g_jobs_mu);
+        auto it = g_jobs.find(j);
+        if (it != g_jobs.end()) { ctx = it->second; g_jobs.erase(it); }
+    }
+    if (ctx) (void)hipSetDevice(ctx->device);
+    fy::rm2_job_destroy(j);
+}
 
 int fy_rm2_run(const fy_rm2_params* p, int64_t nnz, const int32_t* user, const int32_t* item, const float* score, int64_t n_map,
                const int32_t* map_user, const int32_t* map_cluster, const int32_t* cluster_count, fy_result** out) {
@@ -349,6 +388,7 @@ static void rows_to_host(fy_result* r) {
     r->h_key0.resize(n); r->h_key1.resize(n); r->h_aux.resize(n); r->h_value.resize(n);
     if (n == 0 || !r->ctx) return;
     try {
+        select_device(r->ctx);
         fy::d2h(r->ctx, r->h_key0.data(), r->d_key0.get(), n);
         fy::d2h(r->ctx, r->h_key1.data(), r->d_key1.get(), n);
         fy::d2h(r->ctx, r->h_aux.data(), r->d_aux.get(), n);
@@ -364,6 +404,7 @@ static void sums_to_host(fy_result* r) {
     r->h_user_id.resize(nu); r->h_user_sum.resize(nu); r->h_item_id.resize(ni); r->h_icoll.resize(ni);
     if (!r->ctx) return;
     try {
+        select_device(r->ctx);
         fy::d2h(r->ctx, r->h_user_id.data(), r->d_user_id.get(), nu);
         fy::d2h(r->ctx, r->h_user_sum.data(), r->d_user_sum.get(), nu);
         fy::d2h(r->ctx, r->h_item_id.data(), r->d_item_id.get(), ni);
@@ -393,6 +434,7 @@ int fy_result_stats(fy_result* r, fy_stats* out) {
 void fy_result_free(fy_result* r) {
     if (!r) return;
     fy::Context* ctx = r->ctx;
+    if (ctx) (void)hipSetDevice(ctx->device);
     delete r;
     if (ctx) (void)hipStreamSynchronize(ctx->stream);
 }

@@ -161,14 +161,19 @@ class RcclCollectives:
         self._ctx = ctx
         self.rank, self.world = rank, world
         idbuf = C.create_string_buffer(128)
+        why = None
         if rank == 0:
             rc = self._lib.fy_rccl_unique_id(idbuf)
             if rc:
-                raise RuntimeError("fy_rccl_unique_id: %s" % self._lib.fy_last_error().decode())
+                why = "fy_rccl_unique_id: %s" % self._lib.fy_last_error().decode()
         if world > 1:
-            box = [idbuf.raw if rank == 0 else None]
+            # rank 0's failure travels in place of the id: every rank raises, nobody is left waiting in the broadcast
+            box = [(idbuf.raw, why) if rank == 0 else None]
             dist.broadcast_object_list(box, src=0, group=group)
-            idbuf = C.create_string_buffer(box[0], 128)
+            raw, why = box[0]
+            idbuf = C.create_string_buffer(raw, 128)
+        if why:
+            raise RuntimeError(why)
         h = C.c_void_p()
         rc = self._lib.fy_rccl_create(ctx._h, rank, world, idbuf, C.byref(h))
         if rc:

@@ -17,6 +17,9 @@
  * returns.  Results are library-owned until fy_result_free.  One fy_context drives one GPU; a process uses one
  * context per device (one process per GPU under torch.distributed / a Hadoop task per GPU).  A context is not
  * re-entrant: calls on one context must not overlap; distinct contexts may be used from distinct threads.
+ * Every entry point that takes a context, or a ratings / job / result object made on one, selects that context's
+ * device for the calling thread (hipSetDevice) before it touches the GPU, and leaves it selected: a host may drive
+ * several devices from one process and hand an object to another thread.
  * There is NO CPU fallback: without a gfx950 device every compute entry point fails with FY_ERR_NO_DEVICE.
  */
 #ifndef FILMYOU_H
