@@ -399,7 +399,7 @@ def main():
                              "full_pass_frac_of_v_log_f32_peak": (t2 / (float(np.mean([x["ms_score"] for x in s2])) * 1e-3) / V_LOG_F32_PEAK)
                                                                  if (s2[-1]["blocks_total"] == 0 and np.mean([x["ms_score"] for x in s2]) > 0) else None,
                              # ... and by SURVEY 8d's byte model (4 B per log term against HBM) over the whole job; measured beside it
-                             # (profiles/r4/k50_n1000_pmc_*.txt): 3.0 B of fabric reads per term, 10.9 VALU instructions per term, 84 % VALU-busy
+                             # (profiles/r4/k50_n1000_pmc_*.txt): 2.8 B of fabric reads per term, 10.9 VALU instructions per term, 66 - 84 % VALU-busy
                              "full_pass_frac_of_hbm_by_survey_unit": (4.0 * t2 / (el2 / 2) / 1e9 / HBM_PEAK_GBS) if s2[-1]["blocks_total"] == 0 else None,
                              "log_terms_evaluated": int(s2[-1]["log_terms_evaluated"]) if s2[-1]["blocks_total"] else int(s2[-1]["log_terms"]),
                              "blocks_survived_frac": (s2[-1]["blocks_survived"] / s2[-1]["blocks_total"]) if s2[-1]["blocks_total"] else None,
