@@ -221,7 +221,9 @@ __global__ __launch_bounds__(256) void k_v2(const unsigned char* __restrict__ M_
                 const unsigned long long rs = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(rb >> 32)) << 32) |
                                               (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)rb);
                 typedef const __attribute__((address_space(1))) unsigned char* gptr;       // global, not flat
-                g[r] = *reinterpret_cast<const __attribute__((address_space(1))) U3*>(reinterpret_cast<gptr>(rs) + lane_off);
+                typedef const __attribute__((address_space(1))) uint32_t* gword;
+                const gword gw = reinterpret_cast<gword>(reinterpret_cast<gptr>(rs) + lane_off);
+                g[r].a = gw[0]; g[r].b = gw[1]; g[r].c = gw[2];                            // one global_load_dwordx3
             }
             float m[4] = {1.f, 1.f, 1.f, 1.f};     // product of the sub-products' mantissas
             int ex[4] = {0, 0, 0, 0};              // sum of their exponents
