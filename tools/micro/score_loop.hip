@@ -19,7 +19,11 @@
 //
 // Both kernels are checked against a host fp64 evaluation of the same packed matrix on sampled (user, column) pairs, then timed.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o /tmp/score_loop tools/micro/score_loop.hip && /tmp/score_loop [Ic] [users] [centre]
-// NOT YET RUN ON A GPU (written with the round's GPU minutes spent): what exists is the STATIC count of the gfx950 code
+// Run once, with the round's last GPU seconds (profiles/r4/micro_score_loop.txt: Ic 4096, 4096 users, 2.6e9 log terms, a 50 MB matrix):
+//   v1 1.128 ms = 2.32e12 log terms/s (the library's kernels: 2.0 - 2.6e12), v2<4> 0.892 ms (1.26 x), v2<8> 0.916 ms (1.23 x); all checks
+//   passed, v2's worst error against fp64 a third of v1's (1.7e-6 / 2.0e-6 against 6.9e-6 relative).  2.2 x fewer VALU instructions buy
+//   1.25 x: behind the instruction count the loop meets the cache hierarchy's gather rate (8.7 TB/s of 768-byte row segments into the CUs).
+// The STATIC count of the gfx950 code
 // (`-S --cuda-device-only -o /tmp/score_loop.s`, hipcc of ROCm 7.2; VALU instructions on the hot path of one batch of eight rows =
 // 32 log terms per lane):
 //   v1      341  (42.6 per row -- the library's kernel measured 43.6 per row with the counters): 64 v_fmac, 32 v_perm + 32 v_lshrrev,
