@@ -164,7 +164,7 @@ __device__ __forceinline__ uint32_t mad24(uint32_t x, uint32_t cadd) {      // (
     asm("v_mad_u32_u24 %0, %1, 64, %2" : "=v"(r) : "v"(x), "s"(cadd));
     return r;
 }
-template <int SUB>
+template <int SUB, bool CENTRED>
 __global__ __launch_bounds__(256) void k_v2(const unsigned char* __restrict__ M_, const float* __restrict__ a_, const float* __restrict__ b_,
                                             const int* __restrict__ rowptr_, const int* __restrict__ idx_, const float* __restrict__ e_,
                                             const float* __restrict__ q_, const double* __restrict__ pv_, float* __restrict__ S_, Args A) {
@@ -173,8 +173,14 @@ __global__ __launch_bounds__(256) void k_v2(const unsigned char* __restrict__ M_
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int chunk = blockIdx.x / A.n_slices, slice = blockIdx.x - chunk * A.n_slices;
     const int col0 = chunk * CW, col = col0 + lane * 4;
-    const float sc = __builtin_amdgcn_ldexpf(1.f, A.centre);
-    v2f a01, a23, b01, b23;      // a and b scaled by 2^centre: x' = G' + a' e + q b'
+    // CENTRED (what profiles/r4/micro_score_loop.txt measured): every term scaled by 2^centre.  !CENTRED (what tools/patches/
+    // score_body_v2.patch puts into the library): the terms as they are, the product of SUB = 4 of them STARTED at 2^108 -- an exact zero
+    // term (every never co-rated pair at lambda = 0, quirk Q7) stays a zero and takes the term-by-term path to its -inf; with the centring
+    // folded into the exponent field a zero entry became 2^(centre - 127) and could hide inside a normal product.
+    static_assert(CENTRED || SUB == 4, "a start value covers four terms");
+    const float sc = CENTRED ? __builtin_amdgcn_ldexpf(1.f, A.centre) : 1.f;
+    const float P0 = CENTRED ? 1.f : 0x1p108f;
+    v2f a01, a23, b01, b23;      // CENTRED: a and b scaled by 2^centre: x' = G' + a' e + q b'
     {
         float av[4], bv[4];
 #pragma unroll
@@ -186,7 +192,7 @@ __global__ __launch_bounds__(256) void k_v2(const unsigned char* __restrict__ M_
         b01 = v2f{bv[0], bv[1]}; b23 = v2f{bv[2], bv[3]};
     }
     const uint32_t lane_off = (uint32_t)col * 3u;               // this lane's 12 bytes inside a row
-    const uint32_t cadd = (uint32_t)A.centre << 23;               // 2^centre in the exponent field
+    const uint32_t cadd = CENTRED ? (uint32_t)A.centre << 23 : 0u;   // 2^centre in the exponent field
     const int last_row = A.Ic - 1;
     const double LN2 = 0.69314718055994530942;
     for (int u = slice * 4 + wave; u < A.n_users; u += A.n_slices * 4) {
@@ -231,10 +237,11 @@ __global__ __launch_bounds__(256) void k_v2(const unsigned char* __restrict__ M_
             }
             float m[4] = {1.f, 1.f, 1.f, 1.f};     // product of the sub-products' mantissas
             int ex[4] = {0, 0, 0, 0};              // sum of their exponents
+            int n_folded = 0;                      // !CENTRED: folded sub-products, 2^108 each
 #pragma unroll
             for (int r0 = 0; r0 < SB; r0 += SUB) {
                 if (k + r0 >= end) break;
-                v2f p01 = v2f{1.f, 1.f}, p23 = v2f{1.f, 1.f};
+                v2f p01 = v2f{P0, P0}, p23 = v2f{P0, P0};
 #pragma unroll
                 for (int r = r0; r < r0 + SUB; r++) {
                     if (k + r < end) {
@@ -255,7 +262,10 @@ __global__ __launch_bounds__(256) void k_v2(const unsigned char* __restrict__ M_
                 bool ok = true;
 #pragma unroll
                 for (int v = 0; v < 4; v++) ok = ok && __builtin_amdgcn_classf(pp[v], 0x100);      // +normal
+                // (!CENTRED: none below 2^-90 either -- no partial product passed through the denormals, whatever the order of the terms)
+                if (!CENTRED) ok = ok && fminf(fminf(pp[0], pp[1]), fminf(pp[2], pp[3])) > 0x1p-90f;
                 if (__builtin_expect(__all(ok), 1)) {
+                    n_folded++;
 #pragma unroll
                     for (int v = 0; v < 4; v++) {
                         m[v] *= __builtin_amdgcn_frexp_mantf(pp[v]);
@@ -282,11 +292,11 @@ __global__ __launch_bounds__(256) void k_v2(const unsigned char* __restrict__ M_
                 }
             }
 #pragma unroll
-            for (int v = 0; v < 4; v++) t[v] += (double)__builtin_amdgcn_logf(m[v]) + (double)ex[v];
+            for (int v = 0; v < 4; v++) t[v] += (double)__builtin_amdgcn_logf(m[v]) + (double)(ex[v] - (CENTRED ? 0 : 108 * n_folded));
         }
         float4 o;
         float* ov = reinterpret_cast<float*>(&o);
-        const double base = pv_[u] - LN2 * (double)(end - beg) * (double)A.centre;      // every term carried 2^centre
+        const double base = pv_[u] - (CENTRED ? LN2 * (double)(end - beg) * (double)A.centre : 0.0);      // CENTRED: every term carried 2^centre
 #pragma unroll
         for (int v = 0; v < 4; v++) ov[v] = ((mask >> v) & 1u || col + v >= A.Ic) ? __builtin_nanf("") : (float)(base + LN2 * t[v]);
         *reinterpret_cast<float4*>(S_ + (long long)u * A.ldS + col) = o;
@@ -373,8 +383,9 @@ int main(int argc, char** argv) {
         for (int rep = 0; rep < 4; rep++) {
             CHECK(hipEventRecord(t0));
             if (which == 1) k_v1<<<n_chunks * n_slices, 256>>>(A);
-            else if (which == 4) k_v2<4><<<n_chunks * n_slices, 256>>>(dM, da, db, drp, didx, de, dq, dpv, S, A);
-            else k_v2<8><<<n_chunks * n_slices, 256>>>(dM, da, db, drp, didx, de, dq, dpv, S, A);
+            else if (which == 4) k_v2<4, true><<<n_chunks * n_slices, 256>>>(dM, da, db, drp, didx, de, dq, dpv, S, A);
+            else if (which == 40) k_v2<4, false><<<n_chunks * n_slices, 256>>>(dM, da, db, drp, didx, de, dq, dpv, S, A);
+            else k_v2<8, true><<<n_chunks * n_slices, 256>>>(dM, da, db, drp, didx, de, dq, dpv, S, A);
             CHECK(hipEventRecord(t1));
             CHECK(hipEventSynchronize(t1));
             CHECK(hipGetLastError());
@@ -424,6 +435,9 @@ int main(int argc, char** argv) {
     ok = check(dS2, "v2<4>") && ok;
     const float ms8 = run(8, dS2, "v2, products of 8 terms");
     ok = check(dS2, "v2<8>") && ok;
-    printf("speed-up over v1: %.2f (products of 4), %.2f (products of 8)   %s\n", ms1 / ms4, ms1 / ms8, ok ? "CHECKS PASSED" : "CHECKS FAILED");
+    const float ms40 = run(40, dS2, "v2, 4 terms from 2^108");
+    ok = check(dS2, "v2<4, start value>") && ok;
+    printf("speed-up over v1: %.2f (products of 4), %.2f (products of 8), %.2f (4 terms from 2^108: the library patch)   %s\n", ms1 / ms4, ms1 / ms8,
+           ms1 / ms40, ok ? "CHECKS PASSED" : "CHECKS FAILED");
     return ok ? 0 : 2;
 }
