@@ -134,3 +134,45 @@ def test_cooperative_partial_sums_reduce_to_the_oracle_scores(tmp_path, world):
     np.testing.assert_allclose(got, ref["rec_score"].astype(np.float64), rtol=1e-5)
     # rated candidates stayed masked through the sum, everything else is a score
     assert np.array_equal(np.isnan(scores), A > 0)
+
+
+def _worker_rccl_id_failure(rank, world, port, out_dir):
+    """RcclCollectives when rank 0 cannot produce the ncclUniqueId: the failure travels in the broadcast, EVERY rank raises."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    par = importlib.import_module("filmyou-core_amd.parallel")
+    native = importlib.import_module("filmyou-core_amd._native")
+    par.init_distributed(backend="gloo")
+
+    class _Lib:      # the library with a unique-id call that fails (what a host without librccl sees); nothing else is reached
+        def fy_rccl_unique_id(self, buf):
+            return -9
+
+        def fy_last_error(self):
+            return b"librccl.so could not be opened: injected"
+
+        def fy_rccl_create(self, *a):
+            raise AssertionError("rank %d went on to ncclCommInitRank: it would wait for the others forever" % rank)
+
+    native_load = native.load
+    native.load = lambda: _Lib()
+    try:
+        try:
+            par.RcclCollectives(None, rank, world)
+            verdict = "no error"
+        except RuntimeError as e:
+            verdict = str(e)
+    finally:
+        native.load = native_load
+    with open(os.path.join(out_dir, "verdict_%d.txt" % rank), "w") as f:
+        f.write(verdict)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_rccl_unique_id_failure_reaches_every_rank(tmp_path):
+    world = 2
+    mp.spawn(_worker_rccl_id_failure, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    verdicts = [open(tmp_path / ("verdict_%d.txt" % r)).read() for r in range(world)]
+    assert all("fy_rccl_unique_id" in v and "injected" in v for v in verdicts), verdicts
