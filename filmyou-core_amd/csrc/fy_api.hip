@@ -82,8 +82,9 @@ void fy::load_tuning_from_env(Tuning& t) {
 // another thread) would otherwise build one context's job in another GPU's memory.  The job handle is opaque in this file,
 // so the contexts of live jobs are kept here (fy_rm2_prepare ... fy_rm2_job_destroy).
 namespace {
-std::mutex g_jobs_mu;
-std::unordered_map<const fy_rm2_job*, fy::Context*> g_jobs;
+// (never destroyed: a host may release its last job from a static destructor of its own, after this library's would have run)
+std::mutex& g_jobs_mu = *new std::mutex;
+std::unordered_map<const fy_rm2_job*, fy::Context*>& g_jobs = *new std::unordered_map<const fy_rm2_job*, fy::Context*>;
 fy::Context* job_context(const fy_rm2_job* j) {
     std::lock_guard<std::mutex> g(g_jobs_mu);
     auto it = g_jobs.find(j);
