@@ -1,6 +1,6 @@
 #!/bin/bash
-# First GPU call of the next round, in one piece (about 10 minutes; give gpurun --timeout 900):
-#   /usr/local/graft/bin/gpurun --timeout 900 -- 'bash tools/round5_first_call.sh > gpurun_out/r5_first.log 2>&1; tail -40 gpurun_out/r5_first.log'
+# First GPU call of the next round, in one piece (about 13 minutes; give gpurun --timeout 1100):
+#   /usr/local/graft/bin/gpurun --timeout 1100 -- 'bash tools/round5_first_call.sh > gpurun_out/r5_first.log 2>&1; tail -40 gpurun_out/r5_first.log'
 # 1. the two experiments that were written without GPU time (tools/micro/score_loop.hip incl. its lambda = 0 mode, tools/micro/score_tiled.hip
 #    with what each arrangement fetches); 2. the prepared patches applied ON THE BOX'S COPY of the tree (nothing comes back but gpurun_out/),
 #    the library rebuilt, the gating tests, the bench line.  A step that fails or is killed at its limit ends the call: no GPU step after it.
@@ -40,3 +40,8 @@ d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 print("cold ms per job", round(d["ms_per_step"], 2), " phases", {k: round(v, 2) for k, v in d["phase_ms_rank0"].items()})
 print("regime ms", {k: round(v["ms_per_step"], 1) for k, v in d.get("reference_regime", {}).items() if "ms_per_step" in v})
 PY
+
+step "the precision gate with the patches: every row of the full-size jobs against the fp64 definition, pruned = full pass"
+timeout -k 10 300 python3 -m pytest tests/test_full_size_gpu.py -m gpu -x -q -k "fp64_definition or pruned_equals_full_pass or panel_mode" > $OUT/tests_fullsize.log 2>&1; rc=$?
+tail -6 $OUT/tests_fullsize.log; [ $rc = 0 ] || fail "full-size parity with the patches (rc $rc)"
+echo "ALL STEPS PASSED"
