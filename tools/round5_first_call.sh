@@ -29,7 +29,7 @@ git apply tools/patches/score_body_v2.patch || fail "score_body_v2.patch does no
 git apply tools/patches/topn_select_strided.patch || fail "topn_select_strided.patch does not apply"
 python3 -c "import __graft_entry__ as g; g.build()" > $OUT/build.log 2>&1 || { tail -20 $OUT/build.log; fail "build with the patches"; }
 timeout -k 10 90 python3 -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; rc=$?; tail -2 $OUT/smoke.log | cut -c1-200; [ $rc = 0 ] || fail "smoke with the patches (rc $rc)"
-timeout -k 10 420 python3 -m pytest tests/test_rm2_gpu.py tests/test_pruned_coop_gpu.py tests/test_random_small_gpu.py -m gpu -x -q > $OUT/tests_quick.log 2>&1; rc=$?
+timeout -k 10 420 python3 -m pytest tests/test_rm2_gpu.py tests/test_pruned_coop_gpu.py tests/test_multirank_gpu.py tests/test_random_small_gpu.py -m gpu -x -q > $OUT/tests_quick.log 2>&1; rc=$?
 tail -6 $OUT/tests_quick.log; [ $rc = 0 ] || fail "tests with the patches (rc $rc): no bench"
 
 step "bench with the patches"
